@@ -1,0 +1,120 @@
+"""Pins the CPU oracle of the UNet (oracle/unet_ref.py) to vectors captured from the reference."""
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, rel_l2
+from oracle import unet_ref as R
+
+
+def _module_params(prefix_shapes):
+    return R.closed_form_params(prefix_shapes)
+
+
+def test_param_shapes_match_reference_count():
+    s5 = R.unet_param_shapes(64, 5, 2)
+    s9 = R.unet_param_shapes(64, 9, 2)
+    n5 = sum(int(torch.tensor(v).prod()) for v in s5.values())
+    n9 = sum(int(torch.tensor(v).prod()) for v in s9.values())
+    assert len(s5) == 276
+    assert n5 == 35717314
+    assert n9 == 35729858
+
+
+def test_resblock_modules():
+    g = load_golden("modules_fp32")
+    eps = lambda site, x: 1e-5
+    for tag, ci, co in (("resblock_128_64", 128, 64), ("resblock_64_64", 64, 64)):
+        shapes = {}
+        shapes["mlp.1.weight"] = (co * 2, 256)
+        shapes["mlp.1.bias"] = (co * 2,)
+        for blk, cin in (("block1", ci), ("block2", co)):
+            shapes[f"{blk}.proj.weight"] = (co, cin, 3, 3)
+            shapes[f"{blk}.proj.bias"] = (co,)
+            shapes[f"{blk}.norm.weight"] = (co,)
+            shapes[f"{blk}.norm.bias"] = (co,)
+        if ci != co:
+            shapes["res_conv.weight"] = (co, ci, 1, 1)
+            shapes["res_conv.bias"] = (co,)
+        P = {"m." + k: v for k, v in R.closed_form_params(shapes).items()}
+        y = R.resnet_block(P, "m", g[f"{tag}.x"], g[f"{tag}.temb"], eps, R.q_id)
+        assert rel_l2(y, g[f"{tag}.y"]) < 2e-6, tag
+
+
+def test_attention_modules():
+    g = load_golden("modules_fp32")
+    eps = lambda site, x: 1e-5
+    # Residual(PreNorm(LinearAttention)): state-dict order fn.fn.to_qkv, fn.fn.to_out.0.{w,b}, fn.fn.to_out.1.g, fn.norm.g
+    shapes = {"fn.fn.to_qkv.weight": (384, 64, 1, 1), "fn.fn.to_out.0.weight": (64, 128, 1, 1),
+              "fn.fn.to_out.0.bias": (64,), "fn.fn.to_out.1.g": (1, 64, 1, 1), "fn.norm.g": (1, 64, 1, 1)}
+    P = {"m." + k: v for k, v in R.closed_form_params(shapes).items()}
+    y = R.linear_attention(P, "m", g["linattn_64.x"], eps, R.q_id)
+    assert rel_l2(y, g["linattn_64.y"]) < 2e-6
+    shapes = {"fn.fn.to_qkv.weight": (384, 64, 1, 1), "fn.fn.to_out.weight": (64, 128, 1, 1),
+              "fn.fn.to_out.bias": (64,), "fn.norm.g": (1, 64, 1, 1)}
+    P = {"m." + k: v for k, v in R.closed_form_params(shapes).items()}
+    y = R.attention(P, "m", g["attn_64.x"], eps, R.q_id)
+    assert rel_l2(y, g["attn_64.y"]) < 2e-6
+
+
+def test_resample_modules():
+    g = load_golden("modules_fp32")
+    P = {"m." + k: v for k, v in R.closed_form_params({"1.weight": (128, 256, 1, 1), "1.bias": (128,)}).items()}
+    assert rel_l2(R.downsample(P, "m", g["downsample_64_128.x"], R.q_id), g["downsample_64_128.y"]) < 2e-6
+    P = {"m." + k: v for k, v in R.closed_form_params({"1.weight": (64, 128, 3, 3), "1.bias": (64,)}).items()}
+    assert rel_l2(R.upsample(P, "m", g["upsample_128_64.x"], R.q_id), g["upsample_128_64.y"]) < 2e-6
+    P = R.closed_form_params({"weight": (64, 64, 3, 3), "bias": (64,)})
+    w = R.standardize_weight(P["weight"], 1e-5)
+    y = torch.nn.functional.conv2d(g["wsconv_64_64.x"], w, P["bias"], padding=1)
+    assert rel_l2(y, g["wsconv_64_64.y"]) < 2e-6
+
+
+@pytest.mark.parametrize("tag,ch", [("c5_32x32", 5), ("c9_32x48", 9)])
+def test_unet_end_to_end_fp32(tag, ch):
+    g = load_golden(f"unet_fp32_{tag}")
+    P = R.closed_form_params(R.unet_param_shapes(64, ch, 2))
+    taps = {}
+    with torch.no_grad():
+        y = R.unet_forward(P, g["x"], g["cond"], g["t"], mode="fp32", taps=taps)
+    assert rel_l2(y, g["y"]) < 1e-5
+    for k in g:
+        if k.endswith(".slice"):
+            name = k[len("tap."):-len(".slice")]
+            assert rel_l2(taps[name][:, :4, :6, :6], g[k]) < 1e-5, name
+
+
+@pytest.mark.parametrize("tag,ch", [("c5_32x32", 5), ("c9_32x48", 9)])
+def test_autocast_mode_matches_reference_cpu_autocast(tag, ch):
+    """mode='autocast' under torch.autocast('cpu') vs the reference under the same context:
+    same eps decision at every site (DD:107, DD:122) and the same output."""
+    with open(os.path.join(GOLDEN, f"unet_autocast_eps_{tag}.json")) as f:
+        seen = json.load(f)
+    g = load_golden(f"unet_fp32_{tag}")
+    ga = load_golden(f"unet_autocast_{tag}")
+    P = R.closed_form_params(R.unet_param_shapes(64, ch, 2))
+    trace = {}
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        y = R.unet_forward(P, g["x"], g["cond"], g["t"], mode="autocast", eps_trace=trace)
+    assert set(seen) == set(trace) == set(R.site_eps())
+    for k, v in seen.items():
+        assert trace[k] == pytest.approx(v), k
+    assert rel_l2(y.float(), ga["y"]) < 2e-2
+
+
+@pytest.mark.parametrize("tag,ch", [("c5_32x32", 5), ("c9_32x48", 9)])
+def test_engine_contract_vs_reference_autocast(tag, ch):
+    """bf16c (fp32 math on bf16-stored tensors) vs the reference under bf16 autocast, with the
+    eps table the reference itself used in that (CPU-policy) run: the contract must sit inside
+    the reference's own bf16 noise (~1e-2)."""
+    with open(os.path.join(GOLDEN, f"unet_autocast_eps_{tag}.json")) as f:
+        seen = json.load(f)
+    g = load_golden(f"unet_fp32_{tag}")
+    ga = load_golden(f"unet_autocast_{tag}")
+    P = R.closed_form_params(R.unet_param_shapes(64, ch, 2))
+    with torch.no_grad():
+        y = R.unet_forward(P, g["x"], g["cond"], g["t"], mode="bf16c", eps_table=seen)
+    err_ref = rel_l2(y, ga["y"])
+    print(f"bf16c vs reference autocast rel-L2 = {err_ref:.3e}; autocast vs fp32 = {rel_l2(ga['y'], g['y']):.3e}")
+    assert err_ref < 0.1   # informative: closed-form weights amplify bf16 rounding ~10x vs default init
