@@ -1,0 +1,183 @@
+/* libofd_hip -- C-ABI of the MI355X-native FlowDiffuser hot path (gfx950 only).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  All pointers are
+ * DEVICE pointers unless a parameter says "host".  Every call enqueues work on `stream`
+ * (a hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream) and returns
+ * 0 on success or a negative ofd_status; ofd_last_error() gives the message of the last
+ * failure on the calling thread.  No call synchronises the device.  The caller owns all
+ * buffers; the library owns nothing but the handles it returns.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo,
+ * algorithms/diffusion_animation/):
+ *   softsplat_new.py:255-269,352-423  cuda_launch("softsplat_out")      -> ofd_splat_fwd
+ *   softsplat_new.py:489-565          cuda_launch("softsplat_ingrad")   -> ofd_splat_bwd_in
+ *   softsplat_new.py:600-700          cuda_launch("softsplat_flowgrad") -> ofd_splat_bwd_flow
+ *   warp.py:121-156   warp_forward_flow (NaN handling + holes)          -> ofd_warp_prep / ofd_warp_holes
+ *   warp.py:95-119    warp_backward_flow (2x F.grid_sample + mask)      -> ofd_grid_warp_fwd
+ *   denoising_diffusion.py:363-417    Unet.forward                      -> ofd_unet_forward
+ *   denoising_diffusion.py:666-698    p_mean_variance + p_sample update -> ofd_ddpm_update
+ *   denoising_diffusion.py:750-767    ddim_sample update                -> ofd_ddim_update
+ *   denoising_diffusion.py:806-812    q_sample                          -> ofd_q_sample
+ *   warp.py:260-271 + denoising_diffusion.py:908,973  nan_mse + nanmean -> ofd_nan_mse_sum
+ */
+#ifndef OFD_H
+#define OFD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    OFD_OK = 0,
+    OFD_ERR_ARG = -1,       /* bad shape / null pointer / unsupported configuration */
+    OFD_ERR_HIP = -2,       /* a HIP runtime call failed */
+    OFD_ERR_WORKSPACE = -3, /* workspace too small */
+    OFD_ERR_STATE = -4      /* handle used out of order (e.g. forward before weights) */
+} ofd_status;
+
+int ofd_version(void);               /* (major << 16) | minor */
+const char* ofd_last_error(void);    /* thread-local, never NULL */
+
+/* ---------------------------------------------------------------- forward splat (SS) ------
+ * Tensors are contiguous NCHW fp32.  in: (B,C,H,W), flow: (B,2,H,W) with channel 0 = x
+ * displacement, out: (B,C,H/scale,W/scale).  out is fully overwritten (no zero-fill needed).
+ * radius: half-width in source pixels of the window an output tile scans (>= the expected
+ * max |flow| + 1; samples that land farther are still handled, through a slower list pass).
+ * workspace: ofd_splat_workspace_bytes(B,H,W) bytes. */
+size_t ofd_splat_workspace_bytes(int B, int H, int W);
+int ofd_splat_fwd(const float* in, const float* flow, float* out, int B, int C, int H, int W,
+                  int scale, int offset_x, int offset_y, int radius,
+                  void* workspace, size_t workspace_bytes, void* stream);
+/* optional debug output of softsplat_out's integer corner (x0,y0) per source pixel, int32
+ * (B,H,W,2), -2^30 where the sample is skipped (non-finite).  Used by the index parity tests. */
+int ofd_splat_corners(const float* flow, int32_t* corners, int B, int H, int W,
+                      int scale, int offset_x, int offset_y, void* stream);
+int ofd_splat_bwd_in(const float* flow, const float* outgrad, float* ingrad, int B, int C, int H, int W,
+                     int scale, int offset_x, int offset_y, void* stream);
+int ofd_splat_bwd_flow(const float* in, const float* flow, const float* outgrad, float* flowgrad,
+                       int B, int C, int H, int W, int scale, int offset_x, int offset_y, void* stream);
+
+/* warp_forward_flow pieces (WP:121-156).
+ * prep : first (B,C,H,W) -> ten_in (B,C+1,H,W) = cat(nan_to_zero(first) * w, w), w = 0 where any
+ *        channel of the pixel is NaN else 1.  square != 0 squares the values (get_variance).
+ * holes: splat result (B,C+1,Ho,Wo) -> img (B,C,Ho,Wo); mode 0 = raw sums ("linear_unn"),
+ *        mode 1 = divide by (weight + 1e-7) ("linear"); set_nans != 0 puts NaN where weight <= 0. */
+int ofd_warp_prep(const float* first, float* ten_in, int B, int C, int H, int W, int square, void* stream);
+int ofd_warp_holes(const float* splat, float* img, int B, int C, int Ho, int Wo, int mode, int set_nans, void* stream);
+
+/* ------------------------------------------------------------ grid_sample warp (WP:95-119) -
+ * second: (B,C,H,W), flow: (B,2,H,W) exactly as handed to the reference's warp(mode='backward'):
+ * after its flip(1) channel 1 displaces x and channel 0 displaces y (WP:105-106).
+ * out, mask: (B,C,H,W); mask may be NULL.  bilinear, zeros padding, align_corners=True. */
+int ofd_grid_warp_fwd(const float* second, const float* flow, float* out, float* mask,
+                      int B, int C, int H, int W, void* stream);
+/* integer north-west corner (ix_nw, iy_nw) per pixel, int32 (B,H,W,2): index parity tests. */
+int ofd_grid_warp_corners(const float* flow, int32_t* corners, int B, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------- diffusion elementwise -
+ * x_t, model_out, noise, out: (B,C,H,W) fp32 with n_per_sample = C*H*W.  Coefficients are
+ * per-sample fp32 arrays of length B gathered by the host from the schedule (DD:422-425). */
+int ofd_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac,
+                 float* out, int B, size_t n_per_sample, void* stream);
+/* x_{t-1} = c1*clamp(model_out) + c2*x_t + sigma*noise (sigma = exp(0.5*logvar); pass noise=NULL
+ * or sigma=0 at t == 0).  x_start (clamped model_out) is written when non-NULL. */
+int ofd_ddpm_update(const float* x_t, const float* model_out, const float* noise,
+                    const float* coef1, const float* coef2, const float* sigma,
+                    float* out, float* x_start, int B, size_t n_per_sample, void* stream);
+/* DDIM (DD:750-767): x0 = clamp(model_out); eps = (sr*x_t - x0)/srm1;
+ * out = x0*sqrt_an + c*eps + sigma*noise; last != 0 returns x0. */
+int ofd_ddim_update(const float* x_t, const float* model_out, const float* noise,
+                    const float* sqrt_recip_ac, const float* sqrt_recipm1_ac,
+                    const float* sqrt_alpha_next, const float* c, const float* sigma, int last,
+                    float* out, float* x_start, int B, size_t n_per_sample, void* stream);
+/* sum and count over positions where neither pred nor target is NaN of (pred-target)^2.
+ * result: 2 doubles {sum, count} (device), zeroed by the call. */
+int ofd_nan_mse_sum(const float* pred, const float* target, size_t n, double* result, void* stream);
+
+/* ------------------------------------------------------------------------ UNet (DD:272-417) -
+ * Handle-based executor of the whole forward: one call runs every kernel of the network on
+ * `stream`.  Parameters keep the reference's state-dict names. */
+typedef struct ofd_unet ofd_unet;
+
+typedef struct {
+    int dim;            /* 64 (must be a multiple of 64) */
+    int channels;       /* UNet input channels = x channels + cond channels (5 or 9) */
+    int out_dim;        /* 2 */
+    int eps_mode;       /* 0: eps 1e-5 everywhere (reference precision 32);
+                           1: per-site eps the reference uses under bf16 autocast (DD:107,122) */
+} ofd_unet_config;
+
+int ofd_unet_create(const ofd_unet_config* cfg, ofd_unet** out);
+void ofd_unet_destroy(ofd_unet* u);
+/* number of parameter tensors, and name / element count of the i-th (reference state-dict order) */
+int ofd_unet_num_params(const ofd_unet* u);
+const char* ofd_unet_param_name(const ofd_unet* u, int i);
+size_t ofd_unet_param_numel(const ofd_unet* u, int i);
+/* copy fp32 parameter i from a device buffer (reference layout, e.g. OIHW) into the engine */
+int ofd_unet_set_param(ofd_unet* u, int i, const float* dev_src, size_t numel, void* stream);
+/* weight standardisation + bf16 re-layout of everything set so far; call after set_param */
+int ofd_unet_prepare(ofd_unet* u, void* stream);
+size_t ofd_unet_workspace_bytes(const ofd_unet* u, int B, int H, int W);
+/* x: (B,Cx,H,W) fp32, cond: (B,Cc,H,W) fp32 or NULL (Cx+Cc == channels), t: (B,) int64,
+ * out: (B,out_dim,H,W) fp32.  H and W must be multiples of 8. */
+int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float* cond, int Cc, const int64_t* t,
+                     float* out, int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+/* debug: copy a named intermediate of the LAST forward (e.g. "init_conv", "downs.0.0",
+ * "mid_attn") as NCHW fp32 into dst (numel checked).  Returns OFD_ERR_ARG for unknown names. */
+int ofd_unet_read_tap(ofd_unet* u, const char* name, float* dst, size_t numel, void* stream);
+/* per-kernel-class device time of forwards run with profiling enabled (HIP events on the
+ * stream the kernels are launched on).  classes: see ofd_unet_prof_name(). */
+int ofd_unet_set_profiling(ofd_unet* u, int enabled);
+int ofd_unet_prof_count(const ofd_unet* u);
+const char* ofd_unet_prof_name(const ofd_unet* u, int i);
+/* resolves the recorded events (host-synchronises) -> ms, launches and flops/bytes summed since last reset */
+int ofd_unet_prof_read(ofd_unet* u, int i, double* ms, long long* launches, double* flops, double* bytes);
+int ofd_unet_prof_reset(ofd_unet* u);
+
+/* ---------------------------------------------------------------- single ops (parity tests) -
+ * NHWC bf16 activations (uint16_t* = raw bf16 bits).  These are the kernels the executor
+ * launches, exposed one by one so that each can be checked against the oracle. */
+typedef struct {
+    const void* src;        /* bf16 NHWC */
+    int channels;           /* channels taken from this source (multiple of 64; 7x7: 16) */
+    int src_channels;       /* channel count (pixel stride) of the source tensor */
+    int ch_offset;          /* first channel taken */
+    int upsample;           /* 1: source is (H/2,W/2), read with nearest x2 (DD:91) */
+    int unshuffle;          /* 1: source is (2H,2W); this entry is sub-pixel (p1,p2) of DD:97 */
+    int p1, p2;
+} ofd_conv_src;
+
+typedef struct {
+    int B, H, W;            /* OUTPUT spatial size */
+    int ksize;              /* 1, 3 or 7 */
+    int n_src;              /* 1..4 */
+    ofd_conv_src src[4];
+    int Cout;               /* multiple of 64 */
+    const void* weight;     /* bf16, engine layout (ofd_conv_weight_layout) */
+    const float* bias;      /* fp32 [Cout] or NULL */
+    const float* in_scale;  /* optional prologue: y = silu(x*in_scale[b][c] + in_shift[b][c]) */
+    const float* in_shift;  /* fp32 [B][Cin] */
+    const void* residual;   /* optional epilogue add: bf16 NHWC (B,H,W,Cout) */
+    const void* res_act;    /* optional epilogue add of silu(r*res_scale[b][c] + res_shift[b][c]) */
+    const float* res_scale;
+    const float* res_shift;
+    void* out;              /* bf16 NHWC (B,H,W,Cout) */
+    float* gn_partial;      /* optional: per-tile GroupNorm partial sums, see ofd_conv_gn_partial_count */
+} ofd_conv_args;
+
+int ofd_conv_forward(const ofd_conv_args* a, void* stream);
+size_t ofd_conv_gn_partial_count(int B, int H, int W, int Cout);   /* floats */
+/* OIHW fp32 -> engine bf16 layout [tap][Cin/8][Cout][8]; eps < 0: plain conv, else weight
+ * standardisation with that eps (DD:109-112).  cin_pad: Cin rounded up (7x7: 16).
+ * unshuffle != 0: Cin index is c*4+p1*2+p2 (DD:97) and is regrouped as (p1,p2) major. */
+size_t ofd_conv_weight_elems(int Cout, int Cin_pad, int ksize);
+int ofd_conv_weight_prep(const float* w_oihw, void* w_out, int Cout, int Cin, int Cin_pad, int ksize,
+                         float ws_eps, int unshuffle, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFD_H */

@@ -1,0 +1,472 @@
+// Flow-warp kernels for gfx950: forward splat (scatter, restated from the reference's
+// softsplat_out/_ingrad/_flowgrad, softsplat_new.py:352-700) and the bilinear grid_sample
+// backward warp (warp.py:95-119).  HBM-bound gathers/scatters: no MFMA here.
+//
+// Forward splat design (instead of the reference's one global atomicAdd per corner):
+//   * an output tile of 64x64 pixels x 4 channels is owned by one workgroup and accumulated in
+//     LDS (ds_add_f32); the workgroup scans the source window = tile footprint +- radius, so
+//     flow is read once per pixel (not once per channel) and the output is written once,
+//     coalesced, with no zero-fill pass and no global atomics;
+//   * samples whose corner lands in a tile whose window does not contain them ("far" corners,
+//     |displacement| > radius) are appended to a list by the workgroup that owns the SOURCE
+//     pixel and added with global atomics by a second, normally empty, kernel.
+// This file is compiled with -ffp-contract=off: corner indices must be bit-exact.
+#include "common.h"
+
+namespace ofd {
+
+struct SplatGeom {
+    int B, C, H, W, Ho, Wo, scale, ox, oy, radius, ntx, nty;
+};
+
+constexpr int S_TH = 64, S_TW = 64, S_CG = 4, S_NT = 512;
+constexpr int SKIPPED = -(1 << 30);
+
+// variant 0: forward (SS:374-390), 1: ingrad (SS:515-533), 2: flowgrad (SS:628-647).
+// Same float/double mix as the reference source: the bare 1.0 literals are double.
+template <int VARIANT>
+__device__ __forceinline__ bool splat_remap(float flow_x, float flow_y, int x, int y, const SplatGeom& g,
+                                            float& fx, float& fy, float& dxx, float& dyy) {
+    float fltX = (float)x + flow_x;
+    float fltY = (float)y + flow_y;
+    dxx = 0.0f;
+    dyy = 0.0f;
+    if (!isfinite(fltX) || !isfinite(fltY)) return false;
+    const bool guard = (VARIANT == 0) ? (g.scale > 1) : true;
+    const float fW = (float)g.W, fH = (float)g.H, fs = (float)g.scale, fox = (float)g.ox, foy = (float)g.oy;
+
+    if (guard && (double)fltX >= (double)fW - 1.0) {
+        const float k = (float)((abs(g.ox - (g.W % g.scale))) % g.scale);
+        fltX = (float)((double)fltX + ((double)(fltX - fW) + 1.0) * (double)k);
+        if (VARIANT == 1) fltX = (float)((double)fltX + ((double)(fltX - fW) + 1.0) * (double)fox);
+        fltX = (fltX - fox) / fs;
+    } else if (fltX - fox < 0.0f) {
+        fltX = fltX - fox;
+    } else {
+        fltX = (fltX - fox) / fs;
+        dxx = 1.0f / fs;
+    }
+    if (guard && (double)fltY >= (double)fH - 1.0) {
+        const float k = (VARIANT == 2) ? foy : (float)((abs(g.oy - (g.H % g.scale))) % g.scale);
+        fltY = (float)((double)fltY + ((double)(fltY - fH) + 1.0) * (double)k);
+        fltY = (fltY - foy) / fs;
+    } else if (fltY - foy < 0.0f) {
+        fltY = fltY - foy;
+    } else {
+        fltY = (fltY - foy) / fs;
+        dyy = 1.0f / fs;
+    }
+    fx = fltX;
+    fy = fltY;
+    return true;
+}
+
+__device__ __forceinline__ void corner_weights(float fx, float fy, int x0, int y0, float w[4]) {
+    const float x1 = (float)(x0 + 1), y1 = (float)(y0 + 1), fx0 = (float)x0, fy0 = (float)y0;
+    w[0] = (x1 - fx) * (y1 - fy);     // north-west
+    w[1] = (fx - fx0) * (y1 - fy);    // north-east
+    w[2] = (x1 - fx) * (fy - fy0);    // south-west
+    w[3] = (fx - fx0) * (fy - fy0);   // south-east
+}
+
+// clamp before the int conversion so that huge finite targets cannot overflow (they are out of
+// every tile either way)
+__device__ __forceinline__ int floor_to_int(float v) {
+    v = floorf(v);
+    v = fminf(fmaxf(v, -1.0e9f), 1.0e9f);
+    return (int)v;
+}
+
+// source-footprint interval [lo, hi) of output tile t along one axis
+__device__ __forceinline__ void footprint(int t, int nt, int tile, int scale, int full, int& lo, int& hi) {
+    lo = t * tile * scale;
+    hi = (t == nt - 1) ? full : (t + 1) * tile * scale;
+}
+
+__global__ void __launch_bounds__(S_NT) splat_tile_kernel(const float* __restrict__ in, const float* __restrict__ flow,
+                                                          float* __restrict__ out, unsigned long long* __restrict__ far_list,
+                                                          unsigned int* __restrict__ far_count, unsigned int far_cap,
+                                                          SplatGeom g, int c0, int cg) {
+    __shared__ float acc[S_CG][S_TH][S_TW];
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x, ty = blockIdx.y, n = blockIdx.z;
+    const int X0 = tx * S_TW, Y0 = ty * S_TH;
+
+    for (int i = tid; i < S_CG * S_TH * S_TW; i += S_NT) (&acc[0][0][0])[i] = 0.0f;
+    __syncthreads();
+
+    int fx0, fx1, fy0, fy1;
+    footprint(tx, g.ntx, S_TW, g.scale, g.W, fx0, fx1);
+    footprint(ty, g.nty, S_TH, g.scale, g.H, fy0, fy1);
+    const int wx0 = max(0, fx0 - g.radius), wx1 = min(g.W, fx1 + g.radius);
+    const int wy0 = max(0, fy0 - g.radius), wy1 = min(g.H, fy1 + g.radius);
+    const int ww = wx1 - wx0, wh = wy1 - wy0;
+    const size_t plane = (size_t)g.H * g.W;
+    const float* flow_n = flow + (size_t)n * 2 * plane;
+    const float* in_n = in + ((size_t)n * g.C + c0) * plane;
+
+    for (int p = tid; p < ww * wh; p += S_NT) {
+        const int y = wy0 + p / ww, x = wx0 + p % ww;
+        const size_t pix = (size_t)y * g.W + x;
+        float fx, fy, d0, d1;
+        if (!splat_remap<0>(flow_n[pix], flow_n[plane + pix], x, y, g, fx, fy, d0, d1)) continue;
+        const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
+        const bool own = (x >= fx0) && (x < fx1) && (y >= fy0) && (y < fy1);
+        const int lx0 = x0 - X0, ly0 = y0 - Y0;
+        const bool touches = (lx0 >= -1) && (lx0 < S_TW) && (ly0 >= -1) && (ly0 < S_TH);
+        if (!touches && !own) continue;
+        float w[4];
+        corner_weights(fx, fy, x0, y0, w);
+        if (touches) {
+            float v[S_CG];
+#pragma unroll
+            for (int c = 0; c < S_CG; ++c) v[c] = (c < cg) ? in_n[(size_t)c * plane + pix] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int lx = lx0 + (k & 1), ly = ly0 + (k >> 1);
+                const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+                if (lx >= 0 && lx < S_TW && ly >= 0 && ly < S_TH && cx < g.Wo && cy < g.Ho) {
+#pragma unroll
+                    for (int c = 0; c < S_CG; ++c)
+                        if (c < cg) atomicAdd(&acc[c][ly][lx], v[c] * w[k]);
+                }
+            }
+        }
+        if (own && c0 == 0) {
+            // far corners: in-bounds corners whose owner tile does not scan this source pixel
+            unsigned mask = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+                if (cx < 0 || cx >= g.Wo || cy < 0 || cy >= g.Ho) continue;
+                int lo, hi;
+                footprint(cx / S_TW, g.ntx, S_TW, g.scale, g.W, lo, hi);
+                bool near = (x >= lo - g.radius) && (x < hi + g.radius);
+                footprint(cy / S_TH, g.nty, S_TH, g.scale, g.H, lo, hi);
+                near = near && (y >= lo - g.radius) && (y < hi + g.radius);
+                if (!near) mask |= 1u << k;
+            }
+            if (mask) {
+                const unsigned slot = atomicAdd(far_count, 1u);
+                if (slot < far_cap) far_list[slot] = ((unsigned long long)((size_t)n * plane + pix) << 4) | mask;
+            }
+        }
+    }
+    __syncthreads();
+
+    const size_t oplane = (size_t)g.Ho * g.Wo;
+    float* out_n = out + ((size_t)n * g.C + c0) * oplane;
+    for (int i = tid; i < cg * S_TH * S_TW; i += S_NT) {
+        const int c = i / (S_TH * S_TW), r = (i / S_TW) % S_TH, col = i % S_TW;
+        const int oy_ = Y0 + r, ox_ = X0 + col;
+        if (oy_ < g.Ho && ox_ < g.Wo) out_n[(size_t)c * oplane + (size_t)oy_ * g.Wo + ox_] = acc[c][r][col];
+    }
+}
+
+__global__ void __launch_bounds__(256) splat_far_kernel(const float* __restrict__ in, const float* __restrict__ flow,
+                                                        float* __restrict__ out, const unsigned long long* __restrict__ far_list,
+                                                        const unsigned int* __restrict__ far_count, unsigned int far_cap, SplatGeom g) {
+    const unsigned count = min(*far_count, far_cap);
+    const size_t plane = (size_t)g.H * g.W, oplane = (size_t)g.Ho * g.Wo;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const unsigned long long e = far_list[i];
+        const unsigned mask = (unsigned)(e & 15ull);
+        const size_t lin = (size_t)(e >> 4);
+        const int n = (int)(lin / plane);
+        const size_t pix = lin % plane;
+        const int y = (int)(pix / g.W), x = (int)(pix % g.W);
+        float fx, fy, d0, d1;
+        if (!splat_remap<0>(flow[(size_t)n * 2 * plane + pix], flow[(size_t)n * 2 * plane + plane + pix], x, y, g, fx, fy, d0, d1))
+            continue;
+        const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
+        float w[4];
+        corner_weights(fx, fy, x0, y0, w);
+        for (int c = 0; c < g.C; ++c) {
+            const float v = in[((size_t)n * g.C + c) * plane + pix];
+            for (int k = 0; k < 4; ++k)
+                if (mask & (1u << k))
+                    atomicAdd(&out[((size_t)n * g.C + c) * oplane + (size_t)(y0 + (k >> 1)) * g.Wo + (x0 + (k & 1))], v * w[k]);
+        }
+    }
+}
+
+__global__ void splat_corners_kernel(const float* __restrict__ flow, int32_t* __restrict__ corners, SplatGeom g) {
+    const size_t plane = (size_t)g.H * g.W, total = (size_t)g.B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / plane);
+        const size_t pix = i % plane;
+        const int y = (int)(pix / g.W), x = (int)(pix % g.W);
+        float fx, fy, d0, d1;
+        const bool ok = splat_remap<0>(flow[(size_t)n * 2 * plane + pix], flow[(size_t)n * 2 * plane + plane + pix], x, y, g, fx, fy, d0, d1);
+        corners[2 * i] = ok ? floor_to_int(fx) : SKIPPED;
+        corners[2 * i + 1] = ok ? floor_to_int(fy) : SKIPPED;
+    }
+}
+
+// gather: one thread per source pixel, all channels (flow read once)
+__global__ void __launch_bounds__(256) splat_ingrad_kernel(const float* __restrict__ flow, const float* __restrict__ outgrad,
+                                                           float* __restrict__ ingrad, SplatGeom g) {
+    const size_t plane = (size_t)g.H * g.W, oplane = (size_t)g.Ho * g.Wo, total = (size_t)g.B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / plane);
+        const size_t pix = i % plane;
+        const int y = (int)(pix / g.W), x = (int)(pix % g.W);
+        float fx = 0.0f, fy = 0.0f, d0, d1;
+        const bool ok = splat_remap<1>(flow[(size_t)n * 2 * plane + pix], flow[(size_t)n * 2 * plane + plane + pix], x, y, g, fx, fy, d0, d1);
+        const int x0 = ok ? floor_to_int(fx) : 0, y0 = ok ? floor_to_int(fy) : 0;
+        float w[4];
+        corner_weights(fx, fy, x0, y0, w);
+        for (int c = 0; c < g.C; ++c) {
+            float acc = 0.0f;
+            if (ok) {
+                const float* gp = outgrad + ((size_t)n * g.C + c) * oplane;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+                    if (cx >= 0 && cx < g.Wo && cy >= 0 && cy < g.Ho) acc += gp[(size_t)cy * g.Wo + cx] * w[k];
+                }
+            }
+            ingrad[((size_t)n * g.C + c) * plane + pix] = acc;   // skipped samples keep 0 (SS:468-474)
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) splat_flowgrad_kernel(const float* __restrict__ in, const float* __restrict__ flow,
+                                                             const float* __restrict__ outgrad, float* __restrict__ flowgrad, SplatGeom g) {
+    const size_t plane = (size_t)g.H * g.W, oplane = (size_t)g.Ho * g.Wo, total = (size_t)g.B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / plane);
+        const size_t pix = i % plane;
+        const int y = (int)(pix / g.W), x = (int)(pix % g.W);
+        float fx, fy, dxx, dyy;
+        const bool ok = splat_remap<2>(flow[(size_t)n * 2 * plane + pix], flow[(size_t)n * 2 * plane + plane + pix], x, y, g, fx, fy, dxx, dyy);
+        float gx = 0.0f, gy = 0.0f;
+        if (ok) {
+            const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
+            const float x1 = (float)(x0 + 1), y1 = (float)(y0 + 1);
+            // SS:661-675: channel 0 uses the y-weights and dfltYY, channel 1 the x-weights and dfltXX
+            const float wx[4] = {-1.0f * (y1 - fy), +1.0f * (y1 - fy), -1.0f * (fy - (float)y0), +1.0f * (fy - (float)y0)};
+            const float wy[4] = {(x1 - fx) * -1.0f, (fx - (float)x0) * -1.0f, (x1 - fx) * +1.0f, (fx - (float)x0) * +1.0f};
+            for (int c = 0; c < g.C; ++c) {
+                const float v = in[((size_t)n * g.C + c) * plane + pix];
+                const float* gp = outgrad + ((size_t)n * g.C + c) * oplane;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+                    if (cx >= 0 && cx < g.Wo && cy >= 0 && cy < g.Ho) {
+                        const float go = gp[(size_t)cy * g.Wo + cx];
+                        gx += go * v * wx[k] * dyy;
+                        gy += go * v * wy[k] * dxx;
+                    }
+                }
+            }
+        }
+        flowgrad[(size_t)n * 2 * plane + pix] = gx;
+        flowgrad[(size_t)n * 2 * plane + plane + pix] = gy;
+    }
+}
+
+__global__ void __launch_bounds__(256) warp_prep_kernel(const float* __restrict__ first, float* __restrict__ ten_in,
+                                                        int B, int C, size_t plane, int square) {
+    const size_t total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / plane, pix = i % plane;
+        bool any_nan = false;
+        for (int c = 0; c < C; ++c) any_nan |= isnan(first[(n * C + c) * plane + pix]);
+        const float w = any_nan ? 0.0f : 1.0f;
+        for (int c = 0; c < C; ++c) {
+            float v = first[(n * C + c) * plane + pix];
+            v = isnan(v) ? 0.0f : v;
+            if (square) v = v * v;
+            ten_in[(n * (C + 1) + c) * plane + pix] = v * w;
+        }
+        ten_in[(n * (C + 1) + C) * plane + pix] = w;
+    }
+}
+
+__global__ void __launch_bounds__(256) warp_holes_kernel(const float* __restrict__ splat, float* __restrict__ img,
+                                                         int B, int C, size_t plane, int mode, int set_nans) {
+    const size_t total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / plane, pix = i % plane;
+        const float w = splat[(n * (C + 1) + C) * plane + pix];
+        for (int c = 0; c < C; ++c) {
+            float v = splat[(n * (C + 1) + c) * plane + pix];
+            if (mode == 1) v = v / (w + 0.0000001f);
+            if (set_nans && !(w > 0.0f)) v = __uint_as_float(0x7fc00000u);
+            img[(n * C + c) * plane + pix] = v;
+        }
+    }
+}
+
+// ---- grid_sample backward warp (WP:95-119): exact op order of the reference expression -------
+__device__ __forceinline__ void grid_coords(float flow_c0, float flow_c1, int x, int y, int H, int W, float& ix, float& iy) {
+    // flow.flip(1): channel 1 displaces x, channel 0 displaces y (WP:105-106)
+    const float gx = (float)x + flow_c1;
+    const float gy = (float)y + flow_c0;
+    const float vx = 2.0f * gx / (float)max(W - 1, 1) - 1.0f;       // WP:108
+    const float vy = 2.0f * gy / (float)max(H - 1, 1) - 1.0f;       // WP:109
+    ix = ((vx + 1.0f) / 2.0f) * (float)(W - 1);                       // ATen align_corners un-normalise
+    iy = ((vy + 1.0f) / 2.0f) * (float)(H - 1);
+}
+
+__global__ void __launch_bounds__(256) grid_warp_kernel(const float* __restrict__ second, const float* __restrict__ flow,
+                                                        float* __restrict__ out, float* __restrict__ mask, int B, int C, int H, int W) {
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / plane, pix = i % plane;
+        const int y = (int)(pix / W), x = (int)(pix % W);
+        float ix, iy;
+        grid_coords(flow[n * 2 * plane + pix], flow[n * 2 * plane + plane + pix], x, y, H, W, ix, iy);
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        const float w_nw = (fx0 + 1.0f - ix) * (fy0 + 1.0f - iy), w_ne = (ix - fx0) * (fy0 + 1.0f - iy);
+        const float w_sw = (fx0 + 1.0f - ix) * (iy - fy0), w_se = (ix - fx0) * (iy - fy0);
+        const float w[4] = {w_nw, w_ne, w_sw, w_se};
+        // NaN / huge coordinates: every corner is out of bounds
+        const bool finite = fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
+        const int x0 = finite ? (int)fx0 : -10, y0 = finite ? (int)fy0 : -10;
+        bool inb[4];
+        float msum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+            inb[k] = cx >= 0 && cx < W && cy >= 0 && cy < H;
+            if (inb[k]) msum += w[k];
+        }
+        float m = msum;
+        if (m < 0.999f) m = 0.0f;                                   // WP:116-117
+        if (m > 0.0f) m = 1.0f;
+        for (int c = 0; c < C; ++c) {
+            const float* sp = second + (n * C + c) * plane;
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (inb[k]) acc += sp[(size_t)(y0 + (k >> 1)) * W + (x0 + (k & 1))] * w[k];
+            out[(n * C + c) * plane + pix] = acc;
+            if (mask) mask[(n * C + c) * plane + pix] = m;
+        }
+    }
+}
+
+__global__ void grid_warp_corners_kernel(const float* __restrict__ flow, int32_t* __restrict__ corners, int B, int H, int W) {
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / plane, pix = i % plane;
+        float ix, iy;
+        grid_coords(flow[n * 2 * plane + pix], flow[n * 2 * plane + plane + pix], (int)(pix % W), (int)(pix / W), H, W, ix, iy);
+        corners[2 * i] = floor_to_int(ix);
+        corners[2 * i + 1] = floor_to_int(iy);
+    }
+}
+
+static int make_geom(SplatGeom& g, int B, int C, int H, int W, int scale, int ox, int oy, int radius) {
+    OFD_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0, "splat: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
+    OFD_CHECK_ARG(scale >= 1 && H / scale > 0 && W / scale > 0, "splat: bad scale %d for %dx%d", scale, H, W);
+    OFD_CHECK_ARG(ox >= 0 && oy >= 0 && ox < scale && oy < scale, "splat: offset (%d,%d) must be in [0,scale)", ox, oy);
+    OFD_CHECK_ARG((size_t)B * H * W < (1ull << 31), "splat: B*H*W must be < 2^31");
+    g = SplatGeom{B, C, H, W, H / scale, W / scale, scale, ox, oy, radius < 0 ? 0 : radius, 0, 0};
+    g.ntx = cdiv(g.Wo, S_TW);
+    g.nty = cdiv(g.Ho, S_TH);
+    return OFD_OK;
+}
+
+static inline int stream_grid(size_t total, int block) {
+    size_t b = (total + block - 1) / block;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace ofd
+
+using namespace ofd;
+
+extern "C" size_t ofd_splat_workspace_bytes(int B, int H, int W) {
+    return 16 + sizeof(unsigned long long) * (size_t)B * H * W;
+}
+
+extern "C" int ofd_splat_fwd(const float* in, const float* flow, float* out, int B, int C, int H, int W, int scale,
+                             int offset_x, int offset_y, int radius, void* workspace, size_t workspace_bytes, void* stream) {
+    SplatGeom g;
+    int rc = make_geom(g, B, C, H, W, scale, offset_x, offset_y, radius);
+    if (rc) return rc;
+    OFD_CHECK_ARG(in && flow && out && workspace, "splat_fwd: null pointer");
+    OFD_CHECK_ARG(g.nty <= 65535 && B <= 65535, "splat_fwd: grid too large");
+    if (workspace_bytes < ofd_splat_workspace_bytes(B, H, W)) {
+        set_error("splat_fwd: workspace %zu < %zu", workspace_bytes, ofd_splat_workspace_bytes(B, H, W));
+        return OFD_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int* count = (unsigned int*)workspace;
+    unsigned long long* list = (unsigned long long*)((char*)workspace + 16);
+    const unsigned cap = (unsigned)((size_t)B * H * W);
+    OFD_HIP(hipMemsetAsync(count, 0, 16, s));
+    for (int c0 = 0; c0 < C; c0 += S_CG) {
+        const int cg = (C - c0 < S_CG) ? (C - c0) : S_CG;
+        splat_tile_kernel<<<dim3(g.ntx, g.nty, B), S_NT, 0, s>>>(in, flow, out, list, count, cap, g, c0, cg);
+    }
+    splat_far_kernel<<<256, 256, 0, s>>>(in, flow, out, list, count, cap, g);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" int ofd_splat_corners(const float* flow, int32_t* corners, int B, int H, int W, int scale, int offset_x,
+                                 int offset_y, void* stream) {
+    SplatGeom g;
+    int rc = make_geom(g, B, 1, H, W, scale, offset_x, offset_y, 0);
+    if (rc) return rc;
+    OFD_CHECK_ARG(flow && corners, "splat_corners: null pointer");
+    splat_corners_kernel<<<stream_grid((size_t)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(flow, corners, g);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" int ofd_splat_bwd_in(const float* flow, const float* outgrad, float* ingrad, int B, int C, int H, int W,
+                                int scale, int offset_x, int offset_y, void* stream) {
+    SplatGeom g;
+    int rc = make_geom(g, B, C, H, W, scale, offset_x, offset_y, 0);
+    if (rc) return rc;
+    OFD_CHECK_ARG(flow && outgrad && ingrad, "splat_bwd_in: null pointer");
+    splat_ingrad_kernel<<<stream_grid((size_t)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(flow, outgrad, ingrad, g);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" int ofd_splat_bwd_flow(const float* in, const float* flow, const float* outgrad, float* flowgrad, int B,
+                                  int C, int H, int W, int scale, int offset_x, int offset_y, void* stream) {
+    SplatGeom g;
+    int rc = make_geom(g, B, C, H, W, scale, offset_x, offset_y, 0);
+    if (rc) return rc;
+    OFD_CHECK_ARG(in && flow && outgrad && flowgrad, "splat_bwd_flow: null pointer");
+    splat_flowgrad_kernel<<<stream_grid((size_t)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(in, flow, outgrad, flowgrad, g);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" int ofd_warp_prep(const float* first, float* ten_in, int B, int C, int H, int W, int square, void* stream) {
+    OFD_CHECK_ARG(first && ten_in && B > 0 && C > 0 && H > 0 && W > 0, "warp_prep: bad argument");
+    warp_prep_kernel<<<stream_grid((size_t)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(first, ten_in, B, C, (size_t)H * W, square);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" int ofd_warp_holes(const float* splat, float* img, int B, int C, int Ho, int Wo, int mode, int set_nans, void* stream) {
+    OFD_CHECK_ARG(splat && img && B > 0 && C > 0 && Ho > 0 && Wo > 0, "warp_holes: bad argument");
+    OFD_CHECK_ARG(mode == 0 || mode == 1, "warp_holes: mode must be 0 (linear_unn) or 1 (linear)");
+    warp_holes_kernel<<<stream_grid((size_t)B * Ho * Wo, 256), 256, 0, (hipStream_t)stream>>>(splat, img, B, C, (size_t)Ho * Wo, mode, set_nans);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" int ofd_grid_warp_fwd(const float* second, const float* flow, float* out, float* mask, int B, int C, int H,
+                                 int W, void* stream) {
+    OFD_CHECK_ARG(second && flow && out && B > 0 && C > 0 && H > 0 && W > 0, "grid_warp_fwd: bad argument");
+    grid_warp_kernel<<<stream_grid((size_t)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(second, flow, out, mask, B, C, H, W);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" int ofd_grid_warp_corners(const float* flow, int32_t* corners, int B, int H, int W, void* stream) {
+    OFD_CHECK_ARG(flow && corners && B > 0 && H > 0 && W > 0, "grid_warp_corners: bad argument");
+    grid_warp_corners_kernel<<<stream_grid((size_t)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(flow, corners, B, H, W);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}

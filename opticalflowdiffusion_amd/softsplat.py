@@ -1,0 +1,109 @@
+"""Forward splatting (mirror of the reference's softsplat_new.py interface) on the HIP kernels.
+
+``softsplat(tenIn, tenFlow, tenMetric, strMode, scale, offset)`` keeps the reference signature
+and modes (softsplat_new.py:278-333); the three CUDA kernels it JIT-compiled through CuPy are
+replaced by ``ofd_splat_fwd`` / ``ofd_splat_bwd_in`` / ``ofd_splat_bwd_flow``.
+"""
+import torch
+
+from . import _lib as L
+
+# scan radius (source pixels) of an output tile; FlowDiffuser clamps flow to +-flow_max = 20 px
+# (flow_diffuser.py:141). Larger displacements stay correct through the far-corner list.
+DEFAULT_RADIUS = 24
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes):
+    key = (device.index,)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def splat_forward(ten_in, ten_flow, scale=1, offset_x=0, offset_y=0, radius=DEFAULT_RADIUS):
+    """softsplat_func.forward (softsplat_new.py:339-454) without autograd."""
+    L.require_gpu(ten_in, ten_flow)
+    ten_in, ten_flow = L.f32c(ten_in), L.f32c(ten_flow)
+    B, C, H, W = ten_in.shape
+    if ten_flow.shape != (B, 2, H, W):
+        raise L.OfdError(f"flow must be (B,2,H,W) = {(B, 2, H, W)}, got {tuple(ten_flow.shape)}")
+    out = torch.empty(B, C, H // scale, W // scale, dtype=torch.float32, device=ten_in.device)
+    nbytes = L.lib().ofd_splat_workspace_bytes(B, H, W)
+    ws = _workspace(ten_in.device, nbytes)
+    L.check(L.lib().ofd_splat_fwd(L.ptr(ten_in), L.ptr(ten_flow), L.ptr(out), B, C, H, W, scale, offset_x, offset_y,
+                                  radius, L.ptr(ws), ws.numel(), L.stream()))
+    return out
+
+
+def splat_corners(ten_flow, scale=1, offset_x=0, offset_y=0):
+    """int32 (B,H,W,2) north-west corner (x0,y0) of softsplat_out per source pixel (parity tests)."""
+    L.require_gpu(ten_flow)
+    ten_flow = L.f32c(ten_flow)
+    B, _, H, W = ten_flow.shape
+    out = torch.empty(B, H, W, 2, dtype=torch.int32, device=ten_flow.device)
+    L.check(L.lib().ofd_splat_corners(L.ptr(ten_flow), L.ptr(out), B, H, W, scale, offset_x, offset_y, L.stream()))
+    return out
+
+
+class softsplat_func(torch.autograd.Function):
+    """softsplat_new.py:339-730.  Inputs are cast to fp32 as the reference's custom_fwd does."""
+
+    @staticmethod
+    def forward(ctx, tenIn, tenFlow, scale, offset_x, offset_y):
+        tenIn, tenFlow = L.f32c(tenIn), L.f32c(tenFlow)
+        out = splat_forward(tenIn, tenFlow, scale, offset_x, offset_y)
+        ctx.save_for_backward(tenIn, tenFlow)
+        ctx.geom = (scale, offset_x, offset_y)
+        return out
+
+    @staticmethod
+    def backward(ctx, tenOutgrad):
+        tenIn, tenFlow = ctx.saved_tensors
+        scale, ox, oy = ctx.geom
+        g = L.f32c(tenOutgrad)
+        B, C, H, W = tenIn.shape
+        ingrad = flowgrad = None
+        if ctx.needs_input_grad[0]:
+            ingrad = torch.empty_like(tenIn)
+            L.check(L.lib().ofd_splat_bwd_in(L.ptr(tenFlow), L.ptr(g), L.ptr(ingrad), B, C, H, W, scale, ox, oy, L.stream()))
+        if ctx.needs_input_grad[1]:
+            flowgrad = torch.empty_like(tenFlow)
+            L.check(L.lib().ofd_splat_bwd_flow(L.ptr(tenIn), L.ptr(tenFlow), L.ptr(g), L.ptr(flowgrad), B, C, H, W,
+                                               scale, ox, oy, L.stream()))
+        return ingrad, flowgrad, None, None, None
+
+
+def softsplat(tenIn, tenFlow, tenMetric, strMode, scale=1, offset=(0, 0)):
+    """softsplat_new.py:278-333 (same modes, same assertions)."""
+    base = strMode.split("-")[0]
+    assert base in ["sum", "avg", "linear", "soft", "linear_unn"]
+    if strMode in ("sum", "avg"):
+        assert tenMetric is None
+    if base in ("linear", "linear_unn", "soft"):
+        assert tenMetric is not None
+
+    if strMode == "avg":
+        tenIn = torch.cat([tenIn, tenIn.new_ones([tenIn.shape[0], 1, tenIn.shape[2], tenIn.shape[3]])], 1)
+    elif base in ("linear", "linear_unn"):
+        tenIn = torch.cat([tenIn * tenMetric, tenMetric], 1)
+    elif base == "soft":
+        tenIn = torch.cat([tenIn * tenMetric.exp(), tenMetric.exp()], 1)
+
+    tenOut = softsplat_func.apply(tenIn, tenFlow, scale, offset[0], offset[1])
+
+    if base in ["avg", "linear", "soft"]:
+        tenNormalize = tenOut[:, -1:, :, :]
+        parts = strMode.split("-")
+        if len(parts) == 1 or parts[1] == "addeps":
+            tenNormalize = tenNormalize + 0.0000001
+        elif parts[1] == "zeroeps":
+            tenNormalize = tenNormalize.clone()
+            tenNormalize[tenNormalize == 0.0] = 1.0
+        elif parts[1] == "clipeps":
+            tenNormalize = tenNormalize.clip(0.0000001, None)
+        return torch.cat((tenOut[:, :-1, :, :] / tenNormalize, tenOut[:, -1, None, :, :]), dim=1)
+    return tenOut

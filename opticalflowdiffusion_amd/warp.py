@@ -1,0 +1,140 @@
+"""Warp layer with the reference's interface (algorithms/diffusion_animation/warp.py, rep='flow').
+
+``warp(first, second, flow, rep='flow', mode='backward'|'forward', **kw)`` -- WP:83-93.
+  forward  -> warp_forward_flow  (WP:121-156): NaN-aware forward splat through the HIP splat kernels
+  backward -> warp_backward_flow (WP:95-119) : bilinear grid_sample gather + validity mask
+rep='filter' (FlowLearner / MatrixFlow only) is outside the FlowDiffuser path and raises.
+"""
+import torch
+
+from . import _lib as L
+from .softsplat import softsplat_func, splat_forward
+
+
+class _WarpForward(torch.autograd.Function):
+    """warp_forward_flow with warp_style in {"sum","linear"}: prep -> splat -> holes, three HIP
+    launches; gradients flow to `first` and `flow` through the reference's backward kernels."""
+
+    @staticmethod
+    def forward(ctx, first, flow, scale, ox, oy, set_nans, linear, square):
+        first, flow = L.f32c(first), L.f32c(flow)
+        B, C, H, W = first.shape
+        lib = L.lib()
+        ten_in = torch.empty(B, C + 1, H, W, dtype=torch.float32, device=first.device)
+        L.check(lib.ofd_warp_prep(L.ptr(first), L.ptr(ten_in), B, C, H, W, int(square), L.stream()))
+        ten_out = splat_forward(ten_in, flow, scale, ox, oy)
+        Ho, Wo = ten_out.shape[-2:]
+        img = torch.empty(B, C, Ho, Wo, dtype=torch.float32, device=first.device)
+        L.check(lib.ofd_warp_holes(L.ptr(ten_out), L.ptr(img), B, C, Ho, Wo, int(linear), int(set_nans), L.stream()))
+        ctx.save_for_backward(ten_in, flow, ten_out)
+        ctx.cfg = (scale, ox, oy, set_nans, linear, square)
+        return img
+
+    @staticmethod
+    def backward(ctx, g_img):
+        ten_in, flow, ten_out = ctx.saved_tensors
+        scale, ox, oy, set_nans, linear, square = ctx.cfg
+        if square:
+            raise L.OfdError("get_variance=True is not differentiable in this build")
+        B, C1, H, W = ten_in.shape
+        C = C1 - 1
+        g_img = L.f32c(g_img)
+        w = ten_out[:, -1:]
+        if set_nans:                                  # torch.where(weights > 0, img, nan) (WP:154-155)
+            g_img = torch.where(w > 0, g_img, torch.zeros_like(g_img))
+        g_out = torch.zeros_like(ten_out)
+        if linear:                                    # img = sum / (w + 1e-7)
+            denom = w + 0.0000001
+            g_out[:, :C] = g_img / denom
+            g_out[:, C:] = -(g_img * ten_out[:, :C] / (denom * denom)).sum(1, keepdim=True)
+        else:
+            g_out[:, :C] = g_img
+        lib = L.lib()
+        g_first = g_flow = None
+        if ctx.needs_input_grad[0]:
+            g_in = torch.empty_like(ten_in)
+            L.check(lib.ofd_splat_bwd_in(L.ptr(flow), L.ptr(g_out), L.ptr(g_in), B, C1, H, W, scale, ox, oy, L.stream()))
+            # ten_in[:, :C] = nan_to_zero(first) * w_in: gradient reaches `first` where w_in == 1
+            g_first = g_in[:, :C] * ten_in[:, C:]
+        if ctx.needs_input_grad[1]:
+            g_flow = torch.empty_like(flow)
+            L.check(lib.ofd_splat_bwd_flow(L.ptr(ten_in), L.ptr(flow), L.ptr(g_out), L.ptr(g_flow), B, C1, H, W,
+                                           scale, ox, oy, L.stream()))
+        return g_first, g_flow, None, None, None, None, None, None
+
+
+def warp_forward_flow(first, second, flow, scale=1, set_nans=True, get_variance=False, offset=[0, 0], warp_style="sum"):
+    """WP:121-156."""
+    L.require_gpu(first, flow)
+    offset = [o % scale for o in offset]
+    linear = warp_style != "sum"
+    img = _WarpForward.apply(first, flow, scale, offset[0], offset[1], bool(set_nans) and not get_variance, linear, False)
+    if get_variance:                                  # WP:142-152: splat(x^2) - splat(x)^2
+        var = _WarpForward.apply(first, flow, scale, offset[0], offset[1], False, False, True)
+        img = var - torch.square(img)
+        if set_nans:                                  # holes of the NaN-aware weights (WP:154-155)
+            valid = (~torch.isnan(first).any(dim=1, keepdim=True)).float()
+            w = _WarpForward.apply(valid, flow, scale, offset[0], offset[1], False, False, False)
+            img = torch.where(w > 0, img, torch.full_like(img, float("nan")))
+    return img
+
+
+def warp_backward_flow(first, second, flow):
+    """WP:95-119: returns (output, mask)."""
+    L.require_gpu(second, flow)
+    if second.requires_grad or flow.requires_grad:
+        raise L.OfdError("warp(mode='backward') is forward-only in this build (FlowDiffuser never differentiates it)")
+    second, flow = L.f32c(second), L.f32c(flow)
+    B, C, H, W = second.shape
+    out = torch.empty_like(second)
+    mask = torch.empty_like(second)
+    L.check(L.lib().ofd_grid_warp_fwd(L.ptr(second), L.ptr(flow), L.ptr(out), L.ptr(mask), B, C, H, W, L.stream()))
+    return out, mask
+
+
+def grid_warp_corners(flow):
+    L.require_gpu(flow)
+    flow = L.f32c(flow)
+    B, _, H, W = flow.shape
+    out = torch.empty(B, H, W, 2, dtype=torch.int32, device=flow.device)
+    L.check(L.lib().ofd_grid_warp_corners(L.ptr(flow), L.ptr(out), B, H, W, L.stream()))
+    return out
+
+
+def warp(first, second, flow, rep="flow", mode="backward", **kwargs):
+    """WP:83-93."""
+    if rep != "flow":
+        raise NotImplementedError("rep='filter' belongs to FlowLearner/MatrixFlow, outside the FlowDiffuser path")
+    if mode == "backward":
+        return warp_backward_flow(first, second, flow, **kwargs)
+    elif mode == "forward":
+        return warp_forward_flow(first, second, flow, **kwargs)
+    raise ValueError(f"unknown warp mode {mode!r}")
+
+
+def nan_mse(pred, target, reduction="mean"):
+    """WP:260-271.  reduction='mean' runs the fused HIP reduction; 'none' returns the compacted
+    squared errors (dynamic shape, as the reference)."""
+    if reduction == "mean" and not (pred.requires_grad or target.requires_grad):
+        L.require_gpu(pred, target)
+        p, t = L.f32c(pred).flatten(), L.f32c(target).flatten()
+        res = torch.empty(2, dtype=torch.float64, device=p.device)
+        L.check(L.lib().ofd_nan_mse_sum(L.ptr(p), L.ptr(t), p.numel(), L.ptr(res), L.stream()))
+        return (res[0] / res[1]).float()
+    pred, target = pred.flatten(), target.flatten()
+    ok = torch.logical_not(torch.logical_or(torch.isnan(target), torch.isnan(pred)))
+    sq = torch.square(pred[ok] - target[ok])
+    return torch.nanmean(sq) if reduction == "mean" else sq
+
+
+def scale(img, up=None, down=None):
+    """WP:234-243."""
+    if up is not None and down is not None:
+        raise ValueError("one of up or down")
+    if up is not None:
+        return torch.nn.functional.interpolate(img, scale_factor=up, mode="bilinear")
+    if down is not None:
+        b, c, h, w = img.shape
+        p = img.reshape(b, c, h // down, down, w // down, down)
+        return torch.mean(torch.mean(p, dim=-1), dim=-2)
+    return img

@@ -1,0 +1,247 @@
+"""GPU parity of the flow-warp kernels (through the C-ABI) against the CPU oracle and the
+reference goldens.  Corner indices must be bit-exact, values within fp32 summation-order noise."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+from oracle import warp_ref as WR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ofd():
+    import opticalflowdiffusion_amd as m
+    from opticalflowdiffusion_amd import _lib
+    _lib.lib()          # fails loudly if the HIP library is missing
+    return m
+
+
+def _flows(B, H, W, seed, mag):
+    g = torch.Generator().manual_seed(seed)
+    real = (torch.rand(B, 2, H, W, generator=g) * 2 - 1) * mag
+    integer = torch.randint(-int(mag), int(mag) + 1, (B, 2, H, W), generator=g).float()
+    mixed = torch.where(torch.rand(B, 2, H, W, generator=g) < 0.5, integer, real)
+    return {"real": real, "int": integer, "mixed": mixed}
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 40, 72), (1, 3, 130, 200), (3, 1, 64, 64), (1, 7, 33, 47)])
+@pytest.mark.parametrize("kind", ["real", "int", "mixed"])
+def test_splat_forward_scale1(ofd, shape, kind):
+    from opticalflowdiffusion_amd.softsplat import splat_forward, splat_corners
+    B, C, H, W = shape
+    torch.manual_seed(1)
+    img = torch.rand(B, C, H, W)
+    flow = _flows(B, H, W, 2, 9.0)[kind]
+    ref, ref_c = WR.splat_out(img, flow, return_corners=True)
+    out = splat_forward(img.cuda(), flow.cuda()).cpu()
+    corners = splat_corners(flow.cuda()).cpu()
+    assert torch.equal(corners, ref_c)                       # integer grid indexing: bit-exact
+    assert float((out - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    assert rel_l2(out, ref) < 1e-6
+
+
+@pytest.mark.parametrize("scale,off", [(2, (0, 0)), (2, (1, 1)), (4, (3, 1)), (8, (5, 2)), (16, (0, 7))])
+def test_splat_forward_pyramid_scales(ofd, scale, off):
+    from opticalflowdiffusion_amd.softsplat import splat_forward, splat_corners
+    torch.manual_seed(3)
+    B, C, H, W = 2, 4, 96, 144
+    img = torch.rand(B, C, H, W)
+    flow = _flows(B, H, W, 4, 6.0)["mixed"]
+    ref, ref_c = WR.splat_out(img, flow, scale, off[0], off[1], return_corners=True)
+    out = splat_forward(img.cuda(), flow.cuda(), scale, off[0], off[1]).cpu()
+    assert torch.equal(splat_corners(flow.cuda(), scale, off[0], off[1]).cpu(), ref_c)
+    assert rel_l2(out, ref) < 1e-6
+
+
+def test_splat_far_displacements_and_nonfinite(ofd):
+    """|flow| far beyond the tile radius goes through the far-corner list; inf/NaN flow is skipped."""
+    from opticalflowdiffusion_amd.softsplat import splat_forward
+    torch.manual_seed(5)
+    B, C, H, W = 2, 3, 150, 260
+    img = torch.rand(B, C, H, W)
+    flow = (torch.rand(B, 2, H, W) * 2 - 1) * 120.0
+    flow[0, 0, 3, 5] = float("inf")
+    flow[1, 1, 9, 9] = float("nan")
+    ref = WR.splat_out(img, flow)
+    for radius in (0, 8, 24, 400):
+        out = splat_forward(img.cuda(), flow.cuda(), radius=radius).cpu()
+        assert rel_l2(out, ref) < 1e-6, radius
+
+
+def test_splat_backward_kernels(ofd):
+    from opticalflowdiffusion_amd._lib import lib, check, ptr, stream
+    torch.manual_seed(6)
+    B, C, H, W = 2, 4, 48, 80
+    img = torch.rand(B, C, H, W)
+    for scale, off, mag in ((1, (0, 0), 5.0), (2, (1, 0), 5.0), (4, (2, 3), 30.0)):
+        flow = _flows(B, H, W, 7, mag)["mixed"]
+        gout = torch.rand(B, C, H // scale, W // scale)
+        ref_in = WR.splat_ingrad(flow, gout, img.shape, scale, off[0], off[1])
+        ref_fl = WR.splat_flowgrad(img, flow, gout, scale, off[0], off[1])
+        d_img, d_flow, d_g = img.cuda(), flow.cuda(), gout.cuda()
+        g_in = torch.empty_like(d_img)
+        g_fl = torch.empty_like(d_flow)
+        check(lib().ofd_splat_bwd_in(ptr(d_flow), ptr(d_g), ptr(g_in), B, C, H, W, scale, off[0], off[1], stream()))
+        check(lib().ofd_splat_bwd_flow(ptr(d_img), ptr(d_flow), ptr(d_g), ptr(g_fl), B, C, H, W, scale, off[0], off[1], stream()))
+        assert rel_l2(g_in.cpu(), ref_in) < 1e-6, scale
+        assert rel_l2(g_fl.cpu(), ref_fl) < 1e-5, scale
+
+
+def test_softsplat_modes_and_autograd(ofd):
+    torch.manual_seed(8)
+    B, C, H, W = 1, 3, 24, 40
+    img = torch.rand(B, C, H, W)
+    flow = _flows(B, H, W, 9, 3.0)["real"]
+    metric = torch.rand(B, 1, H, W)
+    for mode, m in (("sum", None), ("avg", None), ("linear", metric), ("linear_unn", metric), ("soft", metric),
+                    ("linear-zeroeps", metric), ("linear-clipeps", metric)):
+        ref = WR.softsplat(img, flow, m, mode)
+        out = ofd.softsplat(img.cuda(), flow.cuda(), None if m is None else m.cuda(), mode).cpu()
+        assert rel_l2(out, ref) < 1e-6, mode
+    a = img.cuda().requires_grad_(True)
+    f = flow.cuda().requires_grad_(True)
+    out = ofd.softsplat(a, f, None, "sum")
+    gout = torch.rand_like(out)
+    out.backward(gout)
+    assert rel_l2(a.grad.cpu(), WR.splat_ingrad(flow, gout.cpu(), img.shape)) < 1e-6
+    assert rel_l2(f.grad.cpu(), WR.splat_flowgrad(img, flow, gout.cpu())) < 1e-5
+
+
+def test_warp_forward_wrapper(ofd):
+    """warp(mode='forward') incl. NaN inputs, holes, scale/offset and warp_style (WP:121-156)."""
+    torch.manual_seed(10)
+    B, C, H, W = 2, 3, 64, 96
+    img = torch.rand(B, C, H, W) * 2 - 1
+    img[0, 1, 5, 7] = float("nan")
+    img[1, :, 20, 30] = float("nan")
+    flow = _flows(B, H, W, 11, 12.0)["mixed"]
+    for kw in ({}, {"scale": 2}, {"scale": 4, "offset": [5, 2]}, {"set_nans": False}, {"warp_style": "linear"},
+               {"get_variance": True}):
+        ref = WR.warp(img, None, flow, mode="forward", **kw)
+        out = ofd.warp(img.cuda(), None, flow.cuda(), mode="forward", **kw).cpu()
+        assert torch.equal(torch.isnan(out), torch.isnan(ref)), kw
+        ok = ~torch.isnan(ref)
+        assert float((out[ok] - ref[ok]).abs().max()) < 2e-5, kw
+
+
+def test_warp_test_known_answer_and_property_p1(ofd):
+    """warp_test.py:22-27 known answer, warp_test.py:59-75 property P1 -- on the GPU path."""
+    src = torch.zeros(1, 1, 2, 4)
+    src[0, 0, 1, 2] = 1.0
+    flow = torch.zeros(1, 2, 2, 4)
+    flow[0, 0] = 0.5
+    out = ofd.warp(src.cuda(), None, flow.cuda(), mode="forward", set_nans=False).cpu()
+    exp = torch.zeros(1, 1, 2, 4)
+    exp[0, 0, 1, 2] = exp[0, 0, 1, 3] = 0.5
+    assert torch.equal(out, exp)
+    torch.manual_seed(12)
+    L = 2
+    s = torch.rand(2, 3, 128, 128).cuda()
+    f = _flows(2, 128, 128, 13, 2.0)["mixed"].cuda()
+    for off in ([0, 0], [1, 0], [1, 1]):
+        direct = ofd.warp(s, None, f, mode="forward", scale=L, offset=off, set_nans=False) / L ** 2
+        two = ofd.warp(ofd.warp(s, None, f, mode="forward", set_nans=False), None, torch.zeros_like(f), mode="forward",
+                       scale=L, offset=off, set_nans=False) / L ** 2
+        assert float((direct - two)[:, :, 2:-2, 2:-2].abs().max()) < 1e-4
+
+
+def test_grid_sample_warp_against_reference_goldens(ofd):
+    from opticalflowdiffusion_amd.warp import grid_warp_corners
+    g = load_golden("warp_backward")
+    cases = [("rand", g["rand.img"], g["rand.flow"]), ("int", g["rand.img"], g["int.flow"]),
+             ("wideint", g["wide.img"], g["wideint.flow"]), ("wide", g["wide.img"], torch.zeros(1, 2, 6, 1024))]
+    for tag, img, flow in cases:
+        out, mask = ofd.warp(None, img.cuda(), flow.cuda(), mode="backward")
+        assert torch.equal(mask.cpu(), g[f"{tag}.mask"]), tag
+        assert float((out.cpu() - g[f"{tag}.out"]).abs().max()) < 2e-6, tag
+        # integer grid indexing: the exact fp32 op order of WP:108-109 + ATen's un-normalise
+        B, _, H, W = flow.shape
+        xx = torch.arange(W).view(1, 1, W).float() + flow[:, 1]
+        yy = torch.arange(H).view(1, H, 1).float() + flow[:, 0]
+        vx = 2.0 * xx / max(W - 1, 1) - 1.0
+        vy = 2.0 * yy / max(H - 1, 1) - 1.0
+        ix = torch.floor(((vx + 1) / 2) * (W - 1)).int()
+        iy = torch.floor(((vy + 1) / 2) * (H - 1)).int()
+        c = grid_warp_corners(flow.cuda()).cpu()
+        assert torch.equal(c[..., 0], ix) and torch.equal(c[..., 1], iy), tag
+
+
+def test_grid_sample_warp_full_size_properties(ofd):
+    """BASELINE size (16,3,440,1024): zero flow is the identity up to the fp32 round trip, and a
+    constant integer shift equals a slice (size-independent properties; the oracle is too slow here)."""
+    torch.manual_seed(14)
+    img = torch.rand(16, 3, 440, 1024, device="cuda")
+    z = torch.zeros(16, 2, 440, 1024, device="cuda")
+    out, mask = ofd.warp(None, img, z, mode="backward")
+    assert float((out - img).abs().max()) < 2e-4 and bool((mask == 1).all())
+    f = z.clone()
+    f[:, 1] = 3.0        # channel 1 displaces x after the flip (WP:105)
+    f[:, 0] = -2.0
+    out, mask = ofd.warp(None, img, f, mode="backward")
+    assert float((out[:, :, 2:, :-3] - img[:, :, :-2, 3:]).abs().max()) < 2e-4
+    assert bool((mask[:, :, :2] == 0).all()) and bool((mask[:, :, :, -3:] == 0).all())
+
+
+def test_splat_full_size_properties(ofd):
+    """BASELINE size (16,4,440,1024): mass conservation (sum of the splat == sum of the inputs
+    whose four corners stay inside) and zero flow identity."""
+    from opticalflowdiffusion_amd.softsplat import splat_forward
+    torch.manual_seed(15)
+    img = torch.rand(16, 4, 440, 1024, device="cuda")
+    z = torch.zeros(16, 2, 440, 1024, device="cuda")
+    assert torch.equal(splat_forward(img, z), img)
+    f = (torch.rand(16, 2, 440, 1024, device="cuda") * 2 - 1) * 20.0
+    out = splat_forward(img, f)
+    xs = torch.arange(1024, device="cuda").view(1, 1, 1024) + f[:, 0]
+    ys = torch.arange(440, device="cuda").view(1, 440, 1) + f[:, 1]
+    inside = ((xs >= 0) & (xs <= 1023) & (ys >= 0) & (ys <= 439)).unsqueeze(1)
+    lo = float((img * inside).double().sum())
+    hi = float(img.double().sum())
+    total = float(out.double().sum())
+    assert lo * (1 - 1e-5) <= total <= hi * (1 + 1e-5)
+
+
+def test_diffusion_elementwise_kernels(ofd):
+    from opticalflowdiffusion_amd._lib import lib, check, ptr, stream
+    from oracle import diffusion_ref as D
+    S = D.make_schedule(1000)
+    torch.manual_seed(16)
+    B, C, H, Wd = 3, 2, 24, 40
+    x0 = torch.rand(B, C, H, Wd) * 2 - 1
+    nz = torch.randn(B, C, H, Wd)
+    mo = torch.randn(B, C, H, Wd) * 1.5
+    t = torch.tensor([0, 499, 999])
+    n = C * H * Wd
+    keep = []
+
+    def d(v):                       # device copy that stays alive until the test ends
+        keep.append(v.cuda().contiguous())
+        return ptr(keep[-1])
+
+    out = torch.empty(B, C, H, Wd, device="cuda")
+    xs = torch.empty(B, C, H, Wd, device="cuda")
+    check(lib().ofd_q_sample(d(x0), d(nz), d(S["sqrt_alphas_cumprod"][t]), d(S["sqrt_one_minus_alphas_cumprod"][t]),
+                             ptr(out), B, n, stream()))
+    assert rel_l2(out.cpu(), D.q_sample(S, x0, t, nz)) < 1e-6
+    for ti in (999, 1, 0):
+        tt = torch.full((B,), ti)
+        sigma = (0.5 * S["posterior_log_variance_clipped"][tt]).exp() if ti > 0 else torch.zeros(B)
+        check(lib().ofd_ddpm_update(d(x0), d(mo), d(nz), d(S["posterior_mean_coef1"][tt]), d(S["posterior_mean_coef2"][tt]),
+                                    d(sigma), ptr(out), ptr(xs), B, n, stream()))
+        ref, ref_xs = D.p_sample_update(S, x0, ti, mo, nz)
+        assert rel_l2(out.cpu(), ref) < 1e-6 and torch.equal(xs.cpu(), ref_xs), ti
+    for time, time_next in ((999, 979), (19, -1)):
+        tt = torch.full((B,), time)
+        an = S["alphas_cumprod"][max(time_next, 0)]
+        rep = lambda v: d(v.reshape(1).repeat(B))
+        check(lib().ofd_ddim_update(d(x0), d(mo), None, d(S["sqrt_recip_alphas_cumprod"][tt]),
+                                    d(S["sqrt_recipm1_alphas_cumprod"][tt]), rep(an.sqrt()), rep((1 - an).sqrt()), None,
+                                    int(time_next < 0), ptr(out), ptr(xs), B, n, stream()))
+        ref, ref_xs = D.ddim_update(S, x0, time, time_next, mo, torch.zeros_like(x0))
+        assert rel_l2(out.cpu(), ref) < 1e-6, time
+    a = torch.randn(5000)
+    b = torch.randn(5000)
+    a[17] = float("nan")
+    b[4000] = float("nan")
+    assert float(ofd.nan_mse(a.cuda(), b.cuda())) == pytest.approx(float(torch.nanmean(D.nan_mse_none(a, b))), rel=1e-6)
