@@ -116,6 +116,7 @@ void ofd_unet_destroy(ofd_unet* u);
 int ofd_unet_num_params(const ofd_unet* u);
 const char* ofd_unet_param_name(const ofd_unet* u, int i);
 size_t ofd_unet_param_numel(const ofd_unet* u, int i);
+int ofd_unet_param_shape(const ofd_unet* u, int i, int* dims4);   /* returns ndim (1..4) */
 /* copy fp32 parameter i from a device buffer (reference layout, e.g. OIHW) into the engine */
 int ofd_unet_set_param(ofd_unet* u, int i, const float* dev_src, size_t numel, void* stream);
 /* weight standardisation + bf16 re-layout of everything set so far; call after set_param */

@@ -1,0 +1,31 @@
+// Internal launchers of the UNet building-block kernels (blocks.hip, conv_igemm.hip).
+#pragma once
+#include "common.h"
+
+namespace ofd {
+
+struct MlpDesc {            // one ResnetBlock's time-embedding Linear (DD:193-196)
+    const float* weight;    // [n_out][tdim]
+    const float* bias;      // [n_out]
+    int n_out;              // 2 * Cout
+    int offset;             // into the per-sample scale/shift row
+};
+
+int conv_forward_impl(const ofd_conv_args* a, hipStream_t s);
+
+int k_pack_input(const float* x, int Cx, const float* cond, int Cc, bf16_t* out, int B, int H, int W, hipStream_t s);
+int k_time_mlp(const int64_t* t, const float* w1, const float* b1, const float* w2, const float* b2, float* temb,
+               float* temb_silu, int B, int dim, hipStream_t s);
+int k_block_mlp(const float* temb_silu, const MlpDesc* descs, int n_desc, float* ss, int B, int tdim, int ss_stride, hipStream_t s);
+int k_gn_finalize(const float* partial, int B, int H, int W, int C, const float* gamma, const float* beta, const float* ss,
+                  int ss_stride, int ss_offset, float* a_out, float* s_out, hipStream_t s);
+int k_resblock_out(const bf16_t* h, const float* a, const float* sft, const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t s);
+int k_layernorm_c(const bf16_t* x, const float* g, const bf16_t* res, bf16_t* out, size_t npix, int C, float eps, hipStream_t s);
+int la_parts(int n);
+int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s);
+int k_flash_attention(const bf16_t* qkv, bf16_t* out, int B, int n, hipStream_t s);
+int k_final_conv(const bf16_t* x, const float* w, const float* bias, float* out, int B, int H, int W, int C, int out_dim, hipStream_t s);
+int k_nhwc_to_nchw(const bf16_t* x, float* out, int B, int H, int W, int C, hipStream_t s);
+int k_nchw_to_nhwc(const float* x, bf16_t* out, int B, int H, int W, int C, hipStream_t s);
+
+}  // namespace ofd

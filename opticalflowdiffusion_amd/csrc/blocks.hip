@@ -1,0 +1,589 @@
+// The non-convolution kernels of the UNet forward (denoising_diffusion.py), NHWC bf16 activations,
+// fp32 arithmetic: input packing, time MLP, GroupNorm finalisation, ResnetBlock output,
+// channel LayerNorm, LinearAttention (context pass + output pass), flash attention for the mid
+// block and the final 1x1 convolution.
+#include "blocks.h"
+
+namespace ofd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + __expf(-y)); }
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = bf2f((bf16_t)(w[j] & 0xffffu));
+        f[2 * j + 1] = bf2f((bf16_t)(w[j] >> 16));
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+}
+
+// ---- DD:368: cat(x, cond) -> NHWC bf16 padded to 16 channels (input of the 7x7 init_conv) --------
+__global__ void __launch_bounds__(256) pack_input_kernel(const float* __restrict__ x, int Cx, const float* __restrict__ cond, int Cc,
+                                                         bf16_t* __restrict__ out, int B, size_t plane) {
+    const size_t total = (size_t)B * plane;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / plane, pix = i % plane;
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float t = 0.0f;
+            if (c < Cx) t = x[(n * Cx + c) * plane + pix];
+            else if (c < Cx + Cc) t = cond[(n * Cc + (c - Cx)) * plane + pix];
+            v[c] = t;
+        }
+        uint4* o = (uint4*)(out + i * 16);
+        o[0] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+        o[1] = make_uint4(pack2(v[8], v[9]), pack2(v[10], v[11]), pack2(v[12], v[13]), pack2(v[14], v[15]));
+    }
+}
+
+// ---- DD:139-151 + DD:319-324: sinusoidal embedding -> Linear -> GELU(erf) -> Linear; output SiLU(temb)
+// too, which is what every ResnetBlock's mlp consumes (DD:193-196).  One workgroup per sample.
+__global__ void __launch_bounds__(256) time_mlp_kernel(const int64_t* __restrict__ t, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ temb,
+                                                       float* __restrict__ temb_silu, int dim) {
+    __shared__ float emb[256], h1[1024];
+    const int b = blockIdx.x, tid = threadIdx.x, tdim = dim * 4, half_dim = dim / 2;
+    const float tv = (float)t[b];
+    for (int i = tid; i < half_dim; i += 256) {
+        const float k = (float)(9.210340371976184 / (double)(half_dim - 1));   // math.log(10000) / (half_dim - 1), DD:147
+        const float f = expf((float)i * -k);
+        emb[i] = sinf(tv * f);
+        emb[half_dim + i] = cosf(tv * f);
+    }
+    __syncthreads();
+    for (int j = tid; j < tdim; j += 256) {
+        float a = b1[j];
+        for (int k = 0; k < dim; ++k) a += w1[(size_t)j * dim + k] * emb[k];
+        h1[j] = 0.5f * a * (1.0f + erff(a * 0.70710678118654752f));
+    }
+    __syncthreads();
+    for (int j = tid; j < tdim; j += 256) {
+        float a = b2[j];
+        for (int k = 0; k < tdim; ++k) a += w2[(size_t)j * tdim + k] * h1[k];
+        temb[(size_t)b * tdim + j] = a;
+        temb_silu[(size_t)b * tdim + j] = a / (1.0f + expf(-a));
+    }
+}
+
+// ss[b][off + j] = Linear(SiLU(temb))[j] for every ResnetBlock (DD:205-208); grid (B, n_blocks)
+__global__ void __launch_bounds__(256) block_mlp_kernel(const float* __restrict__ temb_silu, const MlpDesc* __restrict__ descs,
+                                                        float* __restrict__ ss, int tdim, int ss_stride) {
+    __shared__ float e[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const MlpDesc d = descs[blockIdx.y];
+    for (int k = tid; k < tdim; k += 256) e[k] = temb_silu[(size_t)b * tdim + k];
+    __syncthreads();
+    for (int j = tid; j < d.n_out; j += 256) {
+        float a = d.bias[j];
+        const float* wr = d.weight + (size_t)j * tdim;
+        for (int k = 0; k < tdim; ++k) a += wr[k] * e[k];
+        ss[(size_t)b * ss_stride + d.offset + j] = a;
+    }
+}
+
+// ---- GroupNorm(8) statistics -> per-(sample, channel) affine (DD:181-185) -------------------------
+// partial: [B][tiles][C/8][2] from the conv epilogue.  y = x*a + s with
+//   a = gamma*rstd*(scale+1), s = (beta - mean*rstd*gamma)*(scale+1) + shift.   grid (B, 8)
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial, int tiles, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ ss, int ss_stride, int ss_offset,
+                                                          float* __restrict__ a_out, float* __restrict__ s_out) {
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int gs = C / 8, octs = gs / 8, noct = C / 8;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = tid; i < tiles * octs; i += 256) {
+        const int tile = i / octs, o = g * octs + i % octs;
+        const float* p = partial + (((size_t)b * tiles + tile) * noct + o) * 2;
+        s1 += (double)p[0];
+        s2 += (double)p[1];
+    }
+    __shared__ double r1[256], r2[256];
+    r1[tid] = s1;
+    r2[tid] = s2;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (tid < k) { r1[tid] += r1[tid + k]; r2[tid] += r2[tid + k]; }
+        __syncthreads();
+    }
+    const double mean_d = r1[0] / count;
+    double var_d = r2[0] / count - mean_d * mean_d;
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d, rstd = rsqrtf((float)var_d + 1e-5f);
+    for (int c = g * gs + tid; c < (g + 1) * gs; c += 256) {
+        float sc = 0.0f, sh = 0.0f;
+        if (ss) {
+            sc = ss[(size_t)b * ss_stride + ss_offset + c];
+            sh = ss[(size_t)b * ss_stride + ss_offset + C + c];
+        }
+        const float ga = gamma[c] * rstd;
+        a_out[(size_t)b * C + c] = ga * (sc + 1.0f);
+        s_out[(size_t)b * C + c] = (beta[c] - mean * ga) * (sc + 1.0f) + sh;
+    }
+}
+
+// ---- DD:214 with identity res_conv: out = SiLU(h*a + s) + x ---------------------------------------
+__global__ void __launch_bounds__(256) resblock_out_kernel(const bf16_t* __restrict__ h, const float* __restrict__ a, const float* __restrict__ s,
+                                                           const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int C, size_t pix_per_sample, size_t total_units) {
+    const int c8n = C / 8;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total_units; u += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = u / c8n;
+        const int c = (int)(u % c8n) * 8;
+        const size_t b = pix / pix_per_sample;
+        float hv[8], xv[8], av[8], sv[8];
+        unpack8(*(const uint4*)(h + u * 8), hv);
+        unpack8(*(const uint4*)(x + u * 8), xv);
+        *(float4*)&av[0] = *(const float4*)(a + b * C + c);
+        *(float4*)&av[4] = *(const float4*)(a + b * C + c + 4);
+        *(float4*)&sv[0] = *(const float4*)(s + b * C + c);
+        *(float4*)&sv[4] = *(const float4*)(s + b * C + c + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = silu_f(hv[j] * av[j] + sv[j]) + xv[j];
+        *(uint4*)(out + u * 8) = pack8(hv);
+    }
+}
+
+// ---- DD:116-125 channel LayerNorm (gain only), optional "+ residual" (Residual of DD:81-87) ------
+// C/8 lanes cooperate on one pixel (each holds 8 channels); a wave covers 512/C pixels at a time.
+__global__ void __launch_bounds__(256) layernorm_c_kernel(const bf16_t* __restrict__ x, const float* __restrict__ g, const bf16_t* __restrict__ res,
+                                                          bf16_t* __restrict__ out, int C, float eps, size_t npix) {
+    const int lpp = C / 8;                         // lanes per pixel: 8,16,32,64
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % lpp, slot = lane / lpp, ppw = 64 / lpp;
+    const size_t wave_global = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    float gv[8];
+    *(float4*)&gv[0] = *(const float4*)(g + sub * 8);
+    *(float4*)&gv[4] = *(const float4*)(g + sub * 8 + 4);
+    const float inv_c = 1.0f / (float)C;
+    for (size_t p0 = wave_global * ppw; p0 < npix; p0 += nwaves * ppw) {
+        const size_t p = p0 + slot;
+        const bool ok = p < npix;
+        float v[8];
+        if (ok) unpack8(*(const uint4*)(x + p * C + sub * 8), v);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+        }
+        float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        for (int o = 1; o < lpp; o <<= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * inv_c;
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] -= mean; q += v[j] * v[j]; }
+        for (int o = 1; o < lpp; o <<= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = rsqrtf(q * inv_c + eps);
+        if (ok) {
+            float r[8];
+            if (res) unpack8(*(const uint4*)(res + p * C + sub * 8), r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * rstd * gv[j] + (res ? r[j] : 0.0f);
+            *(uint4*)(out + p * C + sub * 8) = pack8(v);
+        }
+    }
+}
+
+// ---- LinearAttention, pass 1 (DD:235,238,240): per (sample, head) streaming softmax over n of k and
+// the context k_soft . v^T / n.  A workgroup walks `span` pixels in sub-chunks of 256 with an
+// online max (flash-style rescale) and emits a partial {m[32], l[32], ctx[32][32]}.
+constexpr int LA_SUB = 128;
+__global__ void __launch_bounds__(256) la_ctx_partial_kernel(const bf16_t* __restrict__ qkv, float* __restrict__ partial, int n, int span, int nparts) {
+    __shared__ __attribute__((aligned(16))) float ks[LA_SUB][33];
+    __shared__ __attribute__((aligned(16))) float vs[LA_SUB][32];
+    __shared__ float red[8][32], m_s[32], f_s[32];
+    const int tid = threadIdx.x, part = blockIdx.x, bh = blockIdx.y, b = bh / 4, h = bh % 4;
+    const int n_begin = part * span, n_end = min(n, n_begin + span);
+    const int d = tid >> 3, e4 = (tid & 7) * 4;          // thread owns ctx[d][e4..e4+3]
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 32) m_s[tid] = -3.0e38f;
+    float l_run = 0.0f;                                   // threads 0..31: running sum for d = tid
+    __syncthreads();
+    for (int c0 = n_begin; c0 < n_end; c0 += LA_SUB) {
+        const int cnt = min(LA_SUB, n_end - c0);
+        // stage k and v of this head: 128 pixels x (4 + 4) 16-byte units, 4 units per thread
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 256, p = id >> 3, u = id & 7;
+            if (p < cnt) {
+                const bf16_t* row = qkv + ((size_t)b * n + c0 + p) * 384 + h * 32;
+                float f[8];
+                if (u < 4) {
+                    unpack8(*(const uint4*)(row + 128 + u * 8), f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ks[p][u * 8 + j] = f[j];
+                } else {
+                    unpack8(*(const uint4*)(row + 256 + (u - 4) * 8), f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vs[p][(u - 4) * 8 + j] = f[j];
+                }
+            }
+        }
+        __syncthreads();
+        // chunk max per d: 8 groups of 32 lanes
+        {
+            const int dd = tid & 31, grp = tid >> 5;
+            float mx = -3.0e38f;
+            for (int p = grp; p < cnt; p += 8) mx = fmaxf(mx, ks[p][dd]);
+            red[grp][dd] = mx;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float mx = red[0][tid];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) mx = fmaxf(mx, red[g][tid]);
+            const float m_old = m_s[tid], m_new = fmaxf(m_old, mx);
+            f_s[tid] = __expf(m_old - m_new);
+            m_s[tid] = m_new;
+        }
+        __syncthreads();
+        // exponentiate in place + partial row sums
+        {
+            const int dd = tid & 31, grp = tid >> 5;
+            const float m = m_s[dd];
+            float sum = 0.0f;
+            for (int p = grp; p < cnt; p += 8) {
+                const float e = __expf(ks[p][dd] - m);
+                ks[p][dd] = e;
+                sum += e;
+            }
+            red[grp][dd] = sum;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float sum = red[0][tid];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) sum += red[g][tid];
+            l_run = l_run * f_s[tid] + sum;
+        }
+        {
+            const float f = f_s[d];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] *= f;
+            for (int p = 0; p < cnt; ++p) {
+                const float pk = ks[p][d];
+                const float4 vv = *(const float4*)&vs[p][e4];
+                acc[0] += pk * vv.x; acc[1] += pk * vv.y; acc[2] += pk * vv.z; acc[3] += pk * vv.w;
+            }
+        }
+        __syncthreads();
+    }
+    float* o = partial + ((size_t)bh * nparts + part) * 1088;
+    if (tid < 32) { o[tid] = m_s[tid]; o[32 + tid] = l_run; }
+    *(float4*)(o + 64 + d * 32 + e4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// combine the partials: ctx[bh][d][e] = sum_c exp(m_c - M) ctx_c / (sum_c exp(m_c - M) l_c) / n
+__global__ void __launch_bounds__(256) la_ctx_combine_kernel(const float* __restrict__ partial, float* __restrict__ ctx, int nparts, float inv_n) {
+    __shared__ float M[32], Linv[32];
+    const int tid = threadIdx.x, bh = blockIdx.x;
+    const float* base = partial + (size_t)bh * nparts * 1088;
+    if (tid < 32) {
+        float mx = -3.0e38f;
+        for (int c = 0; c < nparts; ++c) mx = fmaxf(mx, base[(size_t)c * 1088 + tid]);
+        float l = 0.0f;
+        for (int c = 0; c < nparts; ++c) l += base[(size_t)c * 1088 + 32 + tid] * __expf(base[(size_t)c * 1088 + tid] - mx);
+        M[tid] = mx;
+        Linv[tid] = 1.0f / l;
+    }
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+        const int d = i >> 5;
+        float a = 0.0f;
+        for (int c = 0; c < nparts; ++c) a += base[(size_t)c * 1088 + 64 + i] * __expf(base[(size_t)c * 1088 + d] - M[d]);
+        ctx[(size_t)bh * 1024 + i] = a * Linv[d] * inv_n;
+    }
+}
+
+// ---- LinearAttention, pass 2 (DD:234,237,242): per pixel q softmax over d, * scale, out = ctx^T q ---
+// workgroup: 32 pixels per iteration; thread -> (pixel, head, 16 of the 32 outputs e)
+__global__ void __launch_bounds__(256) la_out_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ ctx, bf16_t* __restrict__ out, int n, float scale) {
+    __shared__ float cs[4][32][32], qs[32][129];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    for (int i = tid; i < 4096; i += 256) (&cs[0][0][0])[i] = ctx[(size_t)b * 4096 + i];
+    const int px = tid >> 3, hh = (tid & 7) >> 1, eh = (tid & 1) * 16;
+    for (int p0 = blockIdx.x * 32; p0 < n; p0 += gridDim.x * 32) {
+        __syncthreads();
+        // stage + softmax over d: thread -> (pixel px, head hh, half eh/16 of d): 16 values each
+        {
+            const int p = p0 + px;
+            float f[16];
+            if (p < n) {
+                const bf16_t* row = qkv + ((size_t)b * n + p) * 384 + hh * 32 + eh;
+                float a[8], c[8];
+                unpack8(*(const uint4*)(row), a);
+                unpack8(*(const uint4*)(row + 8), c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { f[j] = a[j]; f[8 + j] = c[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) f[j] = 0.0f;
+            }
+            float mx = f[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) mx = fmaxf(mx, f[j]);
+            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { f[j] = __expf(f[j] - mx); sum += f[j]; }
+            sum += __shfl_xor(sum, 1, 64);
+            const float k = scale / sum;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) qs[px][hh * 32 + eh + j] = f[j] * k;
+        }
+        __syncthreads();
+        {
+            float o[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) o[j] = 0.0f;
+            for (int d = 0; d < 32; ++d) {
+                const float qv = qs[px][hh * 32 + d];
+#pragma unroll
+                for (int j = 0; j < 16; j += 4) {
+                    const float4 c4 = *(const float4*)&cs[hh][d][eh + j];
+                    o[j] += qv * c4.x; o[j + 1] += qv * c4.y; o[j + 2] += qv * c4.z; o[j + 3] += qv * c4.w;
+                }
+            }
+            const int p = p0 + px;
+            if (p < n) {
+                bf16_t* dst = out + ((size_t)b * n + p) * 128 + hh * 32 + eh;
+                float lo[8], hi[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { lo[j] = o[j]; hi[j] = o[8 + j]; }
+                *(uint4*)dst = pack8(lo);
+                *(uint4*)(dst + 8) = pack8(hi);
+            }
+        }
+    }
+}
+
+// ---- mid-block attention (DD:256-268), flash style, d = 32, 4 heads, MFMA 32x32x16 bf16 -----------
+// workgroup = 4 waves x 32 queries of one (sample, head); K/V tiles of 64 keys shared through LDS.
+// S^T = K.Q^T puts the query on the lane, so row max / sum are lane-local (+1 cross-half shuffle)
+// and the exponentiated accumulator is directly the B operand of O^T += V^T.P^T.
+constexpr int FA_KT = 64;
+__global__ void __launch_bounds__(256) flash_attn_d32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char k_lds[FA_KT * 80];      // [key][32 d], rows padded to 80 B
+    __shared__ __attribute__((aligned(16))) unsigned char vt_lds[32 * 144];       // [d][64 keys permuted], rows padded to 144 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.y, b = bh / 4, h = bh % 4;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bf16_t* base = qkv + (size_t)b * n * 384;
+
+    bf16x8 qf[2];
+    {
+        const int q = min(q0 + l31, n - 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[s] = *(const bf16x8*)(base + (size_t)q * 384 + h * 32 + s * 16 + half * 8);
+    }
+    f32x16 o_acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[r] = 0.0f;
+    float m_run = -3.0e38f, l_run = 0.0f;
+
+    for (int j0 = 0; j0 < n; j0 += FA_KT) {
+        __syncthreads();     // previous tile fully consumed
+        {
+            // stage K [key][d] and V^T [d][slot]: thread -> key tid/4, 16-B unit tid%4 (8 d's)
+            const int key = tid >> 2, u = tid & 3;
+            const int kg = min(j0 + key, n - 1);
+            const uint4 kv = *(const uint4*)(base + (size_t)kg * 384 + 128 + h * 32 + u * 8);
+            *(uint4*)(k_lds + key * 80 + u * 16) = kv;
+            const uint4 vv = *(const uint4*)(base + (size_t)kg * 384 + 256 + h * 32 + u * 8);
+            // key = kb*32 + 16 s + 8 a + 4 hh + bb  ->  slot = kb*32 + s*16 + hh*8 + a*4 + bb
+            const int kb = key >> 5, kk = key & 31, s = kk >> 4, a = (kk >> 3) & 1, hh = (kk >> 2) & 1, bb = kk & 3;
+            const int slot = kb * 32 + s * 16 + hh * 8 + a * 4 + bb;
+            const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *(bf16_t*)(vt_lds + (u * 8 + 2 * j) * 144 + slot * 2) = (bf16_t)(w[j] & 0xffffu);
+                *(bf16_t*)(vt_lds + (u * 8 + 2 * j + 1) * 144 + slot * 2) = (bf16_t)(w[j] >> 16);
+            }
+        }
+        __syncthreads();
+        f32x16 s_acc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_acc[kb][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 kf = *(const bf16x8*)(k_lds + (kb * 32 + l31) * 80 + (s * 16 + half * 8) * 2);
+                s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s_acc[kb], 0, 0, 0);
+            }
+        }
+        // online softmax; key index of register r: j0 + kb*32 + (r&3) + 8*(r>>2) + 4*half
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float sv = s_acc[kb][r] * scale;
+                if (key >= n) sv = -3.0e38f;
+                s_acc[kb][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(s_acc[kb][r] - m_new);
+                s_acc[kb][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s_acc[kb][8 * s + j];
+                const bf16x8 vf = *(const bf16x8*)(vt_lds + l31 * 144 + (kb * 32 + s * 16 + half * 8) * 2);
+                o_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc, 0, 0, 0);
+            }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < n) {
+        bf16_t* dst = out + ((size_t)b * n + q) * 128 + h * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint2 pk = make_uint2(pack2(o_acc[4 * g] * inv, o_acc[4 * g + 1] * inv), pack2(o_acc[4 * g + 2] * inv, o_acc[4 * g + 3] * inv));
+            *(uint2*)(dst + 8 * g + 4 * half) = pk;
+        }
+    }
+}
+
+// ---- DD:361,417: final 1x1 conv (fp32 weights) -> NCHW fp32 -------------------------------------
+__global__ void __launch_bounds__(256) final_conv_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int C, int out_dim, size_t plane, size_t total) {
+    extern __shared__ float wsm[];     // [out_dim][C]
+    for (int i = threadIdx.x; i < out_dim * C; i += 256) wsm[i] = w[i];
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / plane, pix = i % plane;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; c += 8) {
+            float f[8];
+            unpack8(*(const uint4*)(x + i * C + c), f);
+            for (int o = 0; o < out_dim; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[o] += f[j] * wsm[o * C + c + j];
+        }
+        for (int o = 0; o < out_dim; ++o) out[(n * out_dim + o) * plane + pix] = acc[o] + bias[o];
+    }
+}
+
+// debug: NHWC bf16 -> NCHW fp32
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int C, size_t plane, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pixc = i / C;
+        const int c = (int)(i % C);
+        const size_t n = pixc / plane, pix = pixc % plane;
+        out[(n * C + c) * plane + pix] = bf2f(x[i]);
+    }
+}
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int C, size_t plane, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pixc = i / C;
+        const int c = (int)(i % C);
+        const size_t n = pixc / plane, pix = pixc % plane;
+        out[i] = f2bf(x[(n * C + c) * plane + pix]);
+    }
+}
+
+static inline int sgrid(size_t total, int block = 256, int cap = 4096) {
+    size_t b = (total + block - 1) / block;
+    return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
+}
+
+// ------------------------------------------------------------------------------------ launchers
+int k_pack_input(const float* x, int Cx, const float* cond, int Cc, bf16_t* out, int B, int H, int W, hipStream_t s) {
+    OFD_CHECK_ARG(Cx + Cc <= 16 && Cx > 0, "pack_input: %d+%d channels (max 16)", Cx, Cc);
+    pack_input_kernel<<<sgrid((size_t)B * H * W), 256, 0, s>>>(x, Cx, cond, Cc, out, B, (size_t)H * W);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+int k_time_mlp(const int64_t* t, const float* w1, const float* b1, const float* w2, const float* b2, float* temb, float* temb_silu, int B, int dim, hipStream_t s) {
+    OFD_CHECK_ARG(dim * 4 <= 1024 && dim <= 256, "time_mlp: dim %d too large", dim);
+    time_mlp_kernel<<<B, 256, 0, s>>>(t, w1, b1, w2, b2, temb, temb_silu, dim);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+int k_block_mlp(const float* temb_silu, const MlpDesc* descs, int n_desc, float* ss, int B, int tdim, int ss_stride, hipStream_t s) {
+    block_mlp_kernel<<<dim3(B, n_desc), 256, 0, s>>>(temb_silu, descs, ss, tdim, ss_stride);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+int k_gn_finalize(const float* partial, int B, int H, int W, int C, const float* gamma, const float* beta, const float* ss, int ss_stride,
+                  int ss_offset, float* a_out, float* s_out, hipStream_t s) {
+    OFD_CHECK_ARG(C % 64 == 0, "gn_finalize: C=%d", C);
+    const int tiles = cdiv(H, 8) * cdiv(W, 32);
+    gn_finalize_kernel<<<dim3(B, 8), 256, 0, s>>>(partial, tiles, C, (double)H * W * (C / 8), gamma, beta, ss, ss_stride, ss_offset, a_out, s_out);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+int k_resblock_out(const bf16_t* h, const float* a, const float* sft, const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t s) {
+    const size_t units = (size_t)B * H * W * (C / 8);
+    resblock_out_kernel<<<sgrid(units), 256, 0, s>>>(h, a, sft, x, out, C, (size_t)H * W, units);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+int k_layernorm_c(const bf16_t* x, const float* g, const bf16_t* res, bf16_t* out, size_t npix, int C, float eps, hipStream_t s) {
+    OFD_CHECK_ARG(C == 64 || C == 128 || C == 256 || C == 512, "layernorm_c: C=%d unsupported", C);
+    const size_t waves = (npix + (512 / C) - 1) / (512 / C);
+    layernorm_c_kernel<<<sgrid(waves * 64), 256, 0, s>>>(x, g, res, out, C, eps, npix);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+int la_parts(int n) { return cdiv(n, 4096); }
+int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s) {
+    const int nparts = la_parts(n);
+    la_ctx_partial_kernel<<<dim3(nparts, B * 4), 256, 0, s>>>(qkv, partial, n, 4096, nparts);
+    la_ctx_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, nparts, 1.0f / (float)n);
+    int gx = cdiv(n, 32);
+    if (gx > 1024) gx = 1024;
+    la_out_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, ctx, out, n, 0.17677669529663687f);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+int k_flash_attention(const bf16_t* qkv, bf16_t* out, int B, int n, hipStream_t s) {
+    flash_attn_d32_kernel<<<dim3(cdiv(n, 128), B * 4), 256, 0, s>>>(qkv, out, n, 0.17677669529663687f);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+int k_final_conv(const bf16_t* x, const float* w, const float* bias, float* out, int B, int H, int W, int C, int out_dim, hipStream_t s) {
+    OFD_CHECK_ARG(out_dim >= 1 && out_dim <= 4 && C % 8 == 0, "final_conv: out_dim=%d C=%d", out_dim, C);
+    final_conv_kernel<<<sgrid((size_t)B * H * W), 256, out_dim * C * sizeof(float), s>>>(x, w, bias, out, C, out_dim, (size_t)H * W, (size_t)B * H * W);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+int k_nhwc_to_nchw(const bf16_t* x, float* out, int B, int H, int W, int C, hipStream_t s) {
+    const size_t total = (size_t)B * H * W * C;
+    nhwc_to_nchw_kernel<<<sgrid(total), 256, 0, s>>>(x, out, C, (size_t)H * W, total);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+int k_nchw_to_nhwc(const float* x, bf16_t* out, int B, int H, int W, int C, hipStream_t s) {
+    const size_t total = (size_t)B * H * W * C;
+    nchw_to_nhwc_kernel<<<sgrid(total), 256, 0, s>>>(x, out, C, (size_t)H * W, total);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+}  // namespace ofd

@@ -1,0 +1,432 @@
+// Implicit-GEMM convolution for gfx950 (MFMA 32x32x16 bf16, fp32 accumulate), NHWC bf16.
+//
+// Restates what the reference gets from cuDNN through F.conv2d for every convolution of the UNet
+// (denoising_diffusion.py:92,98,114,200,222,225,253,254,297,339,354,361) plus the glue the
+// reference runs as separate PyTorch ops around it, fused here:
+//   prologue : GroupNorm-apply * (scale+1) + shift -> SiLU  (DD:181-187) as one per-(sample,
+//              channel) affine + SiLU applied while the input tile is staged into LDS;
+//              channel concat (DD:405,408,414), nearest x2 up-sampling (DD:91) and
+//              pixel-unshuffle (DD:97) are address arithmetic of the loader;
+//   epilogue : bias, residual add / "+ SiLU(affine(h))" (DD:214), bf16 store, and the per-tile
+//              partial sums GroupNorm needs for the NEXT block (DD:181).
+//
+// Tiling: one workgroup (4 waves) owns 8x32 output pixels x BN output channels.  The input tile
+// with its halo ((8+k-1)x(32+k-1) pixels x 64 channels) is staged ONCE per 64-channel chunk
+// into LDS and reused by all k*k taps (LDS tile reuse instead of k*k global re-reads); weights
+// stream per tap through a double-buffered LDS slab.  MFMA operands are read with ds_read_b128
+// from XOR-swizzled images (conflict-free, see swz()).  The MFMA is issued "swapped"
+// (A = weights, B = pixels) so that a lane's accumulator registers are 4 consecutive output
+// channels of one pixel -> 8-byte NHWC stores.
+#include "common.h"
+
+namespace ofd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int TH = 8, TW = 32, NTHREADS = 256;
+
+struct ConvSrcDev {
+    const bf16_t* ptr;
+    int chunks;         // K-chunks (of CK channels) taken from this source
+    int src_channels;   // pixel stride of the source tensor
+    int ch_offset;
+    int SH, SW;         // source spatial size
+    int mode;           // 0: same size, 1: nearest x2 up-sample, 2: pixel-unshuffle sub-pixel (p1,p2)
+    int p1, p2;
+};
+
+struct ConvParams {
+    int B, H, W, Cout, Cin_total, n_src, total_chunks, tiles_x, tiles_y;
+    ConvSrcDev src[4];
+    const bf16_t* weight;
+    const float* bias;
+    const float* in_scale;
+    const float* in_shift;
+    const bf16_t* residual;
+    const bf16_t* res_act;
+    const float* res_scale;
+    const float* res_shift;
+    bf16_t* out;
+    float* gn_partial;
+};
+
+template <int KS, int BN>
+struct Cfg {
+    static constexpr int CK = (KS == 7) ? 16 : 64;          // channels per K-chunk
+    static constexpr int NC = CK / 8;                       // 16-byte units per pixel
+    static constexpr int PAD = KS / 2;
+    static constexpr int IH = TH + KS - 1, IW = TW + KS - 1, NPIX = IH * IW;
+    static constexpr int STAGES = (KS == 3) ? 9 : (KS == 7 ? 7 : 1);   // weight slabs per chunk
+    static constexpr int KSTEPS = (KS == 7) ? 7 : 4;                    // MFMA k-steps per slab
+    static constexpr int SC8 = KSTEPS * 2;                              // 8-channel rows per slab
+    static constexpr int X_BYTES = NPIX * CK * 2;
+    static constexpr int W_BYTES = SC8 * BN * 16;
+    static constexpr int LDS_BYTES = X_BYTES + 2 * W_BYTES;
+    static constexpr int XPT = (NPIX * NC + NTHREADS - 1) / NTHREADS;  // 16-B units per thread
+    static constexpr int WPT = (SC8 * BN + NTHREADS - 1) / NTHREADS;
+    static constexpr int NTN = BN / 32;
+    static constexpr int PPR = 256 / (CK * 2);              // pixels per 256-B LDS bank row
+};
+
+// XOR swizzle of the 16-byte unit index inside a pixel: 16 consecutive pixels read at the same
+// logical unit by one ds_read_b128 lane group land on 16 distinct 16-B slots of the bank row.
+template <int CK>
+__device__ __forceinline__ int swz(int p) {
+    return (CK == 64) ? ((p >> 1) & 7) : ((p >> 3) & 1);
+}
+
+__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + __expf(-y)); }
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+// reduce N per-lane values over the 64 lanes of a wave with N-ish shuffles: afterwards lane l
+// holds in v[0] the total of value index (l >> (6 - log2 N)) (for N = 32: l >> 1, N = 16: l >> 2).
+template <int N>
+__device__ __forceinline__ void wave_reduce_multi(float (&v)[N]) {
+    int n = N;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        if (n > 1) {
+            const int half = n / 2;
+            const bool upper = (threadIdx.x & off) != 0;
+#pragma unroll
+            for (int i = 0; i < N / 2; ++i) {
+                if (i < half) {
+                    const float send = upper ? v[i] : v[i + half];
+                    const float keep = upper ? v[i + half] : v[i];
+                    v[i] = keep + __shfl_xor(send, off, 64);
+                }
+            }
+            n = half;
+        } else {
+            v[0] += __shfl_xor(v[0], off, 64);
+        }
+    }
+}
+
+template <int KS, int BN>
+__global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParams P) {
+    using C = Cfg<KS, BN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lds_x = smem;
+    unsigned char* lds_w = smem + C::X_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // XCD-aware tile order: blocks that share an XCD (bid % 8) get a contiguous run of tiles, so
+    // the halo rows two neighbouring tiles share are served by one L2.
+    const int ntiles = P.tiles_x * P.tiles_y * P.B;
+    int tile = blockIdx.x;
+    if (ntiles >= 8) {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int b = tile / (P.tiles_x * P.tiles_y);
+    const int t_in = tile % (P.tiles_x * P.tiles_y);
+    const int oy0 = (t_in / P.tiles_x) * TH, ox0 = (t_in % P.tiles_x) * TW;
+    const int n0 = blockIdx.y * BN;
+
+    f32x16 acc[C::NTN][2];
+#pragma unroll
+    for (int i = 0; i < C::NTN; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.0f;
+
+    uint4 wreg[C::WPT];
+
+    // global -> registers of weight slab (chunk kc, stage st)
+    auto load_w = [&](int kc, int st) {
+#pragma unroll
+        for (int i = 0; i < C::WPT; ++i) {
+            const int u = tid + i * NTHREADS;
+            const int r = u / BN, n = u % BN;
+            size_t row;
+            if (KS == 7) row = (size_t)(st * 7 + r / 2) * 2 + (r & 1);
+            else row = (size_t)st * (P.Cin_total / 8) + kc * 8 + r;
+            if (u < C::SC8 * BN) wreg[i] = *(const uint4*)(P.weight + (row * P.Cout + n0 + n) * 8);
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < C::WPT; ++i) {
+            const int u = tid + i * NTHREADS;
+            if (u < C::SC8 * BN) *(uint4*)(lds_w + buf * C::W_BYTES + u * 16) = wreg[i];
+        }
+    };
+
+    int src_i = 0, src_first = 0;   // source that owns chunk kc, and its first chunk
+    for (int kc = 0; kc < P.total_chunks; ++kc) {
+        while (kc >= src_first + P.src[src_i].chunks) {
+            src_first += P.src[src_i].chunks;
+            ++src_i;
+        }
+        const ConvSrcDev& S = P.src[src_i];
+        const int kcl = kc - src_first;
+
+        // ---- stage the input tile (+halo) of this chunk: global -> regs -> (affine+SiLU) -> LDS
+        uint4 xreg[C::XPT];
+        const int c8 = tid % C::NC;
+#pragma unroll
+        for (int i = 0; i < C::XPT; ++i) {
+            const int p = tid / C::NC + i * (NTHREADS / C::NC);
+            const int ty = p / C::IW, tx = p - ty * C::IW;
+            const int iy = oy0 - C::PAD + ty, ix = ox0 - C::PAD + tx;
+            const bool ok = (p < C::NPIX) && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+            int sy = iy, sx = ix;
+            if (S.mode == 1) { sy = iy >> 1; sx = ix >> 1; }
+            else if (S.mode == 2) { sy = 2 * iy + S.p1; sx = 2 * ix + S.p2; }
+            xreg[i] = make_uint4(0, 0, 0, 0);
+            if (ok) xreg[i] = *(const uint4*)(S.ptr + (((size_t)b * S.SH + sy) * S.SW + sx) * S.src_channels + S.ch_offset + kcl * C::CK + c8 * 8);
+        }
+        load_w(kc, 0);
+        float ps[8], pb[8];
+        if (P.in_scale) {
+            const int cg = kc * C::CK + c8 * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ps[j] = P.in_scale[(size_t)b * P.Cin_total + cg + j];
+                pb[j] = P.in_shift[(size_t)b * P.Cin_total + cg + j];
+            }
+        }
+        __syncthreads();   // every wave has finished reading lds_x / lds_w of the previous chunk
+#pragma unroll
+        for (int i = 0; i < C::XPT; ++i) {
+            const int p = tid / C::NC + i * (NTHREADS / C::NC);
+            if (p < C::NPIX) {
+                uint4 v = xreg[i];
+                if (P.in_scale) {
+                    const int ty = p / C::IW, tx = p - ty * C::IW;
+                    const int iy = oy0 - C::PAD + ty, ix = ox0 - C::PAD + tx;
+                    if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) {   // zero padding stays zero
+                        uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float lo = silu_f(bf2f((bf16_t)(w4[j] & 0xffffu)) * ps[2 * j] + pb[2 * j]);
+                            const float hi = silu_f(bf2f((bf16_t)(w4[j] >> 16)) * ps[2 * j + 1] + pb[2 * j + 1]);
+                            w4[j] = pack2(lo, hi);
+                        }
+                        v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                    }
+                }
+                *(uint4*)(lds_x + p * (C::CK * 2) + ((c8 ^ swz<C::CK>(p)) * 16)) = v;
+            }
+        }
+        store_w(0);
+
+        // ---- weight slabs: prefetch slab st+1 to registers while slab st feeds the MFMAs
+#pragma unroll 1
+        for (int st = 0; st < C::STAGES; ++st) {
+            if (st + 1 < C::STAGES) load_w(kc, st + 1);
+            __syncthreads();   // lds_x (st == 0) and lds_w[st & 1] are complete
+            const unsigned char* wbuf = lds_w + (st & 1) * C::W_BYTES;
+            const int ky = (KS == 3) ? st / 3 : (KS == 7 ? st : 0);
+            const int kx3 = (KS == 3) ? st % 3 : 0;
+#pragma unroll
+            for (int ks = 0; ks < C::KSTEPS; ++ks) {
+                const int kx = (KS == 7) ? ks : kx3;
+                const int unit = (KS == 7) ? half : (ks * 2 + half);
+                bf16x8 xf[2], wf[C::NTN];
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const int p = (wave * 2 + pt + ky) * C::IW + l31 + kx;
+                    xf[pt] = *(const bf16x8*)(lds_x + p * (C::CK * 2) + ((unit ^ swz<C::CK>(p)) * 16));
+                }
+#pragma unroll
+                for (int nt = 0; nt < C::NTN; ++nt)
+                    wf[nt] = *(const bf16x8*)(wbuf + ((ks * 2 + half) * BN + nt * 32 + l31) * 16);
+#pragma unroll
+                for (int nt = 0; nt < C::NTN; ++nt)
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+                        acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[pt], acc[nt][pt], 0, 0, 0);
+            }
+            if (st + 1 < C::STAGES) store_w((st + 1) & 1);   // other buffer: last read in stage st-1
+        }
+    }
+
+    // ---- epilogue: bias, residual forms, bf16 store, GroupNorm partial sums ---------------------
+    constexpr int NV = (BN / 8) * 2;
+    float stat[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) stat[i] = 0.0f;
+
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int oy = oy0 + wave * 2 + pt, ox = ox0 + l31;
+        const bool ok = oy < P.H && ox < P.W;
+        const size_t pix = ((size_t)b * P.H + oy) * P.W + ox;
+#pragma unroll
+        for (int nt = 0; nt < C::NTN; ++nt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = n0 + nt * 32 + 8 * g + 4 * half;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[nt][pt][4 * g + j];
+                if (P.bias) {
+                    const float4 bv = *(const float4*)(P.bias + c);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if (ok) {
+                    if (P.res_act) {
+                        const uint2 r = *(const uint2*)(P.res_act + pix * P.Cout + c);
+                        const float4 sc = *(const float4*)(P.res_scale + (size_t)b * P.Cout + c);
+                        const float4 sh = *(const float4*)(P.res_shift + (size_t)b * P.Cout + c);
+                        v[0] += silu_f(bf2f((bf16_t)(r.x & 0xffffu)) * sc.x + sh.x);
+                        v[1] += silu_f(bf2f((bf16_t)(r.x >> 16)) * sc.y + sh.y);
+                        v[2] += silu_f(bf2f((bf16_t)(r.y & 0xffffu)) * sc.z + sh.z);
+                        v[3] += silu_f(bf2f((bf16_t)(r.y >> 16)) * sc.w + sh.w);
+                    }
+                    if (P.residual) {
+                        const uint2 r = *(const uint2*)(P.residual + pix * P.Cout + c);
+                        v[0] += bf2f((bf16_t)(r.x & 0xffffu));
+                        v[1] += bf2f((bf16_t)(r.x >> 16));
+                        v[2] += bf2f((bf16_t)(r.y & 0xffffu));
+                        v[3] += bf2f((bf16_t)(r.y >> 16));
+                    }
+                    const uint2 q = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                    *(uint2*)(P.out + pix * P.Cout + c) = q;
+                    if (P.gn_partial) {   // statistics of the values as stored (bf16), DD:181
+                        const float q0 = bf2f((bf16_t)(q.x & 0xffffu)), q1 = bf2f((bf16_t)(q.x >> 16));
+                        const float q2 = bf2f((bf16_t)(q.y & 0xffffu)), q3 = bf2f((bf16_t)(q.y >> 16));
+                        stat[(nt * 4 + g) * 2] += (q0 + q1) + (q2 + q3);
+                        stat[(nt * 4 + g) * 2 + 1] += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+                    }
+                }
+            }
+        }
+    }
+
+    if (P.gn_partial) {
+        wave_reduce_multi<NV>(stat);
+        __syncthreads();                           // all MFMA reads of LDS are done: reuse it
+        float* red = (float*)smem;                 // [4 waves][NV]
+        constexpr int SH_ = (NV == 32) ? 1 : 2;    // lane l holds value index l >> SH_
+        if ((lane & ((1 << SH_) - 1)) == 0) red[wave * NV + (lane >> SH_)] = stat[0];
+        __syncthreads();
+        if (tid < NV) {
+            const float s = (red[tid] + red[NV + tid]) + (red[2 * NV + tid] + red[3 * NV + tid]);
+            const size_t base = ((size_t)b * (P.tiles_x * P.tiles_y) + t_in) * (P.Cout / 8) * 2;
+            P.gn_partial[base + (n0 / 8) * 2 + tid] = s;
+        }
+    }
+}
+
+// ---- weight preparation: OIHW fp32 -> [tap][Cin_pad/8][Cout][8] bf16 (+ weight standardisation)
+__global__ void __launch_bounds__(256) conv_weight_prep_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout,
+                                                               int Cin, int Cin_pad, int ksize, float ws_eps, int unshuffle) {
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const int taps = ksize * ksize, n = Cin * taps;
+    const float* wo = w + (size_t)o * n;
+    __shared__ double sh[256];
+    float mean = 0.0f, rstd = 1.0f;
+    if (ws_eps >= 0.0f) {       // DD:109-112: biased variance over (Cin, kh, kw), fp32 result
+        double s = 0.0;
+        for (int i = tid; i < n; i += 256) s += (double)wo[i];
+        sh[tid] = s;
+        __syncthreads();
+        for (int k = 128; k > 0; k >>= 1) { if (tid < k) sh[tid] += sh[tid + k]; __syncthreads(); }
+        const double m = sh[0] / n;
+        __syncthreads();
+        double v = 0.0;
+        for (int i = tid; i < n; i += 256) { const double d = (double)wo[i] - m; v += d * d; }
+        sh[tid] = v;
+        __syncthreads();
+        for (int k = 128; k > 0; k >>= 1) { if (tid < k) sh[tid] += sh[tid + k]; __syncthreads(); }
+        mean = (float)m;
+        rstd = rsqrtf((float)(sh[0] / n) + ws_eps);
+    }
+    const int c8n = Cin_pad / 8;
+    for (int i = tid; i < Cin_pad * taps; i += 256) {
+        const int cp = i / taps, tap = i % taps;     // cp: engine channel index
+        float v = 0.0f;
+        if (cp < Cin) {
+            int ci = cp;
+            if (unshuffle) {                          // engine order (p1 p2) c  <-  reference c (p1 p2), DD:97
+                const int Cq = Cin / 4, sub = cp / Cq, c = cp % Cq;
+                ci = c * 4 + sub;
+            }
+            v = (wo[(size_t)ci * taps + tap] - mean) * rstd;
+        }
+        out[(((size_t)tap * c8n + cp / 8) * Cout + o) * 8 + (cp % 8)] = f2bf(v);
+    }
+}
+
+template <int KS, int BN>
+static int launch_conv(const ConvParams& P, hipStream_t s) {
+    using C = Cfg<KS, BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OFD_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<KS, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set = true;
+    }
+    dim3 grid(P.tiles_x * P.tiles_y * P.B, P.Cout / BN);
+    conv_igemm_kernel<KS, BN><<<grid, NTHREADS, C::LDS_BYTES, s>>>(P);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
+    OFD_CHECK_ARG(a && a->out && a->weight, "conv: null out/weight");
+    OFD_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0, "conv: bad shape");
+    OFD_CHECK_ARG(a->ksize == 1 || a->ksize == 3 || a->ksize == 7, "conv: ksize %d unsupported", a->ksize);
+    OFD_CHECK_ARG(a->Cout > 0 && a->Cout % 64 == 0, "conv: Cout=%d must be a multiple of 64", a->Cout);
+    OFD_CHECK_ARG(a->n_src >= 1 && a->n_src <= 4, "conv: n_src=%d", a->n_src);
+    OFD_CHECK_ARG(!(a->in_scale) == !(a->in_shift), "conv: in_scale/in_shift must come together");
+    OFD_CHECK_ARG(!a->res_act || (a->res_scale && a->res_shift), "conv: res_act needs res_scale/res_shift");
+    const int ck = a->ksize == 7 ? 16 : 64;
+    ConvParams P{};
+    P.B = a->B; P.H = a->H; P.W = a->W; P.Cout = a->Cout; P.n_src = a->n_src;
+    P.tiles_x = cdiv(a->W, TW); P.tiles_y = cdiv(a->H, TH);
+    OFD_CHECK_ARG((long)P.tiles_x * P.tiles_y * P.B < (1l << 31), "conv: too many tiles");
+    int cin = 0;
+    for (int i = 0; i < a->n_src; ++i) {
+        const ofd_conv_src& s_ = a->src[i];
+        OFD_CHECK_ARG(s_.src && s_.channels > 0 && s_.channels % ck == 0, "conv: source %d channels=%d must be a multiple of %d", i, s_.channels, ck);
+        OFD_CHECK_ARG(s_.ch_offset % 8 == 0 && s_.src_channels % 8 == 0 && s_.ch_offset + s_.channels <= s_.src_channels,
+                      "conv: source %d channel window [%d,+%d) of %d", i, s_.ch_offset, s_.channels, s_.src_channels);
+        OFD_CHECK_ARG(!(s_.upsample && s_.unshuffle), "conv: source %d both upsample and unshuffle", i);
+        OFD_CHECK_ARG(!s_.upsample || (a->H % 2 == 0 && a->W % 2 == 0), "conv: upsample needs even output size");
+        ConvSrcDev& d = P.src[i];
+        d.ptr = (const bf16_t*)s_.src; d.chunks = s_.channels / ck; d.src_channels = s_.src_channels; d.ch_offset = s_.ch_offset;
+        d.mode = s_.upsample ? 1 : (s_.unshuffle ? 2 : 0);
+        d.SH = s_.upsample ? a->H / 2 : (s_.unshuffle ? a->H * 2 : a->H);
+        d.SW = s_.upsample ? a->W / 2 : (s_.unshuffle ? a->W * 2 : a->W);
+        d.p1 = s_.p1; d.p2 = s_.p2;
+        cin += s_.channels;
+        P.total_chunks += d.chunks;
+    }
+    P.Cin_total = cin;
+    OFD_CHECK_ARG(a->ksize != 7 || (P.total_chunks == 1 && a->Cout == 64 && !a->in_scale), "conv: 7x7 supports one 16-channel source, Cout=64");
+    P.weight = (const bf16_t*)a->weight; P.bias = a->bias; P.in_scale = a->in_scale; P.in_shift = a->in_shift;
+    P.residual = (const bf16_t*)a->residual; P.res_act = (const bf16_t*)a->res_act; P.res_scale = a->res_scale; P.res_shift = a->res_shift;
+    P.out = (bf16_t*)a->out; P.gn_partial = a->gn_partial;
+    const bool wide = (a->Cout % 128 == 0);
+    if (a->ksize == 3) return wide ? launch_conv<3, 128>(P, s) : launch_conv<3, 64>(P, s);
+    if (a->ksize == 1) return wide ? launch_conv<1, 128>(P, s) : launch_conv<1, 64>(P, s);
+    return launch_conv<7, 64>(P, s);
+}
+
+}  // namespace ofd
+using namespace ofd;
+
+extern "C" int ofd_conv_forward(const ofd_conv_args* a, void* stream) { return conv_forward_impl(a, (hipStream_t)stream); }
+
+extern "C" size_t ofd_conv_gn_partial_count(int B, int H, int W, int Cout) {
+    return (size_t)B * cdiv(H, TH) * cdiv(W, TW) * (Cout / 8) * 2;
+}
+
+extern "C" size_t ofd_conv_weight_elems(int Cout, int Cin_pad, int ksize) { return (size_t)ksize * ksize * Cin_pad * Cout; }
+
+extern "C" int ofd_conv_weight_prep(const float* w_oihw, void* w_out, int Cout, int Cin, int Cin_pad, int ksize, float ws_eps,
+                                    int unshuffle, void* stream) {
+    OFD_CHECK_ARG(w_oihw && w_out && Cout > 0 && Cin > 0 && Cin_pad >= Cin && Cin_pad % 8 == 0, "weight_prep: bad argument");
+    OFD_CHECK_ARG(!unshuffle || (Cin % 4 == 0 && Cin == Cin_pad), "weight_prep: unshuffle needs Cin %% 4 == 0");
+    conv_weight_prep_kernel<<<Cout, 256, 0, (hipStream_t)stream>>>(w_oihw, (bf16_t*)w_out, Cout, Cin, Cin_pad, ksize, ws_eps, unshuffle);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}

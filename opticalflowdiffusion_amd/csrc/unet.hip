@@ -1,0 +1,644 @@
+// UNet executor: one C call runs the whole forward of denoising_diffusion.py:363-417 as a fixed
+// sequence of HIP launches on the caller's stream.  Parameters keep the reference's state-dict
+// names and order (denoising_diffusion.py:272-361; registration order downs, ups, mid).
+// Host code only: every kernel lives in conv_igemm.hip / blocks.hip.
+#include <map>
+#include <string>
+#include <vector>
+#include "blocks.h"
+
+namespace ofd {
+
+struct Param {
+    std::string name;
+    int ndim;
+    int shape[4];
+    size_t numel;
+    size_t offset;   // floats into d_params (16-byte aligned)
+    bool set;
+};
+
+struct ConvDesc {
+    std::string wname;   // "<prefix>.weight"
+    int Cout, Cin, Cin_pad, ksize;
+    float ws_eps;        // < 0: plain conv
+    int unshuffle;
+    size_t w_off;        // bf16 elements into d_wbuf
+};
+
+struct Tensor {
+    bf16_t* p = nullptr;
+    int C = 0, H = 0, W = 0;
+};
+
+enum ProfClass { PC_CONV3 = 0, PC_CONV1, PC_CONV7, PC_GN, PC_RESOUT, PC_LN, PC_LINATTN, PC_FLASH, PC_MISC, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"conv3x3_igemm", "conv1x1_igemm", "conv7x7_igemm", "gn_finalize", "resblock_out",
+                                           "layernorm_c", "linear_attention_core", "flash_attention_d32", "misc"};
+
+struct ProfRec {
+    int cls;
+    hipEvent_t e0, e1;
+    double flops, bytes;
+};
+
+}  // namespace ofd
+
+using namespace ofd;
+
+struct ofd_unet {
+    ofd_unet_config cfg;
+    std::vector<int> dims;        // [dim, dim*1, dim*2, dim*4, dim*8]
+    std::vector<Param> params;
+    std::map<std::string, int> pindex;
+    std::vector<ConvDesc> convs;
+    std::map<std::string, int> cindex;
+    std::vector<std::string> resblocks;       // names in forward order
+    std::map<std::string, int> ss_offset;     // resblock -> offset in the scale/shift row
+    int ss_stride = 0;
+    float* d_params = nullptr;
+    size_t n_param_floats = 0;
+    bf16_t* d_wbuf = nullptr;
+    size_t n_wbuf = 0;
+    MlpDesc* d_mlp = nullptr;
+    bool prepared = false;
+    // last forward: taps
+    std::map<std::string, Tensor> taps;
+    int last_B = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;
+    double acc_ms[PC_COUNT] = {0}, acc_flops[PC_COUNT] = {0}, acc_bytes[PC_COUNT] = {0};
+    long long acc_launch[PC_COUNT] = {0};
+
+    const float* P(const std::string& n) const {
+        auto it = pindex.find(n);
+        return it == pindex.end() ? nullptr : d_params + params[it->second].offset;
+    }
+    const bf16_t* CW(const std::string& prefix) const { return d_wbuf + convs[cindex.at(prefix)].w_off; }
+};
+
+namespace ofd {
+
+static float site_eps(const ofd_unet* u, const std::string& site) {
+    // eps the reference uses at this site (DD:107, DD:122).  eps_mode 0 = fp32 activations
+    // everywhere; eps_mode 1 = dtype flow of bf16 autocast: 1e-3 only where the site's input is
+    // a bare conv output (see DESIGN.md "Numerics contract").
+    if (u->cfg.eps_mode == 0) return 1e-5f;
+    auto ends = [&](const char* s) { std::string t(s); return site.size() >= t.size() && site.compare(site.size() - t.size(), t.size(), t) == 0; };
+    if (ends(".fn.fn.to_out.1")) return 1e-3f;
+    if (ends(".0.block1.proj") && site.rfind("downs.", 0) == 0) return 1e-3f;
+    if (site == "mid_block1.block1.proj" || site == "final_res_block.block1.proj") return 1e-3f;
+    return 1e-5f;
+}
+
+static void add_param(ofd_unet* u, const std::string& name, std::vector<int> shape) {
+    size_t numel = 1;
+    for (int d : shape) numel *= (size_t)d;
+    Param p{name, (int)shape.size(), {1, 1, 1, 1}, numel, u->n_param_floats, false};
+    for (size_t i = 0; i < shape.size(); ++i) p.shape[i] = shape[i];
+    u->pindex[name] = (int)u->params.size();
+    u->params.push_back(p);
+    u->n_param_floats += (numel + 3) / 4 * 4;
+}
+
+static void add_conv(ofd_unet* u, const std::string& prefix, int co, int ci, int k, bool bias, float ws_eps, int unshuffle = 0) {
+    add_param(u, prefix + ".weight", {co, ci, k, k});
+    if (bias) add_param(u, prefix + ".bias", {co});
+    ConvDesc c{prefix + ".weight", co, ci, (k == 7) ? 16 : ci, k, ws_eps, unshuffle, u->n_wbuf};
+    u->n_wbuf += (size_t)k * k * c.Cin_pad * co;
+    u->cindex[prefix] = (int)u->convs.size();
+    u->convs.push_back(c);
+}
+
+static void add_resblock(ofd_unet* u, const std::string& name, int ci, int co) {
+    const int tdim = u->cfg.dim * 4;
+    add_param(u, name + ".mlp.1.weight", {co * 2, tdim});
+    add_param(u, name + ".mlp.1.bias", {co * 2});
+    add_conv(u, name + ".block1.proj", co, ci, 3, true, site_eps(u, name + ".block1.proj"));
+    add_param(u, name + ".block1.norm.weight", {co});
+    add_param(u, name + ".block1.norm.bias", {co});
+    add_conv(u, name + ".block2.proj", co, co, 3, true, site_eps(u, name + ".block2.proj"));
+    add_param(u, name + ".block2.norm.weight", {co});
+    add_param(u, name + ".block2.norm.bias", {co});
+    if (ci != co) add_conv(u, name + ".res_conv", co, ci, 1, true, -1.0f);
+    u->ss_offset[name] = u->ss_stride;
+    u->ss_stride += 2 * co;
+}
+
+static void add_linattn(ofd_unet* u, const std::string& name, int c) {
+    add_conv(u, name + ".fn.fn.to_qkv", 384, c, 1, false, -1.0f);
+    add_conv(u, name + ".fn.fn.to_out.0", c, 128, 1, true, -1.0f);
+    add_param(u, name + ".fn.fn.to_out.1.g", {1, c, 1, 1});
+    add_param(u, name + ".fn.norm.g", {1, c, 1, 1});
+}
+
+static void build_registry(ofd_unet* u) {
+    const int dim = u->cfg.dim;
+    u->dims = {dim, dim, dim * 2, dim * 4, dim * 8};
+    const int tdim = dim * 4;
+    add_conv(u, "init_conv", dim, u->cfg.channels, 7, true, -1.0f);
+    add_param(u, "time_mlp.1.weight", {tdim, dim});
+    add_param(u, "time_mlp.1.bias", {tdim});
+    add_param(u, "time_mlp.3.weight", {tdim, tdim});
+    add_param(u, "time_mlp.3.bias", {tdim});
+    for (int i = 0; i < 4; ++i) {
+        const int ci = u->dims[i], co = u->dims[i + 1];
+        const std::string p = "downs." + std::to_string(i);
+        add_resblock(u, p + ".0", ci, ci);
+        add_resblock(u, p + ".1", ci, ci);
+        add_linattn(u, p + ".2", ci);
+        if (i < 3) add_conv(u, p + ".3.1", co, ci * 4, 1, true, -1.0f, 1);
+        else add_conv(u, p + ".3", co, ci, 3, true, -1.0f);
+    }
+    for (int i = 0; i < 4; ++i) {
+        const int ci = u->dims[3 - i], co = u->dims[4 - i];
+        const std::string p = "ups." + std::to_string(i);
+        add_resblock(u, p + ".0", co + ci, co);
+        add_resblock(u, p + ".1", co + ci, co);
+        add_linattn(u, p + ".2", co);
+        if (i < 3) add_conv(u, p + ".3.1", ci, co, 3, true, -1.0f);
+        else add_conv(u, p + ".3", ci, co, 3, true, -1.0f);
+    }
+    const int mid = u->dims[4];
+    add_resblock(u, "mid_block1", mid, mid);
+    add_conv(u, "mid_attn.fn.fn.to_qkv", 384, mid, 1, false, -1.0f);
+    add_conv(u, "mid_attn.fn.fn.to_out", mid, 128, 1, true, -1.0f);
+    add_param(u, "mid_attn.fn.norm.g", {1, mid, 1, 1});
+    add_resblock(u, "mid_block2", mid, mid);
+    add_resblock(u, "final_res_block", dim * 2, dim);
+    add_param(u, "final_conv.weight", {u->cfg.out_dim, dim, 1, 1});
+    add_param(u, "final_conv.bias", {u->cfg.out_dim});
+    // forward order of the ResnetBlocks = order of their scale/shift rows (any fixed order works)
+    for (auto& kv : u->ss_offset) u->resblocks.push_back(kv.first);
+}
+
+// ------------------------------------------------------------------------------- forward context
+struct Ctx {
+    ofd_unet* u;
+    hipStream_t s;
+    int B;
+    char* persist;
+    size_t persist_cap, persist_used = 0;
+    char* scratch;
+    size_t scratch_cap, scratch_used = 0;
+    float* ss;
+    int rc = OFD_OK;
+
+    void* alloc(char* base, size_t& used, size_t cap, size_t bytes) {
+        bytes = (bytes + 255) / 256 * 256;
+        if (used + bytes > cap) {
+            if (rc == OFD_OK) { set_error("unet_forward: workspace too small"); rc = OFD_ERR_WORKSPACE; }
+            return nullptr;
+        }
+        void* p = base + used;
+        used += bytes;
+        return p;
+    }
+    Tensor keep(int C, int H, int W) {
+        Tensor t;
+        t.p = (bf16_t*)alloc(persist, persist_used, persist_cap, (size_t)B * H * W * C * 2);
+        t.C = C; t.H = H; t.W = W;
+        return t;
+    }
+    Tensor tmp(int C, int H, int W) {
+        Tensor t;
+        t.p = (bf16_t*)alloc(scratch, scratch_used, scratch_cap, (size_t)B * H * W * C * 2);
+        t.C = C; t.H = H; t.W = W;
+        return t;
+    }
+    float* tmpf(size_t n) { return (float*)alloc(scratch, scratch_used, scratch_cap, n * 4); }
+    void reset_scratch() { scratch_used = 0; }
+
+    // profiling bracket
+    void begin(int cls, double flops, double bytes) {
+        if (!u->profiling) return;
+        while (u->pool.size() < u->pool_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            u->pool.push_back(e);
+        }
+        ProfRec r{cls, u->pool[u->pool_used], u->pool[u->pool_used + 1], flops, bytes};
+        u->pool_used += 2;
+        hipEventRecord(r.e0, s);
+        u->recs.push_back(r);
+    }
+    void end() {
+        if (!u->profiling || u->recs.empty()) return;
+        hipEventRecord(u->recs.back().e1, s);
+    }
+};
+
+#define RUN(expr)                         \
+    do {                                  \
+        if (c.rc == OFD_OK) {             \
+            int rc__ = (expr);            \
+            if (rc__ != OFD_OK) c.rc = rc__; \
+        }                                 \
+    } while (0)
+
+struct SrcSpec {
+    Tensor t;
+    int upsample = 0;
+    int unshuffle = 0, p1 = 0, p2 = 0;
+};
+
+static void conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& srcs, Tensor out, const float* in_scale,
+                 const float* in_shift, const bf16_t* residual, const bf16_t* res_act, const float* res_scale,
+                 const float* res_shift, float* gn_partial) {
+    if (c.rc != OFD_OK) return;
+    const ConvDesc& d = c.u->convs[c.u->cindex.at(prefix)];
+    ofd_conv_args a{};
+    a.B = c.B; a.H = out.H; a.W = out.W; a.ksize = d.ksize; a.n_src = (int)srcs.size(); a.Cout = d.Cout;
+    int cin = 0;
+    for (size_t i = 0; i < srcs.size(); ++i) {
+        a.src[i].src = srcs[i].t.p;
+        a.src[i].channels = srcs[i].t.C;
+        a.src[i].src_channels = srcs[i].t.C;
+        a.src[i].ch_offset = 0;
+        a.src[i].upsample = srcs[i].upsample;
+        a.src[i].unshuffle = srcs[i].unshuffle;
+        a.src[i].p1 = srcs[i].p1;
+        a.src[i].p2 = srcs[i].p2;
+        cin += srcs[i].t.C;
+    }
+    if (cin != d.Cin_pad) { set_error("conv %s: got %d input channels, expected %d", prefix.c_str(), cin, d.Cin_pad); c.rc = OFD_ERR_ARG; return; }
+    a.weight = c.u->d_wbuf + d.w_off;
+    a.bias = c.u->P(prefix + ".bias");
+    a.in_scale = in_scale; a.in_shift = in_shift; a.residual = residual; a.res_act = res_act;
+    a.res_scale = res_scale; a.res_shift = res_shift; a.out = out.p; a.gn_partial = gn_partial;
+    const double px = (double)c.B * out.H * out.W;
+    const double flops = 2.0 * px * d.Cout * (double)d.Cin * d.ksize * d.ksize;   // counted as the reference executes
+    const double bytes = px * 2.0 * (d.Cout + (double)cin / ((srcs[0].upsample) ? 4 : 1)) + (double)d.ksize * d.ksize * d.Cin_pad * d.Cout * 2.0;
+    c.begin(d.ksize == 3 ? PC_CONV3 : (d.ksize == 1 ? PC_CONV1 : PC_CONV7), flops, bytes);
+    RUN(conv_forward_impl(&a, c.s));
+    c.end();
+}
+
+static Tensor resblock(Ctx& c, const std::string& name, const std::vector<Tensor>& in, int Cout, bool keep_out = true) {
+    ofd_unet* u = c.u;
+    const int H = in[0].H, W = in[0].W, B = c.B;
+    std::vector<SrcSpec> srcs;
+    int cin = 0;
+    for (auto& t : in) { SrcSpec s; s.t = t; srcs.push_back(s); cin += t.C; }
+    Tensor h1 = c.tmp(Cout, H, W), h2 = c.tmp(Cout, H, W);
+    const size_t np = ofd_conv_gn_partial_count(B, H, W, Cout);
+    float* p1 = c.tmpf(np);
+    float* p2 = c.tmpf(np);
+    float* a1 = c.tmpf((size_t)B * Cout);
+    float* s1 = c.tmpf((size_t)B * Cout);
+    float* a2 = c.tmpf((size_t)B * Cout);
+    float* s2 = c.tmpf((size_t)B * Cout);
+    Tensor out = keep_out ? c.keep(Cout, H, W) : c.tmp(Cout, H, W);
+    if (c.rc != OFD_OK) return out;
+    conv(c, name + ".block1.proj", srcs, h1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, p1);
+    c.begin(PC_GN, 0, (double)np * 4);
+    RUN(k_gn_finalize(p1, B, H, W, Cout, u->P(name + ".block1.norm.weight"), u->P(name + ".block1.norm.bias"), c.ss, u->ss_stride,
+                      u->ss_offset.at(name), a1, s1, c.s));
+    c.end();
+    SrcSpec hs; hs.t = h1;
+    conv(c, name + ".block2.proj", {hs}, h2, a1, s1, nullptr, nullptr, nullptr, nullptr, p2);
+    c.begin(PC_GN, 0, (double)np * 4);
+    RUN(k_gn_finalize(p2, B, H, W, Cout, u->P(name + ".block2.norm.weight"), u->P(name + ".block2.norm.bias"), nullptr, 0, 0, a2, s2, c.s));
+    c.end();
+    if (cin != Cout) {
+        conv(c, name + ".res_conv", srcs, out, nullptr, nullptr, nullptr, h2.p, a2, s2, nullptr);   // DD:214 fused into the 1x1
+    } else {
+        c.begin(PC_RESOUT, 0, (double)B * H * W * Cout * 6.0);
+        RUN(k_resblock_out(h2.p, a2, s2, in[0].p, out.p, B, H, W, Cout, c.s));
+        c.end();
+    }
+    return out;
+}
+
+static Tensor linattn(Ctx& c, const std::string& name, Tensor x) {
+    ofd_unet* u = c.u;
+    const int H = x.H, W = x.W, B = c.B, C = x.C, n = H * W;
+    Tensor xn = c.tmp(C, H, W), qkv = c.tmp(384, H, W), ao = c.tmp(128, H, W), o2 = c.tmp(C, H, W);
+    const int nparts = la_parts(n);
+    float* partial = c.tmpf((size_t)B * 4 * nparts * 1088);
+    float* ctx = c.tmpf((size_t)B * 4 * 1024);
+    Tensor y = c.keep(C, H, W);
+    if (c.rc != OFD_OK) return y;
+    const size_t npix = (size_t)B * n;
+    c.begin(PC_LN, 0, (double)npix * C * 4);
+    RUN(k_layernorm_c(x.p, u->P(name + ".fn.norm.g"), nullptr, xn.p, npix, C, site_eps(u, name + ".fn.norm"), c.s));
+    c.end();
+    SrcSpec s; s.t = xn;
+    conv(c, name + ".fn.fn.to_qkv", {s}, qkv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    c.begin(PC_LINATTN, 4.0 * npix * 4 * 32 * 32, (double)npix * (384 + 128 + 128) * 2);
+    RUN(k_linear_attention_core(qkv.p, partial, ctx, ao.p, B, n, c.s));
+    c.end();
+    SrcSpec s2; s2.t = ao;
+    conv(c, name + ".fn.fn.to_out.0", {s2}, o2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    c.begin(PC_LN, 0, (double)npix * C * 6);
+    RUN(k_layernorm_c(o2.p, u->P(name + ".fn.fn.to_out.1.g"), x.p, y.p, npix, C, site_eps(u, name + ".fn.fn.to_out.1"), c.s));
+    c.end();
+    return y;
+}
+
+static Tensor midattn(Ctx& c, Tensor x) {
+    ofd_unet* u = c.u;
+    const int H = x.H, W = x.W, B = c.B, C = x.C, n = H * W;
+    Tensor xn = c.tmp(C, H, W), qkv = c.tmp(384, H, W), ao = c.tmp(128, H, W);
+    Tensor y = c.keep(C, H, W);
+    if (c.rc != OFD_OK) return y;
+    const size_t npix = (size_t)B * n;
+    c.begin(PC_LN, 0, (double)npix * C * 4);
+    RUN(k_layernorm_c(x.p, u->P("mid_attn.fn.norm.g"), nullptr, xn.p, npix, C, site_eps(u, "mid_attn.fn.norm"), c.s));
+    c.end();
+    SrcSpec s; s.t = xn;
+    conv(c, "mid_attn.fn.fn.to_qkv", {s}, qkv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    c.begin(PC_FLASH, 4.0 * B * 4.0 * (double)n * n * 32, (double)npix * (384 + 128) * 2);
+    RUN(k_flash_attention(qkv.p, ao.p, B, n, c.s));
+    c.end();
+    SrcSpec s2; s2.t = ao;
+    conv(c, "mid_attn.fn.fn.to_out", {s2}, y, nullptr, nullptr, x.p, nullptr, nullptr, nullptr, nullptr);   // + x (DD:87)
+    return y;
+}
+
+static size_t persist_bytes(const ofd_unet* u, int B, int H, int W) {
+    // every kept tensor of the forward: r, 3 per down level, 1 resample per level, mid (3), 3+1 per up level, final
+    auto T = [&](int C, int h, int w) { return ((size_t)B * h * w * C * 2 + 255) / 256 * 256; };
+    size_t n = T(16, H, W) + T(u->dims[0], H, W);
+    int h = H, w = W;
+    for (int i = 0; i < 4; ++i) {
+        n += 3 * T(u->dims[i], h, w);
+        if (i < 3) { h /= 2; w /= 2; }
+        n += T(u->dims[i + 1], h, w);
+    }
+    n += 3 * T(u->dims[4], h, w);
+    for (int i = 0; i < 4; ++i) {
+        const int co = u->dims[4 - i], ci = u->dims[3 - i];
+        n += 3 * T(co, h, w);
+        if (i < 3) { h *= 2; w *= 2; }
+        n += T(ci, h, w);
+    }
+    n += T(u->dims[0], H, W);
+    return n + 4096;
+}
+
+static size_t scratch_bytes(const ofd_unet* u, int B, int H, int W) {
+    // largest per-block need, taken at full resolution with C = dim (the 1/2, 1/4, 1/8 levels
+    // have 2x channels on 1/4 of the pixels): h1 + h2 + out(tmp) + xn + qkv + ao + o2 + small
+    const size_t px = (size_t)B * H * W;
+    const int C = u->dims[0];
+    size_t act = px * 2 * (size_t)(3 * C + C + 384 + 128 + C);
+    // mid level widest: 512 ch at 1/64 of the pixels is far smaller; small buffers:
+    size_t small = 4 * ofd_conv_gn_partial_count(B, H, W, u->dims[4]) * 4 + (size_t)B * 4 * (la_parts(H * W) * 1088 + 1024) * 4 +
+                   16 * (size_t)B * u->dims[4] * 4 + 64 * 1024;
+    return act + small + 64 * 256;
+}
+
+static size_t small_bytes(const ofd_unet* u, int B) {
+    return ((size_t)B * u->ss_stride + 2 * (size_t)B * u->cfg.dim * 4) * 4 + 4096;
+}
+
+}  // namespace ofd
+
+extern "C" int ofd_unet_create(const ofd_unet_config* cfg, ofd_unet** out) {
+    OFD_CHECK_ARG(cfg && out, "unet_create: null argument");
+    OFD_CHECK_ARG(cfg->dim == 64, "unet_create: dim=%d unsupported (the FlowDiffuser UNet is Unet(64), flow_diffuser.py:106)", cfg->dim);
+    OFD_CHECK_ARG(cfg->channels >= 1 && cfg->channels <= 16, "unet_create: channels=%d (1..16)", cfg->channels);
+    OFD_CHECK_ARG(cfg->out_dim >= 1 && cfg->out_dim <= 4, "unet_create: out_dim=%d (1..4)", cfg->out_dim);
+    OFD_CHECK_ARG(cfg->eps_mode == 0 || cfg->eps_mode == 1, "unet_create: eps_mode=%d", cfg->eps_mode);
+    ofd_unet* u = new ofd_unet();
+    u->cfg = *cfg;
+    build_registry(u);
+    if (hipMalloc(&u->d_params, u->n_param_floats * sizeof(float)) != hipSuccess ||
+        hipMalloc(&u->d_wbuf, u->n_wbuf * sizeof(bf16_t)) != hipSuccess ||
+        hipMalloc(&u->d_mlp, u->resblocks.size() * sizeof(MlpDesc)) != hipSuccess) {
+        set_error("unet_create: hipMalloc failed");
+        ofd_unet_destroy(u);
+        return OFD_ERR_HIP;
+    }
+    hipMemset(u->d_params, 0, u->n_param_floats * sizeof(float));
+    std::vector<MlpDesc> descs;
+    for (auto& name : u->resblocks) {
+        MlpDesc d;
+        d.weight = u->P(name + ".mlp.1.weight");
+        d.bias = u->P(name + ".mlp.1.bias");
+        d.n_out = (int)u->params[u->pindex.at(name + ".mlp.1.bias")].numel;
+        d.offset = u->ss_offset.at(name);
+        descs.push_back(d);
+    }
+    hipMemcpy(u->d_mlp, descs.data(), descs.size() * sizeof(MlpDesc), hipMemcpyHostToDevice);
+    *out = u;
+    return OFD_OK;
+}
+
+extern "C" void ofd_unet_destroy(ofd_unet* u) {
+    if (!u) return;
+    if (u->d_params) hipFree(u->d_params);
+    if (u->d_wbuf) hipFree(u->d_wbuf);
+    if (u->d_mlp) hipFree(u->d_mlp);
+    for (auto e : u->pool) hipEventDestroy(e);
+    delete u;
+}
+
+extern "C" int ofd_unet_num_params(const ofd_unet* u) { return u ? (int)u->params.size() : 0; }
+extern "C" const char* ofd_unet_param_name(const ofd_unet* u, int i) {
+    return (u && i >= 0 && i < (int)u->params.size()) ? u->params[i].name.c_str() : "";
+}
+extern "C" size_t ofd_unet_param_numel(const ofd_unet* u, int i) {
+    return (u && i >= 0 && i < (int)u->params.size()) ? u->params[i].numel : 0;
+}
+
+extern "C" int ofd_unet_param_shape(const ofd_unet* u, int i, int* dims4) {
+    if (!u || i < 0 || i >= (int)u->params.size() || !dims4) return 0;
+    for (int k = 0; k < 4; ++k) dims4[k] = u->params[i].shape[k];
+    return u->params[i].ndim;
+}
+
+extern "C" int ofd_unet_set_param(ofd_unet* u, int i, const float* dev_src, size_t numel, void* stream) {
+    OFD_CHECK_ARG(u && dev_src && i >= 0 && i < (int)u->params.size(), "unet_set_param: bad argument");
+    Param& p = u->params[i];
+    OFD_CHECK_ARG(numel == p.numel, "unet_set_param: %s has %zu elements, got %zu", p.name.c_str(), p.numel, numel);
+    OFD_HIP(hipMemcpyAsync(u->d_params + p.offset, dev_src, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    p.set = true;
+    u->prepared = false;
+    return OFD_OK;
+}
+
+extern "C" int ofd_unet_prepare(ofd_unet* u, void* stream) {
+    OFD_CHECK_ARG(u, "unet_prepare: null handle");
+    for (auto& p : u->params)
+        if (!p.set) {
+            set_error("unet_prepare: parameter %s was never set", p.name.c_str());
+            return OFD_ERR_STATE;
+        }
+    for (auto& c : u->convs) {
+        int rc = ofd_conv_weight_prep(u->P(c.wname), u->d_wbuf + c.w_off, c.Cout, c.Cin, c.Cin_pad, c.ksize, c.ws_eps, c.unshuffle, stream);
+        if (rc != OFD_OK) return rc;
+    }
+    u->prepared = true;
+    return OFD_OK;
+}
+
+extern "C" size_t ofd_unet_workspace_bytes(const ofd_unet* u, int B, int H, int W) {
+    if (!u || B <= 0 || H <= 0 || W <= 0) return 0;
+    return persist_bytes(u, B, H, W) + scratch_bytes(u, B, H, W) + small_bytes(u, B) + 1024;
+}
+
+extern "C" int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float* cond, int Cc, const int64_t* t, float* out,
+                                int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+    OFD_CHECK_ARG(u && x && t && out && workspace, "unet_forward: null argument");
+    OFD_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "unet_forward: H=%d W=%d must be positive multiples of 8 (three 2x down-samplings, DD:95-99)", H, W);
+    OFD_CHECK_ARG(Cx + (cond ? Cc : 0) == u->cfg.channels, "unet_forward: %d + %d input channels, UNet has %d", Cx, cond ? Cc : 0, u->cfg.channels);
+    if (!u->prepared) { set_error("unet_forward: call ofd_unet_prepare after setting parameters"); return OFD_ERR_STATE; }
+    if (workspace_bytes < ofd_unet_workspace_bytes(u, B, H, W)) {
+        set_error("unet_forward: workspace %zu < %zu", workspace_bytes, ofd_unet_workspace_bytes(u, B, H, W));
+        return OFD_ERR_WORKSPACE;
+    }
+    OFD_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "unet_forward: workspace must be 256-byte aligned");
+    Ctx c;
+    c.u = u; c.s = (hipStream_t)stream; c.B = B;
+    char* w = (char*)workspace;
+    const size_t sb = (small_bytes(u, B) + 255) / 256 * 256;
+    float* fsmall = (float*)w;
+    c.ss = fsmall;
+    float* temb = fsmall + (size_t)B * u->ss_stride;
+    float* temb_silu = temb + (size_t)B * u->cfg.dim * 4;
+    c.persist = w + sb;
+    c.persist_cap = persist_bytes(u, B, H, W);
+    c.scratch = c.persist + (c.persist_cap + 255) / 256 * 256;
+    c.scratch_cap = workspace_bytes - (size_t)(c.scratch - w);
+    u->taps.clear();
+    u->last_B = B;
+    const int dim = u->cfg.dim;
+
+    Tensor xin = c.keep(16, H, W);
+    c.begin(PC_MISC, 0, 0);
+    RUN(k_pack_input(x, Cx, cond, cond ? Cc : 0, xin.p, B, H, W, c.s));
+    RUN(k_time_mlp(t, u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"), u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), temb, temb_silu, B, dim, c.s));
+    RUN(k_block_mlp(temb_silu, u->d_mlp, (int)u->resblocks.size(), c.ss, B, dim * 4, u->ss_stride, c.s));
+    c.end();
+    Tensor r = c.keep(dim, H, W);
+    { SrcSpec s; s.t = xin; conv(c, "init_conv", {s}, r, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); }
+    u->taps["init_conv"] = r;
+
+    Tensor xcur = r;
+    std::vector<Tensor> hs;
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "downs." + std::to_string(i);
+        c.reset_scratch();
+        xcur = resblock(c, p + ".0", {xcur}, u->dims[i]);
+        hs.push_back(xcur);
+        u->taps[p + ".0"] = xcur;
+        c.reset_scratch();
+        Tensor x1 = resblock(c, p + ".1", {xcur}, u->dims[i]);
+        u->taps[p + ".1"] = x1;
+        c.reset_scratch();
+        xcur = linattn(c, p + ".2", x1);
+        hs.push_back(xcur);
+        u->taps[p + ".2"] = xcur;
+        if (i < 3) {
+            Tensor d = c.keep(u->dims[i + 1], xcur.H / 2, xcur.W / 2);
+            std::vector<SrcSpec> srcs;
+            for (int sub = 0; sub < 4; ++sub) { SrcSpec s; s.t = xcur; s.unshuffle = 1; s.p1 = sub >> 1; s.p2 = sub & 1; srcs.push_back(s); }
+            conv(c, p + ".3.1", srcs, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            xcur = d;
+        } else {
+            Tensor d = c.keep(u->dims[i + 1], xcur.H, xcur.W);
+            SrcSpec s; s.t = xcur;
+            conv(c, p + ".3", {s}, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            xcur = d;
+        }
+        u->taps[p + ".3"] = xcur;
+    }
+    c.reset_scratch();
+    xcur = resblock(c, "mid_block1", {xcur}, u->dims[4]);
+    u->taps["mid_block1"] = xcur;
+    c.reset_scratch();
+    xcur = midattn(c, xcur);
+    u->taps["mid_attn"] = xcur;
+    c.reset_scratch();
+    xcur = resblock(c, "mid_block2", {xcur}, u->dims[4]);
+    u->taps["mid_block2"] = xcur;
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "ups." + std::to_string(i);
+        const int co = u->dims[4 - i], ci = u->dims[3 - i];
+        c.reset_scratch();
+        Tensor h = hs.back(); hs.pop_back();
+        xcur = resblock(c, p + ".0", {xcur, h}, co);
+        u->taps[p + ".0"] = xcur;
+        c.reset_scratch();
+        h = hs.back(); hs.pop_back();
+        xcur = resblock(c, p + ".1", {xcur, h}, co);
+        u->taps[p + ".1"] = xcur;
+        c.reset_scratch();
+        xcur = linattn(c, p + ".2", xcur);
+        u->taps[p + ".2"] = xcur;
+        if (i < 3) {
+            Tensor d = c.keep(ci, xcur.H * 2, xcur.W * 2);
+            SrcSpec s; s.t = xcur; s.upsample = 1;
+            conv(c, p + ".3.1", {s}, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            xcur = d;
+        } else {
+            Tensor d = c.keep(ci, xcur.H, xcur.W);
+            SrcSpec s; s.t = xcur;
+            conv(c, p + ".3", {s}, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            xcur = d;
+        }
+        u->taps[p + ".3"] = xcur;
+    }
+    c.reset_scratch();
+    xcur = resblock(c, "final_res_block", {xcur, r}, dim);
+    u->taps["final_res_block"] = xcur;
+    c.begin(PC_MISC, 2.0 * B * H * W * dim * u->cfg.out_dim, (double)B * H * W * (dim * 2 + u->cfg.out_dim * 4));
+    RUN(k_final_conv(xcur.p, u->P("final_conv.weight"), u->P("final_conv.bias"), out, B, H, W, dim, u->cfg.out_dim, c.s));
+    c.end();
+    return c.rc;
+}
+
+extern "C" int ofd_unet_read_tap(ofd_unet* u, const char* name, float* dst, size_t numel, void* stream) {
+    OFD_CHECK_ARG(u && name && dst, "unet_read_tap: null argument");
+    auto it = u->taps.find(name);
+    OFD_CHECK_ARG(it != u->taps.end(), "unet_read_tap: no tap named '%s' in the last forward", name);
+    const Tensor& t = it->second;
+    OFD_CHECK_ARG(numel == (size_t)u->last_B * t.C * t.H * t.W, "unet_read_tap: %s has %zu elements, got %zu", name,
+                  (size_t)u->last_B * t.C * t.H * t.W, numel);
+    return k_nhwc_to_nchw(t.p, dst, u->last_B, t.H, t.W, t.C, (hipStream_t)stream);
+}
+
+extern "C" int ofd_unet_set_profiling(ofd_unet* u, int enabled) {
+    OFD_CHECK_ARG(u, "unet_set_profiling: null handle");
+    u->profiling = enabled != 0;
+    return OFD_OK;
+}
+extern "C" int ofd_unet_prof_count(const ofd_unet* u) { return u ? PC_COUNT : 0; }
+extern "C" const char* ofd_unet_prof_name(const ofd_unet* u, int i) { return (u && i >= 0 && i < PC_COUNT) ? kProfNames[i] : ""; }
+
+static int prof_resolve(ofd_unet* u) {
+    for (auto& r : u->recs) {
+        OFD_HIP(hipEventSynchronize(r.e1));
+        float ms = 0.0f;
+        OFD_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        u->acc_ms[r.cls] += ms;
+        u->acc_flops[r.cls] += r.flops;
+        u->acc_bytes[r.cls] += r.bytes;
+        u->acc_launch[r.cls] += 1;
+    }
+    u->recs.clear();
+    u->pool_used = 0;
+    return OFD_OK;
+}
+
+extern "C" int ofd_unet_prof_read(ofd_unet* u, int i, double* ms, long long* launches, double* flops, double* bytes) {
+    OFD_CHECK_ARG(u && i >= 0 && i < PC_COUNT, "unet_prof_read: bad argument");
+    int rc = prof_resolve(u);
+    if (rc != OFD_OK) return rc;
+    if (ms) *ms = u->acc_ms[i];
+    if (launches) *launches = u->acc_launch[i];
+    if (flops) *flops = u->acc_flops[i];
+    if (bytes) *bytes = u->acc_bytes[i];
+    return OFD_OK;
+}
+
+extern "C" int ofd_unet_prof_reset(ofd_unet* u) {
+    OFD_CHECK_ARG(u, "unet_prof_reset: null handle");
+    int rc = prof_resolve(u);
+    for (int i = 0; i < PC_COUNT; ++i) { u->acc_ms[i] = 0; u->acc_flops[i] = 0; u->acc_bytes[i] = 0; u->acc_launch[i] = 0; }
+    return rc;
+}

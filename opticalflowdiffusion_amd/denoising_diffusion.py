@@ -1,0 +1,438 @@
+"""`Unet` and `ConditionalDiffusion` with the reference's interface
+(algorithms/diffusion_animation/denoising_diffusion.py, "DD"), executed by libofd_hip.
+
+`Unet(dim, channels=, out_dim=, time_in=True)` owns fp32 `nn.Parameter`s under the reference's
+state-dict names (DD:272-361), so reference checkpoints load with `load_state_dict`.  Its
+forward is ONE C call (`ofd_unet_forward`) that runs the hand-written HIP kernels; there is no
+PyTorch fallback.  `ConditionalDiffusion` restates DD:463-993 for the configuration FlowDiffuser
+builds (FD:118-127) with the elementwise steps fused into single HIP kernels, generalised to
+non-square `image_size=(H, W)` and with a working DDIM path.
+"""
+import ctypes
+import math
+from collections import namedtuple
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from .warp import nan_mse
+
+ModelPrediction = namedtuple("ModelPrediction", ["pred_noise", "pred_x_start", "additional_out"])
+
+
+def exists(x):
+    return x is not None
+
+
+def default(val, d):
+    if exists(val):
+        return val
+    return d() if callable(d) else d
+
+
+def identity(t, *args, **kwargs):
+    return t
+
+
+class _Node(nn.Module):
+    """Parameter container that reproduces the reference's module tree in state-dict keys."""
+
+
+def _registry(dim, channels, out_dim, eps_mode):
+    """(handle, [(name, shape)]) from the C library, which owns the layer table."""
+    lib = L.lib()
+    cfg = L.UnetConfig(dim, channels, out_dim, eps_mode)
+    h = ctypes.c_void_p()
+    L.check(lib.ofd_unet_create(ctypes.byref(cfg), ctypes.byref(h)))
+    names = []
+    dims = (ctypes.c_int * 4)()
+    for i in range(lib.ofd_unet_num_params(h)):
+        nd = lib.ofd_unet_param_shape(h, i, dims)
+        names.append((lib.ofd_unet_param_name(h, i).decode(), tuple(dims[k] for k in range(nd))))
+    return h, names
+
+
+class Unet(nn.Module):
+    """DD:272-417.  Supported: dim=64, dim_mults=(1,2,4,8), time_in=True, no self-conditioning --
+    the UNet FlowDiffuser instantiates (FD:106-111)."""
+
+    def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=3, self_condition=False,
+                 resnet_block_groups=8, learned_variance=False, learned_sinusoidal_cond=False,
+                 random_fourier_features=False, learned_sinusoidal_dim=16, time_in=True, precision="bf16"):
+        super().__init__()
+        if (dim != 64 or tuple(dim_mults) != (1, 2, 4, 8) or self_condition or learned_variance or learned_sinusoidal_cond
+                or random_fourier_features or not time_in or resnet_block_groups != 8 or init_dim not in (None, dim)):
+            raise NotImplementedError("the HIP engine implements the FlowDiffuser UNet: Unet(64, channels=, out_dim=, time_in=True)")
+        self.channels = channels
+        self.self_condition = False
+        self.time_in = True
+        self.random_or_learned_sinusoidal_cond = False
+        self.out_dim = default(out_dim, channels)
+        self.dim = dim
+        # eps_mode 1: per-site eps of the reference under bf16 autocast (DD:107,122); 0: fp32 rule
+        self.eps_mode = 1 if precision == "bf16" else 0
+        self._handle, reg = _registry(dim, channels, self.out_dim, self.eps_mode)
+        self._names = [n for n, _ in reg]
+        gen = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+        fan_in = 1
+        for name, shape in reg:
+            if name.endswith(".weight") and len(shape) > 1:
+                fan_in = 1
+                for s_ in shape[1:]:
+                    fan_in *= s_
+            self._add(name, nn.Parameter(self._init(name, shape, gen, fan_in)))
+        self._synced = {}
+        self._ws = None
+
+    # -- parameter tree ----------------------------------------------------------------------
+    def _add(self, name, param):
+        node = self
+        parts = name.split(".")
+        for p in parts[:-1]:
+            if p not in node._modules:
+                node.add_module(p, _Node())
+            node = node._modules[p]
+        node.register_parameter(parts[-1], param)
+
+    @staticmethod
+    def _init(name, shape, gen, fan_in):
+        """PyTorch default initialisation of the corresponding reference layers (Conv2d / Linear:
+        kaiming_uniform_(a=sqrt(5)) == U(+-1/sqrt(fan_in)) for weight and bias; norms: ones / zeros)."""
+        if name.endswith(".g") or name.endswith("norm.weight"):
+            return torch.ones(shape)
+        if name.endswith("norm.bias"):
+            return torch.zeros(shape)
+        bound = 1.0 / math.sqrt(fan_in)
+        return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+
+    def _param(self, name):
+        node = self
+        for p in name.split("."):
+            node = node._modules[p] if p in node._modules else node._parameters[p]
+        return node
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None):
+                L.lib().ofd_unet_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    # -- execution ---------------------------------------------------------------------------
+    def _sync_params(self, device):
+        lib = L.lib()
+        dirty = False
+        for i, name in enumerate(self._names):
+            p = self._param(name)
+            key = (p.data_ptr(), p._version, str(p.device))
+            if self._synced.get(name) != key:
+                src = p.detach()
+                if src.device != device or src.dtype != torch.float32 or not src.is_contiguous():
+                    src = src.to(device=device, dtype=torch.float32).contiguous()
+                L.check(lib.ofd_unet_set_param(self._handle, i, L.ptr(src), src.numel(), L.stream()))
+                self._synced[name] = key      # (a temporary `src` is safe to drop: same-stream ordering)
+                dirty = True
+        if dirty:
+            L.check(lib.ofd_unet_prepare(self._handle, L.stream()))
+
+    def _workspace(self, device, B, H, W):
+        need = L.lib().ofd_unet_workspace_bytes(self._handle, B, H, W)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def forward(self, x, external_cond=None, time=None, x_self_cond=None, additional_out=False):
+        if additional_out:
+            raise ValueError("additional tgt not supported for non warp Unet")             # DD:364-365
+        if time is None:
+            raise ValueError("when Unet takes time arg, time argument must be passed in")  # DD:378-379
+        L.require_gpu(x, external_cond, time)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise L.OfdError("Unet.forward under autograd: the HIP backward pass is not part of this build; "
+                             "wrap inference/sampling in torch.no_grad()")
+        x = L.f32c(x)
+        cond = L.f32c(external_cond) if external_cond is not None else None
+        B, Cx, H, W = x.shape
+        Cc = cond.shape[1] if cond is not None else 0
+        t = time.to(torch.int64).contiguous()
+        self._sync_params(x.device)
+        ws = self._workspace(x.device, B, H, W)
+        out = torch.empty(B, self.out_dim, H, W, dtype=torch.float32, device=x.device)
+        L.check(L.lib().ofd_unet_forward(self._handle, L.ptr(x), Cx, L.ptr(cond), Cc, L.ptr(t), L.ptr(out), B, H, W,
+                                         L.ptr(ws), ws.numel(), L.stream()))
+        return out
+
+    def read_tap(self, name, shape):
+        """named intermediate of the last forward as NCHW fp32 (parity tests)."""
+        out = torch.empty(shape, dtype=torch.float32, device=self._ws.device)
+        L.check(L.lib().ofd_unet_read_tap(self._handle, name.encode(), L.ptr(out), out.numel(), L.stream()))
+        return out
+
+    # -- per-kernel-class device timing (HIP events on the launch stream) ----------------------
+    def set_profiling(self, enabled):
+        L.check(L.lib().ofd_unet_set_profiling(self._handle, int(enabled)))
+
+    def profile(self, reset=False):
+        lib = L.lib()
+        res = {}
+        for i in range(lib.ofd_unet_prof_count(self._handle)):
+            ms, n, fl, by = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double(), ctypes.c_double()
+            L.check(lib.ofd_unet_prof_read(self._handle, i, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by)))
+            res[lib.ofd_unet_prof_name(self._handle, i).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+        if reset:
+            L.check(lib.ofd_unet_prof_reset(self._handle))
+        return res
+
+
+# ------------------------------------------------------------------------------------ schedules
+def extract(a, t, x_shape):
+    """DD:422-425."""
+    b, *_ = t.shape
+    out = a.gather(-1, t)
+    return out.reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+def sigmoid_beta_schedule(timesteps, start=-3, end=3, tau=1, clamp_min=1e-5):
+    """DD:448-461."""
+    steps = timesteps + 1
+    t = torch.linspace(0, timesteps, steps, dtype=torch.float64) / timesteps
+    v_start = torch.tensor(start / tau).sigmoid()
+    v_end = torch.tensor(end / tau).sigmoid()
+    alphas_cumprod = (-((t * (end - start) + start) / tau).sigmoid() + v_end) / (v_end - v_start)
+    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+    return torch.clip(betas, 0, 0.999)
+
+
+def linear_beta_schedule(timesteps):
+    """DD:427-434."""
+    scale = 1000 / timesteps
+    return torch.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=torch.float64)
+
+
+def cosine_beta_schedule(timesteps, s=0.008):
+    """DD:436-446."""
+    steps = timesteps + 1
+    t = torch.linspace(0, timesteps, steps, dtype=torch.float64) / timesteps
+    ac = torch.cos((t + s) / (1 + s) * math.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    return torch.clip(1 - (ac[1:] / ac[:-1]), 0, 0.999)
+
+
+class ConditionalDiffusion(nn.Module):
+    """DD:463-993 for objective='pred_x0', noise_space='image' (what FlowDiffuser builds)."""
+
+    def __init__(self, model, image_size, timesteps=1000, sampling_timesteps=None, objective="pred_v",
+                 beta_schedule="sigmoid", schedule_fn_kwargs=dict(), ddim_sampling_eta=0.0, auto_normalize=True,
+                 offset_noise_strength=0.0, min_snr_loss_weight=False, min_snr_gamma=5, conditioned=True,
+                 channels=3, noise_space="image"):
+        super().__init__()
+        if objective != "pred_x0" or noise_space != "image" or auto_normalize or offset_noise_strength != 0.0:
+            raise NotImplementedError("HIP path: objective='pred_x0', noise_space='image', auto_normalize=False (FD:118-127); "
+                                      "noise_space='flow' is broken in the reference itself (warp.py:181-182)")
+        self.model = model
+        self.channels = channels
+        self.self_condition = False
+        self.conditioned = conditioned
+        self.noise_space = noise_space
+        self.image_size = image_size                      # int (square, as the reference) or (H, W)
+        self.objective = objective
+        fn = {"linear": linear_beta_schedule, "cosine": cosine_beta_schedule, "sigmoid": sigmoid_beta_schedule}.get(beta_schedule)
+        if fn is None:
+            raise ValueError(f"unknown beta schedule {beta_schedule}")
+        betas = fn(timesteps, **schedule_fn_kwargs)
+        alphas = 1.0 - betas
+        alphas_cumprod = torch.cumprod(alphas, dim=0)
+        alphas_cumprod_prev = torch.cat((torch.ones(1, dtype=torch.float64), alphas_cumprod[:-1]))
+        (timesteps,) = betas.shape
+        self.num_timesteps = int(timesteps)
+        self.sampling_timesteps = default(sampling_timesteps, timesteps)
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+
+        def reg(name, val):
+            self.register_buffer(name, val.to(torch.float32))
+
+        reg("betas", betas)
+        reg("alphas_cumprod", alphas_cumprod)
+        reg("alphas_cumprod_prev", alphas_cumprod_prev)
+        reg("sqrt_alphas_cumprod", torch.sqrt(alphas_cumprod))
+        reg("sqrt_one_minus_alphas_cumprod", torch.sqrt(1.0 - alphas_cumprod))
+        reg("log_one_minus_alphas_cumprod", torch.log(1.0 - alphas_cumprod))
+        reg("sqrt_recip_alphas_cumprod", torch.sqrt(1.0 / alphas_cumprod))
+        reg("sqrt_recipm1_alphas_cumprod", torch.sqrt(1.0 / alphas_cumprod - 1))
+        posterior_variance = betas * (1.0 - alphas_cumprod_prev) / (1.0 - alphas_cumprod)
+        reg("posterior_variance", posterior_variance)
+        reg("posterior_log_variance_clipped", torch.log(posterior_variance.clamp(min=1e-20)))
+        reg("posterior_mean_coef1", betas * torch.sqrt(alphas_cumprod_prev) / (1.0 - alphas_cumprod))
+        reg("posterior_mean_coef2", (1.0 - alphas_cumprod_prev) * torch.sqrt(alphas) / (1.0 - alphas_cumprod))
+        self.offset_noise_strength = offset_noise_strength
+        snr = alphas_cumprod / (1 - alphas_cumprod)
+        clipped = snr.clone()
+        if min_snr_loss_weight:
+            clipped.clamp_(max=min_snr_gamma)
+        reg("loss_weight", clipped)                        # pred_x0 (DD:575-576)
+        self.normalize = identity
+        self.unnormalize = identity
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    def _hw(self):
+        s = self.image_size
+        return (s, s) if isinstance(s, int) else tuple(s)
+
+    # -- network call ------------------------------------------------------------------------
+    def model_with_condition(self, x, t, x_self_cond, external_cond=None, additional_tgt=None):
+        assert self.conditioned == torch.is_tensor(external_cond)                      # DD:627
+        return self.model(x, external_cond if self.conditioned else None, t, x_self_cond,
+                          additional_out=additional_tgt is not None)
+
+    def predict_noise_from_start(self, x_t, t, x0):
+        return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - x0) / \
+            extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape)
+
+    def model_predictions(self, x, t, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False,
+                          external_cond=None, additional_tgt=None):
+        """DD:634-664 (pred_x0 branch)."""
+        out = self.model_with_condition(x, t, x_self_cond, external_cond=external_cond, additional_tgt=additional_tgt)
+        additional_out = None
+        if additional_tgt is not None:
+            additional_out = out[:, -1 * additional_tgt.shape[1]:]
+            out = out[:, :-1 * additional_tgt.shape[1]]
+        x_start = torch.clamp(out, min=-1.0, max=1.0) if clip_x_start else out
+        pred_noise = self.predict_noise_from_start(x, t, x_start)
+        return ModelPrediction(pred_noise, x_start, additional_out)
+
+    def q_sample(self, x_start, t, noise=None):
+        """DD:806-812 as one fused HIP kernel."""
+        noise = default(noise, lambda: torch.randn_like(x_start))
+        x0, nz = L.f32c(x_start), L.f32c(noise)
+        out = torch.empty_like(x0)
+        a, b = self.sqrt_alphas_cumprod[t].contiguous(), self.sqrt_one_minus_alphas_cumprod[t].contiguous()
+        B = x0.shape[0]
+        L.check(L.lib().ofd_q_sample(L.ptr(x0), L.ptr(nz), L.ptr(a), L.ptr(b), L.ptr(out), B, x0[0].numel(), L.stream()))
+        return out
+
+    # -- DDPM --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def p_sample(self, x, t: int, x_self_cond=None, external_cond=None, additional_tgt=None, noise=None):
+        """DD:676-698: network call + one fused kernel for clamp / posterior mean / noise add."""
+        b = x.shape[0]
+        bt = torch.full((b,), t, device=x.device, dtype=torch.long)
+        out = self.model_with_condition(x, bt, x_self_cond, external_cond=external_cond, additional_tgt=additional_tgt)
+        additional_out = None
+        if additional_tgt is not None:
+            additional_out = out[:, -1 * additional_tgt.shape[1]:]
+            out = L.f32c(out[:, :-1 * additional_tgt.shape[1]])
+        x = L.f32c(x)
+        c1 = self.posterior_mean_coef1[bt].contiguous()
+        c2 = self.posterior_mean_coef2[bt].contiguous()
+        sigma = (0.5 * self.posterior_log_variance_clipped[bt]).exp().contiguous()
+        if t > 0:
+            noise = default(noise, lambda: torch.randn_like(x))
+        else:
+            noise = None                                                               # DD:687
+        pred = torch.empty_like(x)
+        x_start = torch.empty_like(x)
+        L.check(L.lib().ofd_ddpm_update(L.ptr(x), L.ptr(out), L.ptr(noise), L.ptr(c1), L.ptr(c2), L.ptr(sigma),
+                                        L.ptr(pred), L.ptr(x_start), b, x[0].numel(), L.stream()))
+        return pred, x_start, additional_out
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, return_all_timesteps=False, external_cond=None, additional_tgt=None, verbose=False):
+        """DD:700-729 (no per-step print / host sync)."""
+        img = torch.randn(shape, device=self.device)
+        imgs = [img]
+        additionals = [None]
+        for t in reversed(range(0, self.num_timesteps)):
+            img, x_start, additional_out = self.p_sample(img, t, None, external_cond=external_cond, additional_tgt=additional_tgt)
+            if return_all_timesteps:
+                imgs.append(img)
+            additionals.append(additional_out)
+        ret = img if not return_all_timesteps else torch.stack(imgs, dim=1)
+        if additional_tgt is not None:
+            ret = (ret, additionals)
+        return ret
+
+    # -- DDIM --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def ddim_sample(self, shape, return_all_timesteps=False, external_cond=None, additional_tgt=None):
+        """DD:731-774; accepts (and ignores) additional_tgt so that sample() can reach it."""
+        batch, device, T, S, eta = shape[0], self.device, self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
+        times = torch.linspace(-1, T - 1, steps=S + 1)
+        times = list(reversed(times.int().tolist()))
+        time_pairs = list(zip(times[:-1], times[1:]))
+        img = torch.randn(shape, device=device)
+        imgs = [img]
+        n = img[0].numel()
+        ac = self.alphas_cumprod
+        for time, time_next in time_pairs:
+            tc = torch.full((batch,), time, device=device, dtype=torch.long)
+            out = self.model_with_condition(img, tc, None, external_cond=external_cond)
+            sr = self.sqrt_recip_alphas_cumprod[tc].contiguous()
+            srm1 = self.sqrt_recipm1_alphas_cumprod[tc].contiguous()
+            nxt = torch.empty_like(img)
+            last = time_next < 0
+            if last:
+                san = cc = sg = noise = None
+            else:
+                alpha, alpha_next = ac[time], ac[time_next]
+                sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+                c = (1 - alpha_next - sigma ** 2).sqrt()
+                san = alpha_next.sqrt().reshape(1).repeat(batch).contiguous()
+                cc = c.reshape(1).repeat(batch).contiguous()
+                sg = sigma.reshape(1).repeat(batch).contiguous()
+                noise = torch.randn_like(img)                                            # DD:763
+            L.check(L.lib().ofd_ddim_update(L.ptr(img), L.ptr(out), L.ptr(noise), L.ptr(sr), L.ptr(srm1), L.ptr(san), L.ptr(cc),
+                                            L.ptr(sg), int(last), L.ptr(nxt), None, batch, n, L.stream()))
+            img = nxt
+            if return_all_timesteps:
+                imgs.append(img)
+        return img if not return_all_timesteps else torch.stack(imgs, dim=1)
+
+    @torch.no_grad()
+    def sample(self, batch_size=16, return_all_timesteps=False, external_cond=None, additional_tgt=None):
+        """DD:776-784, with image_size allowed to be (H, W)."""
+        H, W = self._hw()
+        fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
+        assert external_cond is None or external_cond.shape[0] == batch_size
+        return fn((batch_size, self.channels, H, W), return_all_timesteps=return_all_timesteps,
+                  external_cond=external_cond, additional_tgt=additional_tgt)
+
+    # -- training loss -----------------------------------------------------------------------
+    def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, external_cond=None, additional_tgt=None,
+                 additional_weight=None, model_out_override=None):
+        """DD:823-891 for targets without the pyramid levels (target='flow'/'target' level 1)."""
+        noise = default(noise, lambda: torch.randn_like(x_start))
+        x = self.q_sample(x_start=x_start, t=t, noise=noise)
+        if model_out_override is None:
+            model_out = self.model_with_condition(x, t, None, external_cond=external_cond, additional_tgt=additional_tgt)
+            if additional_tgt is not None:
+                model_out = model_out[:, :-1 * additional_tgt.shape[1]]
+        else:
+            model_out, _ = model_out_override
+        target = x_start                                                               # pred_x0 (DD:876-877)
+        if target.shape[1] == 5 or additional_tgt is not None:
+            raise NotImplementedError("pyramid loss of target='joint'/'target' (DD:902-961) is a next-round row (SURVEY 8f next-4)")
+        return self._loss(model_out[:, :3], target[:, :3], t)
+
+    def _loss(self, image_out, target, t=None, flow_tgt=None, external_cond=None, flow_out=None, additional_weight=None):
+        """DD:893-983, level 1 only: nanmean of the NaN-masked squared error (no SNR weighting,
+        DD:975-980; anomaly mode and prints dropped)."""
+        if flow_tgt is not None:
+            raise NotImplementedError("pyramid levels need target='joint'")
+        return nan_mse(image_out, target, reduction="mean")
+
+    def forward(self, img, external_cond=None, *args, **kwargs):
+        """DD:985-993."""
+        b, c, h, w = img.shape
+        H, W = self._hw()
+        assert h == H and w == W, f"height and width of image must be {(H, W)}"
+        t = torch.randint(0, self.num_timesteps, (b,), device=img.device).long()
+        return self.p_losses(img, t, external_cond=external_cond, *args, **kwargs)
