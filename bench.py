@@ -1,0 +1,145 @@
+#!/usr/bin/env python
+"""Headline benchmark: UNet denoise steps/sec at flow tensor (16, 2, 436->440, 1024) bf16
+(BASELINE.json configs[1]).
+
+One step = one DDPM reverse step over the batch: `model_predictions` (one UNet forward on the
+HIP engine) + the fused posterior update (denoising_diffusion.py:676-698).  Inputs are synthetic
+(seed 0) and resident in HBM before the timed region.  N > 1: one process per GPU, independent
+chains (weak scaling, no data-path collective -- sampling shards by sample).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+UNET_GFLOP_PER_SAMPLE = 1635.3   # reference module on meta, ch=5 @ 440x1024
+
+
+def cpu_baseline(H, W, batch):
+    """The oracle (CPU restatement of the reference UNet: same torch CPU ops, fp32) timed on this
+    box's host cores on ONE sample of the workload; a batch-16 step is 16x that work."""
+    from oracle import unet_ref as R
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = R.closed_form_params(R.unet_param_shapes(64, 5, 2))
+    x = torch.randn(1, 2, H, W)
+    cond = torch.rand(1, 3, H, W) * 2 - 1
+    t = torch.tensor([999])
+    with torch.no_grad():
+        R.unet_forward(P, x[:, :, :64, :64], cond[:, :, :64, :64], t, mode="fp32")   # warm-up of the op set
+        t0 = time.time()
+        R.unet_forward(P, x, cond, t, mode="fp32")
+        dt = time.time() - t0
+    return {"value": 1.0 / (dt * batch), "unit": "denoise_steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 of {batch} samples: one fp32 UNet forward at 1x5x{H}x{W} in {dt:.1f} s, scaled x{batch}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--height", type=int, default=436)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
+    ap.add_argument("--dump-launches", default=None, help="CSV path: one row per kernel launch of the timed region")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from opticalflowdiffusion_amd import Unet, ConditionalDiffusion
+
+    B = args.batch
+    H = (args.height + 7) // 8 * 8        # 436 -> 440: three 2x down-samplings
+    W = (args.width + 7) // 8 * 8
+    torch.manual_seed(0)
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    unet = Unet(64, channels=5, out_dim=2, precision="bf16").to(dev)
+    diff = ConditionalDiffusion(unet, (H, W), objective="pred_x0", channels=2, auto_normalize=False,
+                                noise_space="image", timesteps=1000, min_snr_loss_weight=True).to(dev)
+    cond = (torch.rand(B, 3, H, W, generator=g) * 2 - 1).to(dev)
+    img = torch.randn(B, 2, H, W, generator=g).to(dev)
+    noises = [torch.randn(B, 2, H, W, device=dev) for _ in range(2)]
+
+    def step(img, t, i):
+        out, _, _ = diff.p_sample(img, t, None, external_cond=cond, noise=noises[i & 1])
+        return out
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    T = 999
+    with torch.no_grad():
+        for i in range(args.warmup):
+            img = step(img, T - i, i)
+        unet.set_profiling(not args.no_profile, args.dump_launches)
+        unet.profile(reset=True)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            img = step(img, T - args.warmup - i, i)
+        sync()
+        elapsed = time.perf_counter() - t0
+    prof = unet.profile() if not args.no_profile else {}
+    unet.set_profiling(False)
+    assert torch.isfinite(img).all(), "non-finite samples"
+
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        steps_per_s = world * args.steps / elapsed
+        line = {
+            "metric": "UNet denoise steps/sec @ 2x436x1024 flow, bs=16",
+            "value": steps_per_s, "unit": "denoise_steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: flow_diffuser DDPM denoise step (UNet fwd + posterior update), "
+                                   f"x (B,2,{args.height},{args.width}) padded to {H}x{W}, cond (B,3,H,W), T=1000, target=flow",
+                       "batch_per_gpu": B, "global_batch": B * world, "height": H, "width": W, "parallelism": f"replicas x{world}"},
+            "unet_mfma_frac_of_peak": steps_per_s / world * B * UNET_GFLOP_PER_SAMPLE * (H * W) / (440 * 1024) / 1e3 / PEAK_BF16_TFLOPS,
+        }
+        if prof:
+            k = prof["conv3x3_igemm"]
+            per_launch_ms = k["ms"] / max(k["launches"], 1)
+            achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+            line["roofline"] = {"kernel": "conv_igemm_kernel<3,*> (3x3 implicit GEMM, 43 launches/step)", "bound": "mfma",
+                                "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                                "traffic": None, "avg_launch_ms": per_launch_ms, "launches": k["launches"]}
+            line["kernel_ms_per_step"] = {n: v["ms"] / args.steps for n, v in prof.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(H, W, B)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

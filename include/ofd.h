@@ -137,6 +137,9 @@ const char* ofd_unet_prof_name(const ofd_unet* u, int i);
 /* resolves the recorded events (host-synchronises) -> ms, launches and flops/bytes summed since last reset */
 int ofd_unet_prof_read(ofd_unet* u, int i, double* ms, long long* launches, double* flops, double* bytes);
 int ofd_unet_prof_reset(ofd_unet* u);
+/* optional: append one CSV row per launch (class,label,ms,flops,bytes) to `path` whenever the
+ * events are resolved; NULL/"" disables */
+int ofd_unet_prof_dump_path(ofd_unet* u, const char* path);
 
 /* ---------------------------------------------------------------- single ops (parity tests) -
  * NHWC bf16 activations (uint16_t* = raw bf16 bits).  These are the kernels the executor

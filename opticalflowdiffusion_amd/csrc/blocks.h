@@ -23,6 +23,10 @@ int k_resblock_out(const bf16_t* h, const float* a, const float* sft, const bf16
 int k_layernorm_c(const bf16_t* x, const float* g, const bf16_t* res, bf16_t* out, size_t npix, int C, float eps, hipStream_t s);
 int la_parts(int n);
 int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s);
+int la_fused_blocks(int n);
+int k_la_weight_prep(const float* wqkv, const float* g, const float* wout, bf16_t* wq, bf16_t* wkv, bf16_t* woutp, int C, hipStream_t s);
+int k_linear_attention_fused(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const bf16_t* woutp, const float* bias, const float* g2,
+                             float* partial, bf16_t* ctxfrag, bf16_t* y, int B, int n, int C, float eps_pre, float eps_post, hipStream_t s);
 int k_flash_attention(const bf16_t* qkv, bf16_t* out, int B, int n, hipStream_t s);
 int k_final_conv(const bf16_t* x, const float* w, const float* bias, float* out, int B, int H, int W, int C, int out_dim, hipStream_t s);
 int k_nhwc_to_nchw(const bf16_t* x, float* out, int B, int H, int W, int C, hipStream_t s);

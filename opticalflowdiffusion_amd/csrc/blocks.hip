@@ -9,8 +9,8 @@ namespace ofd {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + __expf(-y)); }
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ float silu_f(float y) { return y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return f2bf2(a, b); }
 __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll

@@ -34,12 +34,18 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 typedef uint16_t bf16_t;   // raw bits
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even; NaN stays NaN (plain cast semantics)
+// round-to-nearest-even, NaN stays NaN: the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950
+// (a hand-written integer rounding costs a divergent branch per value)
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, h);
 }
 
 }  // namespace ofd

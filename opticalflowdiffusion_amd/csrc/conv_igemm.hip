@@ -76,32 +76,66 @@ __device__ __forceinline__ int swz(int p) {
     return (CK == 64) ? ((p >> 1) & 7) : ((p >> 3) & 1);
 }
 
-__device__ __forceinline__ float silu_f(float y) { return y / (1.0f + __expf(-y)); }
+__device__ __forceinline__ float silu_f(float y) { return y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
 
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return f2bf2(a, b); }
 
-// reduce N per-lane values over the 64 lanes of a wave with N-ish shuffles: afterwards lane l
-// holds in v[0] the total of value index (l >> (6 - log2 N)) (for N = 32: l >> 1, N = 16: l >> 2).
+// reduce N per-lane values over the 64 lanes of a wave with ~N shuffles (butterfly that halves
+// the value set per step): afterwards lane l holds in v[0] the total of value index
+// (l >> (6 - log2 N)) (N = 32: l >> 1, N = 16: l >> 2).  Fully static indexing (no scratch).
+template <int N, int NCUR, int OFF>
+struct WaveReduce {
+    static __device__ __forceinline__ void run(float (&v)[N]) {
+        if constexpr (NCUR > 1) {
+            constexpr int HALF = NCUR / 2;
+            const bool upper = (threadIdx.x & OFF) != 0;
+#pragma unroll
+            for (int i = 0; i < HALF; ++i) {
+                const float send = upper ? v[i] : v[i + HALF];
+                const float keep = upper ? v[i + HALF] : v[i];
+                v[i] = keep + __shfl_xor(send, OFF, 64);
+            }
+            if constexpr (OFF > 1) WaveReduce<N, HALF, OFF / 2>::run(v);
+        } else {
+            v[0] += __shfl_xor(v[0], OFF, 64);
+            if constexpr (OFF > 1) WaveReduce<N, 1, OFF / 2>::run(v);
+        }
+    }
+};
 template <int N>
 __device__ __forceinline__ void wave_reduce_multi(float (&v)[N]) {
-    int n = N;
+    WaveReduce<N, N, 32>::run(v);
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // first-class vector value: always in registers
+template <int N>
+struct U4Arr {
+    u32x4 v[N];
+};
+
+template <int KS, int BN>
+__device__ __forceinline__ void conv_load_w(U4Arr<Cfg<KS, BN>::WPT>& wr, const bf16_t* __restrict__ weight, int cin8, int Cout, int n0,
+                                            int kc, int st, int tid) {
+    using C = Cfg<KS, BN>;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        if (n > 1) {
-            const int half = n / 2;
-            const bool upper = (threadIdx.x & off) != 0;
+    for (int i = 0; i < C::WPT; ++i) {
+        int u = tid + i * NTHREADS;
+        if (C::SC8 * BN % NTHREADS != 0) u = min(u, C::SC8 * BN - 1);
+        const int r = u / BN, n = u % BN;
+        size_t row;
+        if (KS == 7) row = (size_t)(st * 7 + r / 2) * 2 + (r & 1);
+        else row = (size_t)st * cin8 + kc * 8 + r;
+        wr.v[i] = *(const u32x4*)(weight + (row * Cout + n0 + n) * 8);
+    }
+}
+template <int KS, int BN>
+__device__ __forceinline__ void conv_store_w(const U4Arr<Cfg<KS, BN>::WPT>& wr, unsigned char* dst, int tid) {
+    using C = Cfg<KS, BN>;
 #pragma unroll
-            for (int i = 0; i < N / 2; ++i) {
-                if (i < half) {
-                    const float send = upper ? v[i] : v[i + half];
-                    const float keep = upper ? v[i + half] : v[i];
-                    v[i] = keep + __shfl_xor(send, off, 64);
-                }
-            }
-            n = half;
-        } else {
-            v[0] += __shfl_xor(v[0], off, 64);
-        }
+    for (int i = 0; i < C::WPT; ++i) {
+        int u = tid + i * NTHREADS;
+        if (C::SC8 * BN % NTHREADS != 0) u = min(u, C::SC8 * BN - 1);
+        *(u32x4*)(dst + u * 16) = wr.v[i];
     }
 }
 
@@ -136,53 +170,41 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.0f;
 
-    uint4 wreg[C::WPT];
+    U4Arr<C::WPT> wreg;
 
-    // global -> registers of weight slab (chunk kc, stage st)
-    auto load_w = [&](int kc, int st) {
-#pragma unroll
-        for (int i = 0; i < C::WPT; ++i) {
-            const int u = tid + i * NTHREADS;
-            const int r = u / BN, n = u % BN;
-            size_t row;
-            if (KS == 7) row = (size_t)(st * 7 + r / 2) * 2 + (r & 1);
-            else row = (size_t)st * (P.Cin_total / 8) + kc * 8 + r;
-            if (u < C::SC8 * BN) wreg[i] = *(const uint4*)(P.weight + (row * P.Cout + n0 + n) * 8);
-        }
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < C::WPT; ++i) {
-            const int u = tid + i * NTHREADS;
-            if (u < C::SC8 * BN) *(uint4*)(lds_w + buf * C::W_BYTES + u * 16) = wreg[i];
-        }
-    };
-
+    // No predication anywhere in the staging code: indices past the end are clamped (duplicates
+    // rewrite identical bytes), so the loads issue back to back and stay in registers.
+    const int cin8 = P.Cin_total / 8;
     int src_i = 0, src_first = 0;   // source that owns chunk kc, and its first chunk
     for (int kc = 0; kc < P.total_chunks; ++kc) {
         while (kc >= src_first + P.src[src_i].chunks) {
             src_first += P.src[src_i].chunks;
             ++src_i;
         }
-        const ConvSrcDev& S = P.src[src_i];
+        const bf16_t* s_ptr = P.src[src_i].ptr;
+        const int s_ch = P.src[src_i].src_channels, s_off = P.src[src_i].ch_offset, s_SH = P.src[src_i].SH, s_SW = P.src[src_i].SW;
+        const int s_mode = P.src[src_i].mode, s_p1 = P.src[src_i].p1, s_p2 = P.src[src_i].p2;
         const int kcl = kc - src_first;
 
         // ---- stage the input tile (+halo) of this chunk: global -> regs -> (affine+SiLU) -> LDS
         uint4 xreg[C::XPT];
+        unsigned okmask = 0;
         const int c8 = tid % C::NC;
+        const bf16_t* s_base = s_ptr + (size_t)b * s_SH * s_SW * s_ch + s_off + kcl * C::CK + c8 * 8;
 #pragma unroll
         for (int i = 0; i < C::XPT; ++i) {
-            const int p = tid / C::NC + i * (NTHREADS / C::NC);
+            const int p = min(tid / C::NC + i * (NTHREADS / C::NC), C::NPIX - 1);
             const int ty = p / C::IW, tx = p - ty * C::IW;
             const int iy = oy0 - C::PAD + ty, ix = ox0 - C::PAD + tx;
-            const bool ok = (p < C::NPIX) && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
-            int sy = iy, sx = ix;
-            if (S.mode == 1) { sy = iy >> 1; sx = ix >> 1; }
-            else if (S.mode == 2) { sy = 2 * iy + S.p1; sx = 2 * ix + S.p2; }
-            xreg[i] = make_uint4(0, 0, 0, 0);
-            if (ok) xreg[i] = *(const uint4*)(S.ptr + (((size_t)b * S.SH + sy) * S.SW + sx) * S.src_channels + S.ch_offset + kcl * C::CK + c8 * 8);
+            const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+            okmask |= (ok ? 1u : 0u) << i;
+            const int cy = min(max(iy, 0), P.H - 1), cx = min(max(ix, 0), P.W - 1);
+            int sy = cy, sx = cx;
+            if (s_mode == 1) { sy = cy >> 1; sx = cx >> 1; }
+            else if (s_mode == 2) { sy = 2 * cy + s_p1; sx = 2 * cx + s_p2; }
+            xreg[i] = *(const uint4*)(s_base + ((size_t)sy * s_SW + sx) * s_ch);
         }
-        load_w(kc, 0);
+        conv_load_w<KS, BN>(wreg, P.weight, cin8, P.Cout, n0, kc, 0, tid);
         float ps[8], pb[8];
         if (P.in_scale) {
             const int cg = kc * C::CK + c8 * 8;
@@ -195,32 +217,28 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
         __syncthreads();   // every wave has finished reading lds_x / lds_w of the previous chunk
 #pragma unroll
         for (int i = 0; i < C::XPT; ++i) {
-            const int p = tid / C::NC + i * (NTHREADS / C::NC);
-            if (p < C::NPIX) {
-                uint4 v = xreg[i];
-                if (P.in_scale) {
-                    const int ty = p / C::IW, tx = p - ty * C::IW;
-                    const int iy = oy0 - C::PAD + ty, ix = ox0 - C::PAD + tx;
-                    if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) {   // zero padding stays zero
-                        uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+            const int p = min(tid / C::NC + i * (NTHREADS / C::NC), C::NPIX - 1);
+            uint4 v = xreg[i];
+            if (P.in_scale) {
+                uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float lo = silu_f(bf2f((bf16_t)(w4[j] & 0xffffu)) * ps[2 * j] + pb[2 * j]);
-                            const float hi = silu_f(bf2f((bf16_t)(w4[j] >> 16)) * ps[2 * j + 1] + pb[2 * j + 1]);
-                            w4[j] = pack2(lo, hi);
-                        }
-                        v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = silu_f(bf2f((bf16_t)(w4[j] & 0xffffu)) * ps[2 * j] + pb[2 * j]);
+                    const float hi = silu_f(bf2f((bf16_t)(w4[j] >> 16)) * ps[2 * j + 1] + pb[2 * j + 1]);
+                    w4[j] = pack2(lo, hi);
                 }
-                *(uint4*)(lds_x + p * (C::CK * 2) + ((c8 ^ swz<C::CK>(p)) * 16)) = v;
+                v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
             }
+            const bool ok = (okmask >> i) & 1u;                 // zero padding stays zero (applied AFTER the prologue)
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+            *(uint4*)(lds_x + p * (C::CK * 2) + ((c8 ^ swz<C::CK>(p)) * 16)) = v;
         }
-        store_w(0);
+        conv_store_w<KS, BN>(wreg, lds_w, tid);
 
         // ---- weight slabs: prefetch slab st+1 to registers while slab st feeds the MFMAs
 #pragma unroll 1
         for (int st = 0; st < C::STAGES; ++st) {
-            if (st + 1 < C::STAGES) load_w(kc, st + 1);
+            if (st + 1 < C::STAGES) conv_load_w<KS, BN>(wreg, P.weight, cin8, P.Cout, n0, kc, st + 1, tid);
             __syncthreads();   // lds_x (st == 0) and lds_w[st & 1] are complete
             const unsigned char* wbuf = lds_w + (st & 1) * C::W_BYTES;
             const int ky = (KS == 3) ? st / 3 : (KS == 7 ? st : 0);
@@ -244,7 +262,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
                     for (int pt = 0; pt < 2; ++pt)
                         acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[pt], acc[nt][pt], 0, 0, 0);
             }
-            if (st + 1 < C::STAGES) store_w((st + 1) & 1);   // other buffer: last read in stage st-1
+            if (st + 1 < C::STAGES) conv_store_w<KS, BN>(wreg, lds_w + ((st + 1) & 1) * C::W_BYTES, tid);   // other buffer: last read in stage st-1
         }
     }
 

@@ -1,0 +1,356 @@
+// Fused LinearAttention block for gfx950 (denoising_diffusion.py:216-244 inside
+// Residual(PreNorm(.)), DD:81-87, DD:127-135), C in {64, 128}.
+//
+// The reference materialises LayerNorm(x), qkv (6x the activation), the head outputs and the
+// to_out result: ~2.9 KB of HBM traffic per pixel.  Here the block is two streaming passes over x
+// (384 B per pixel) with every contraction on MFMA 32x32x16 bf16 and no intermediate in HBM:
+//   pass 1  x -> LN -> [k|v] = Wkv x^  -> online softmax of k over pixels -> ctx^T += v^T p
+//           (the k/v accumulator tiles are used directly as the operands of the context MFMA:
+//            accumulator rows = pixels = the contraction index, no LDS transpose)
+//   pass 2  x -> LN -> q = Wq x^ -> softmax over d -> out = ctx^T q -> o = Wout out + b
+//           -> LN -> + x   (each stage's accumulator tile is the next MFMA's B operand)
+// The PreNorm gain g is folded into Wq / Wkv (W.diag(g)) when the weights are prepared.
+#include "blocks.h"
+
+namespace ofd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ uint32_t la_pack2(float a, float b) { return f2bf2(a, b); }
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// registers 8*s2 .. 8*s2+7 of an accumulator tile as an MFMA operand fragment (k = tile row)
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s2) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (__bf16)a[8 * s2 + j];
+    return f;
+}
+
+// x tile of 32 pixels -> normalised (no gain) bf16 fragments; lane (pixel, half) holds channels
+// 16 s + 8 half .. + 7 of its pixel for every k-step s.
+template <int C>
+__device__ __forceinline__ void load_norm_x(const bf16_t* __restrict__ xrow, float eps, bf16x8 (&xs)[C / 16], int half) {
+    constexpr int KS = C / 16;
+    float v[KS][8];
+    float sum = 0.0f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const uint4 raw = *(const uint4*)(xrow + 16 * s + 8 * half);
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[s][2 * j] = bf2f((bf16_t)(w[j] & 0xffffu));
+            v[s][2 * j + 1] = bf2f((bf16_t)(w[j] >> 16));
+            sum += v[s][2 * j] + v[s][2 * j + 1];
+        }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / C);
+    float q = 0.0f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[s][j] -= mean;
+            q += v[s][j] * v[s][j];
+        }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q * (1.0f / C) + eps);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xs[s][j] = (__bf16)(v[s][j] * rstd);
+}
+
+// ---- pass 1 ---------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256, 2) la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wkv,
+                                                           float* __restrict__ partial, int n, float eps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KS = C / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    for (int i = tid; i < (C / 8) * 256; i += 256) ((uint4*)smem)[i] = ((const uint4*)wkv)[i];
+    __syncthreads();
+    const int b = blockIdx.y, wave_id = blockIdx.x * 4 + wave, nw = gridDim.x * 4, ntiles = (n + 31) / 32;
+
+    f32x16 ctxT[4];
+    float m[4], l[4];
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+        m[hd] = -3.0e38f;
+        l[hd] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ctxT[hd][r] = 0.0f;
+    }
+    for (int tile = wave_id; tile < ntiles; tile += nw) {
+        // the weight fragments are loop-invariant LDS reads: without this the compiler hoists all of
+        // them into registers (C=128: 512 VGPRs + scratch spills) instead of re-reading LDS per tile
+        asm volatile("" ::: "memory");
+        const int pid = min(tile * 32 + l31, n - 1);
+        bf16x8 xs[KS];
+        load_norm_x<C>(x + ((size_t)b * n + pid) * C, eps, xs, half);
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd) {
+            f32x16 ka, va;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ka[r] = 0.0f; va[r] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 wk = *(const bf16x8*)(smem + ((size_t)(2 * s + half) * 256 + hd * 32 + l31) * 16);
+                const bf16x8 wv = *(const bf16x8*)(smem + ((size_t)(2 * s + half) * 256 + 128 + hd * 32 + l31) * 16);
+                ka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[s], wk, ka, 0, 0, 0);   // rows = pixels, col = d
+                va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[s], wv, va, 0, 0, 0);   // rows = pixels, col = e
+            }
+            float mt = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (tile * 32 + acc_row(r, half) >= n) ka[r] = -3.0e38f;
+                mt = fmaxf(mt, ka[r]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float m_new = fmaxf(m[hd], mt);
+            const float f = __expf(m[hd] - m_new);
+            m[hd] = m_new;
+            float ps = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(ka[r] - m_new);
+                ka[r] = p;
+                ps += p;
+            }
+            l[hd] = l[hd] * f + ps;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ctxT[hd][r] *= f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)   // ctx^T[e][d] += sum_pix v[pix][e] p[pix][d]
+                ctxT[hd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(va, s2), acc_frag(ka, s2), ctxT[hd], 0, 0, 0);
+        }
+    }
+    const int nparts = nw;
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+        float* o = partial + ((size_t)(b * 4 + hd) * nparts + wave_id) * 1088;
+        const float l_tot = l[hd] + __shfl_xor(l[hd], 32, 64);
+        if (half == 0) {
+            o[l31] = m[hd];
+            o[32 + l31] = l_tot;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)   // lane = d (column), registers = e rows
+            *(float4*)(o + 64 + l31 * 32 + 8 * g + 4 * half) = make_float4(ctxT[hd][4 * g], ctxT[hd][4 * g + 1], ctxT[hd][4 * g + 2], ctxT[hd][4 * g + 3]);
+    }
+}
+
+// combine partials -> context as pass 2's A fragments:
+// ctxfrag[bh][s2][lane][j] = ctx[d = 16 s2 + 8 (j>>2) + 4 (lane>>5) + (j&3)][e = lane & 31]
+__global__ void __launch_bounds__(256) la_ctx_combine_frag_kernel(const float* __restrict__ partial, bf16_t* __restrict__ ctxfrag,
+                                                                  int nparts, float inv_n) {
+    __shared__ float M[32], Linv[32], cs[32][33];
+    const int tid = threadIdx.x, bh = blockIdx.x;
+    const float* base = partial + (size_t)bh * nparts * 1088;
+    if (tid < 32) {
+        float mx = -3.0e38f;
+        for (int c = 0; c < nparts; ++c) mx = fmaxf(mx, base[(size_t)c * 1088 + tid]);
+        float l = 0.0f;
+        for (int c = 0; c < nparts; ++c) l += base[(size_t)c * 1088 + 32 + tid] * __expf(base[(size_t)c * 1088 + tid] - mx);
+        M[tid] = mx;
+        Linv[tid] = 1.0f / l;
+    }
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+        const int d = i >> 5, e = i & 31;
+        float a = 0.0f;
+        for (int c = 0; c < nparts; ++c) a += base[(size_t)c * 1088 + 64 + i] * __expf(base[(size_t)c * 1088 + d] - M[d]);
+        cs[d][e] = a * Linv[d] * inv_n;
+    }
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+        const int j = i & 7, lane = (i >> 3) & 63, s2 = i >> 9;
+        const int d = 16 * s2 + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3), e = lane & 31;
+        ctxfrag[(size_t)bh * 1024 + i] = f2bf(cs[d][e]);
+    }
+}
+
+// ---- pass 2 ---------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256, 2) la_out_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wq,
+                                                           const bf16_t* __restrict__ woutp, const bf16_t* __restrict__ ctxfrag,
+                                                           const float* __restrict__ bias, const float* __restrict__ g2,
+                                                           bf16_t* __restrict__ y, int n, float eps_pre, float eps_post, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KS = C / 16, RT = C / 32;
+    constexpr int WQ_B = (C / 8) * 128 * 16, WO_B = 16 * C * 16, CF_B = 4 * 2 * 64 * 16;
+    unsigned char* s_wq = smem;
+    unsigned char* s_wo = smem + WQ_B;
+    unsigned char* s_cf = s_wo + WO_B;
+    float* s_bias = (float*)(s_cf + CF_B);
+    float* s_g2 = s_bias + C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.y;
+    for (int i = tid; i < WQ_B / 16; i += 256) ((uint4*)s_wq)[i] = ((const uint4*)wq)[i];
+    for (int i = tid; i < WO_B / 16; i += 256) ((uint4*)s_wo)[i] = ((const uint4*)woutp)[i];
+    for (int i = tid; i < CF_B / 16; i += 256) ((uint4*)s_cf)[i] = ((const uint4*)(ctxfrag + (size_t)b * 4096))[i];
+    for (int i = tid; i < C; i += 256) { s_bias[i] = bias[i]; s_g2[i] = g2[i]; }
+    __syncthreads();
+    const int wave_id = blockIdx.x * 4 + wave, nw = gridDim.x * 4, ntiles = (n + 31) / 32;
+
+    for (int tile = wave_id; tile < ntiles; tile += nw) {
+        asm volatile("" ::: "memory");   // keep the LDS weight reads inside the loop (see pass 1)
+        const int pix = tile * 32 + l31;
+        const int pid = min(pix, n - 1);
+        const bf16_t* xrow = x + ((size_t)b * n + pid) * C;
+        bf16x8 xs[KS];
+        load_norm_x<C>(xrow, eps_pre, xs, half);
+        f32x16 acc_o[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[rt][r] = 0.0f;
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd) {
+            f32x16 qa;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qa[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {   // rows = d, col = pixel
+                const bf16x8 wf = *(const bf16x8*)(s_wq + ((size_t)(2 * s + half) * 128 + hd * 32 + l31) * 16);
+                qa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xs[s], qa, 0, 0, 0);
+            }
+            float mx = qa[0];                 // softmax over d (DD:234) then * scale (DD:237)
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, qa[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { qa[r] = __expf(qa[r] - mx); sum += qa[r]; }
+            sum += __shfl_xor(sum, 32, 64);
+            const float k = scale / sum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qa[r] *= k;
+            f32x16 oa;                        // out[e][pixel] = sum_d ctx[d][e] q~[d][pixel]   (DD:242)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oa[r] = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 cf = *(const bf16x8*)(s_cf + ((size_t)(hd * 2 + s2) * 64 + lane) * 16);
+                oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf, acc_frag(qa, s2), oa, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {  // o[c][pixel] += sum_e Wout[c][hd*32+e] out[e][pixel]  (to_out.0)
+                const bf16x8 of = acc_frag(oa, s2);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const bf16x8 wf = *(const bf16x8*)(s_wo + ((size_t)((hd * 2 + s2) * 2 + half) * C + rt * 32 + l31) * 16);
+                    acc_o[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, of, acc_o[rt], 0, 0, 0);
+                }
+            }
+        }
+        // bias, LayerNorm over channels (to_out.1, DD:226), + x (Residual)
+        float sum = 0.0f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *(const float4*)(s_bias + rt * 32 + 8 * g + 4 * half);
+                acc_o[rt][4 * g] += bv.x; acc_o[rt][4 * g + 1] += bv.y; acc_o[rt][4 * g + 2] += bv.z; acc_o[rt][4 * g + 3] += bv.w;
+                sum += (acc_o[rt][4 * g] + acc_o[rt][4 * g + 1]) + (acc_o[rt][4 * g + 2] + acc_o[rt][4 * g + 3]);
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / C);
+        float q = 0.0f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc_o[rt][r] -= mean; q += acc_o[rt][r] * acc_o[rt][r]; }
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = rsqrtf(q * (1.0f / C) + eps_post);
+        if (pix < n) {
+            bf16_t* yrow = y + ((size_t)b * n + pix) * C;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = rt * 32 + 8 * g + 4 * half;
+                    const float4 gv = *(const float4*)(s_g2 + c0);
+                    const uint2 xr = *(const uint2*)(xrow + c0);
+                    const float o0 = acc_o[rt][4 * g] * rstd * gv.x + bf2f((bf16_t)(xr.x & 0xffffu));
+                    const float o1 = acc_o[rt][4 * g + 1] * rstd * gv.y + bf2f((bf16_t)(xr.x >> 16));
+                    const float o2 = acc_o[rt][4 * g + 2] * rstd * gv.z + bf2f((bf16_t)(xr.y & 0xffffu));
+                    const float o3 = acc_o[rt][4 * g + 3] * rstd * gv.w + bf2f((bf16_t)(xr.y >> 16));
+                    *(uint2*)(yrow + c0) = make_uint2(la_pack2(o0, o1), la_pack2(o2, o3));
+                }
+        }
+    }
+}
+
+// ---- weight preparation -----------------------------------------------------------------------------
+// wqkv fp32 [384][C] (q | k | v rows), g fp32 [C], wout fp32 [C][128]  ->
+//   wq   bf16 [C/8][128][8] = Wq  . diag(g)
+//   wkv  bf16 [C/8][256][8] = Wkv . diag(g)
+//   wout bf16 [hd*2+s2][half][C][8]: element j = Wout[c][hd*32 + 16 s2 + 8 (j>>2) + 4 half + (j&3)]
+__global__ void __launch_bounds__(256) la_weight_prep_kernel(const float* __restrict__ wqkv, const float* __restrict__ g, const float* __restrict__ wout,
+                                                             bf16_t* __restrict__ wq, bf16_t* __restrict__ wkv, bf16_t* __restrict__ woutp, int C) {
+    const int total = 512 * C;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i < 128 * C) {
+            const int j = i & 7, o = (i >> 3) & 127, c8 = i >> 10, c = c8 * 8 + j;
+            wq[i] = f2bf(wqkv[(size_t)o * C + c] * g[c]);
+        } else if (i < 384 * C) {
+            const int k = i - 128 * C;
+            const int j = k & 7, o = (k >> 3) & 255, c8 = k >> 11, c = c8 * 8 + j;
+            wkv[k] = f2bf(wqkv[(size_t)(128 + o) * C + c] * g[c]);
+        } else {
+            const int k = i - 384 * C;
+            const int j = k & 7, c = (k >> 3) % C, rest = (k >> 3) / C;   // rest = (hd*2+s2)*2 + half
+            const int hh = rest & 1, s2 = (rest >> 1) & 1, hd = rest >> 2;
+            woutp[k] = f2bf(wout[(size_t)c * 128 + hd * 32 + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3)]);
+        }
+    }
+}
+
+template <int C>
+static int launch_la(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const bf16_t* woutp, const float* bias, const float* g2,
+                     float* partial, bf16_t* ctxfrag, bf16_t* y, int B, int n, float eps_pre, float eps_post, hipStream_t s) {
+    constexpr int LDS1 = (C / 8) * 256 * 16;
+    constexpr int LDS2 = (C / 8) * 128 * 16 + 16 * C * 16 + 4 * 2 * 64 * 16 + 2 * C * 4;
+    static bool attr = false;
+    if (!attr) {
+        OFD_HIP(hipFuncSetAttribute((const void*)la_ctx_fused_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1));
+        OFD_HIP(hipFuncSetAttribute((const void*)la_out_fused_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+        attr = true;
+    }
+    const int gx = la_fused_blocks(n);
+    la_ctx_fused_kernel<C><<<dim3(gx, B), 256, LDS1, s>>>(x, wkv, partial, n, eps_pre);
+    la_ctx_combine_frag_kernel<<<B * 4, 256, 0, s>>>(partial, ctxfrag, gx * 4, 1.0f / (float)n);
+    int gx2 = cdiv(cdiv(n, 32), 4 * 4);     // >= 4 tiles per wave amortise the weight staging
+    if (gx2 < 1) gx2 = 1;
+    if (gx2 > 128) gx2 = 128;
+    la_out_fused_kernel<C><<<dim3(gx2, B), 256, LDS2, s>>>(x, wq, woutp, ctxfrag, bias, g2, y, n, eps_pre, eps_post, 0.17677669529663687f);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+int la_fused_blocks(int n) {
+    int gx = cdiv(cdiv(n, 32), 8);
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    return gx;
+}
+
+int k_la_weight_prep(const float* wqkv, const float* g, const float* wout, bf16_t* wq, bf16_t* wkv, bf16_t* woutp, int C, hipStream_t s) {
+    la_weight_prep_kernel<<<cdiv(512 * C, 256), 256, 0, s>>>(wqkv, g, wout, wq, wkv, woutp, C);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+int k_linear_attention_fused(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const bf16_t* woutp, const float* bias, const float* g2,
+                             float* partial, bf16_t* ctxfrag, bf16_t* y, int B, int n, int C, float eps_pre, float eps_post, hipStream_t s) {
+    if (C == 64) return launch_la<64>(x, wq, wkv, woutp, bias, g2, partial, ctxfrag, y, B, n, eps_pre, eps_post, s);
+    if (C == 128) return launch_la<128>(x, wq, wkv, woutp, bias, g2, partial, ctxfrag, y, B, n, eps_pre, eps_post, s);
+    set_error("linear_attention_fused: C=%d unsupported", C);
+    return OFD_ERR_ARG;
+}
+
+}  // namespace ofd

@@ -39,6 +39,7 @@ struct ProfRec {
     int cls;
     hipEvent_t e0, e1;
     double flops, bytes;
+    std::string label;
 };
 
 }  // namespace ofd
@@ -60,12 +61,16 @@ struct ofd_unet {
     bf16_t* d_wbuf = nullptr;
     size_t n_wbuf = 0;
     MlpDesc* d_mlp = nullptr;
+    bf16_t* d_labuf = nullptr;                // fused LinearAttention weights (C <= 128): wq | wkv | wout per block
+    size_t n_labuf = 0;
+    std::map<std::string, std::pair<size_t, int>> la_fused;   // block name -> (offset, C)
     bool prepared = false;
     // last forward: taps
     std::map<std::string, Tensor> taps;
     int last_B = 0;
     // profiling
     bool profiling = false;
+    std::string dump_path;                    // per-launch CSV (class,label,ms,flops,bytes) appended on resolve
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
     size_t pool_used = 0;
@@ -132,6 +137,10 @@ static void add_linattn(ofd_unet* u, const std::string& name, int c) {
     add_conv(u, name + ".fn.fn.to_out.0", c, 128, 1, true, -1.0f);
     add_param(u, name + ".fn.fn.to_out.1.g", {1, c, 1, 1});
     add_param(u, name + ".fn.norm.g", {1, c, 1, 1});
+    if (c <= 128) {
+        u->la_fused[name] = {u->n_labuf, c};
+        u->n_labuf += (size_t)512 * c;
+    }
 }
 
 static void build_registry(ofd_unet* u) {
@@ -212,14 +221,14 @@ struct Ctx {
     void reset_scratch() { scratch_used = 0; }
 
     // profiling bracket
-    void begin(int cls, double flops, double bytes) {
+    void begin(int cls, double flops, double bytes, const std::string& label = std::string()) {
         if (!u->profiling) return;
         while (u->pool.size() < u->pool_used + 2) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return;
             u->pool.push_back(e);
         }
-        ProfRec r{cls, u->pool[u->pool_used], u->pool[u->pool_used + 1], flops, bytes};
+        ProfRec r{cls, u->pool[u->pool_used], u->pool[u->pool_used + 1], flops, bytes, label};
         u->pool_used += 2;
         hipEventRecord(r.e0, s);
         u->recs.push_back(r);
@@ -271,7 +280,8 @@ static void conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& 
     const double px = (double)c.B * out.H * out.W;
     const double flops = 2.0 * px * d.Cout * (double)d.Cin * d.ksize * d.ksize;   // counted as the reference executes
     const double bytes = px * 2.0 * (d.Cout + (double)cin / ((srcs[0].upsample) ? 4 : 1)) + (double)d.ksize * d.ksize * d.Cin_pad * d.Cout * 2.0;
-    c.begin(d.ksize == 3 ? PC_CONV3 : (d.ksize == 1 ? PC_CONV1 : PC_CONV7), flops, bytes);
+    c.begin(d.ksize == 3 ? PC_CONV3 : (d.ksize == 1 ? PC_CONV1 : PC_CONV7), flops, bytes,
+            prefix + " " + std::to_string(d.Cin) + "->" + std::to_string(d.Cout) + " @" + std::to_string(out.H) + "x" + std::to_string(out.W));
     RUN(conv_forward_impl(&a, c.s));
     c.end();
 }
@@ -315,13 +325,30 @@ static Tensor resblock(Ctx& c, const std::string& name, const std::vector<Tensor
 static Tensor linattn(Ctx& c, const std::string& name, Tensor x) {
     ofd_unet* u = c.u;
     const int H = x.H, W = x.W, B = c.B, C = x.C, n = H * W;
+    const size_t npix = (size_t)B * n;
+    auto fit = u->la_fused.find(name);
+    if (fit != u->la_fused.end()) {
+        // fused two-pass block (la_fused.hip): no LayerNorm / qkv / head-output tensors in HBM
+        const int nparts = la_fused_blocks(n) * 4;
+        float* partial = c.tmpf((size_t)B * 4 * nparts * 1088);
+        bf16_t* ctxfrag = (bf16_t*)c.tmpf((size_t)B * 2048);
+        Tensor y = c.keep(C, H, W);
+        if (c.rc != OFD_OK) return y;
+        const bf16_t* base = u->d_labuf + fit->second.first;
+        c.begin(PC_LINATTN, npix * 2.0 * (C * 384.0 + 2 * 4 * 32 * 32 + 128.0 * C), (double)npix * C * 2 * 3,
+                name + " fused C=" + std::to_string(C) + " @" + std::to_string(H) + "x" + std::to_string(W));
+        RUN(k_linear_attention_fused(x.p, base, base + (size_t)128 * C, base + (size_t)384 * C, u->P(name + ".fn.fn.to_out.0.bias"),
+                                     u->P(name + ".fn.fn.to_out.1.g"), partial, ctxfrag, y.p, B, n, C, site_eps(u, name + ".fn.norm"),
+                                     site_eps(u, name + ".fn.fn.to_out.1"), c.s));
+        c.end();
+        return y;
+    }
     Tensor xn = c.tmp(C, H, W), qkv = c.tmp(384, H, W), ao = c.tmp(128, H, W), o2 = c.tmp(C, H, W);
     const int nparts = la_parts(n);
     float* partial = c.tmpf((size_t)B * 4 * nparts * 1088);
     float* ctx = c.tmpf((size_t)B * 4 * 1024);
     Tensor y = c.keep(C, H, W);
     if (c.rc != OFD_OK) return y;
-    const size_t npix = (size_t)B * n;
     c.begin(PC_LN, 0, (double)npix * C * 4);
     RUN(k_layernorm_c(x.p, u->P(name + ".fn.norm.g"), nullptr, xn.p, npix, C, site_eps(u, name + ".fn.norm"), c.s));
     c.end();
@@ -386,7 +413,7 @@ static size_t scratch_bytes(const ofd_unet* u, int B, int H, int W) {
     const int C = u->dims[0];
     size_t act = px * 2 * (size_t)(3 * C + C + 384 + 128 + C);
     // mid level widest: 512 ch at 1/64 of the pixels is far smaller; small buffers:
-    size_t small = 4 * ofd_conv_gn_partial_count(B, H, W, u->dims[4]) * 4 + (size_t)B * 4 * (la_parts(H * W) * 1088 + 1024) * 4 +
+    size_t small = 4 * ofd_conv_gn_partial_count(B, H, W, u->dims[4]) * 4 + (size_t)B * 4 * ((size_t)(la_parts(H * W) > 256 ? la_parts(H * W) : 256) * 1088 + 1024) * 4 +
                    16 * (size_t)B * u->dims[4] * 4 + 64 * 1024;
     return act + small + 64 * 256;
 }
@@ -408,7 +435,8 @@ extern "C" int ofd_unet_create(const ofd_unet_config* cfg, ofd_unet** out) {
     build_registry(u);
     if (hipMalloc(&u->d_params, u->n_param_floats * sizeof(float)) != hipSuccess ||
         hipMalloc(&u->d_wbuf, u->n_wbuf * sizeof(bf16_t)) != hipSuccess ||
-        hipMalloc(&u->d_mlp, u->resblocks.size() * sizeof(MlpDesc)) != hipSuccess) {
+        hipMalloc(&u->d_mlp, u->resblocks.size() * sizeof(MlpDesc)) != hipSuccess ||
+        hipMalloc(&u->d_labuf, (u->n_labuf + 8) * sizeof(bf16_t)) != hipSuccess) {
         set_error("unet_create: hipMalloc failed");
         ofd_unet_destroy(u);
         return OFD_ERR_HIP;
@@ -433,6 +461,7 @@ extern "C" void ofd_unet_destroy(ofd_unet* u) {
     if (u->d_params) hipFree(u->d_params);
     if (u->d_wbuf) hipFree(u->d_wbuf);
     if (u->d_mlp) hipFree(u->d_mlp);
+    if (u->d_labuf) hipFree(u->d_labuf);
     for (auto e : u->pool) hipEventDestroy(e);
     delete u;
 }
@@ -470,6 +499,14 @@ extern "C" int ofd_unet_prepare(ofd_unet* u, void* stream) {
         }
     for (auto& c : u->convs) {
         int rc = ofd_conv_weight_prep(u->P(c.wname), u->d_wbuf + c.w_off, c.Cout, c.Cin, c.Cin_pad, c.ksize, c.ws_eps, c.unshuffle, stream);
+        if (rc != OFD_OK) return rc;
+    }
+    for (auto& kv : u->la_fused) {
+        const std::string& name = kv.first;
+        const int C = kv.second.second;
+        bf16_t* base = u->d_labuf + kv.second.first;
+        int rc = k_la_weight_prep(u->P(name + ".fn.fn.to_qkv.weight"), u->P(name + ".fn.norm.g"), u->P(name + ".fn.fn.to_out.0.weight"),
+                                  base, base + (size_t)128 * C, base + (size_t)384 * C, C, (hipStream_t)stream);
         if (rc != OFD_OK) return rc;
     }
     u->prepared = true;
@@ -607,19 +644,27 @@ extern "C" int ofd_unet_set_profiling(ofd_unet* u, int enabled) {
     u->profiling = enabled != 0;
     return OFD_OK;
 }
+extern "C" int ofd_unet_prof_dump_path(ofd_unet* u, const char* path) {
+    OFD_CHECK_ARG(u, "unet_prof_dump_path: null handle");
+    u->dump_path = path ? path : "";
+    return OFD_OK;
+}
 extern "C" int ofd_unet_prof_count(const ofd_unet* u) { return u ? PC_COUNT : 0; }
 extern "C" const char* ofd_unet_prof_name(const ofd_unet* u, int i) { return (u && i >= 0 && i < PC_COUNT) ? kProfNames[i] : ""; }
 
 static int prof_resolve(ofd_unet* u) {
+    FILE* dump = u->dump_path.empty() ? nullptr : fopen(u->dump_path.c_str(), "a");
     for (auto& r : u->recs) {
         OFD_HIP(hipEventSynchronize(r.e1));
         float ms = 0.0f;
         OFD_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        if (dump) fprintf(dump, "%s,%s,%.4f,%.6g,%.6g\n", kProfNames[r.cls], r.label.c_str(), ms, r.flops, r.bytes);
         u->acc_ms[r.cls] += ms;
         u->acc_flops[r.cls] += r.flops;
         u->acc_bytes[r.cls] += r.bytes;
         u->acc_launch[r.cls] += 1;
     }
+    if (dump) fclose(dump);
     u->recs.clear();
     u->pool_used = 0;
     return OFD_OK;

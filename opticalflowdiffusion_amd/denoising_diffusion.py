@@ -172,8 +172,9 @@ class Unet(nn.Module):
         return out
 
     # -- per-kernel-class device timing (HIP events on the launch stream) ----------------------
-    def set_profiling(self, enabled):
+    def set_profiling(self, enabled, dump_path=None):
         L.check(L.lib().ofd_unet_set_profiling(self._handle, int(enabled)))
+        L.check(L.lib().ofd_unet_prof_dump_path(self._handle, dump_path.encode() if dump_path else None))
 
     def profile(self, reset=False):
         lib = L.lib()
