@@ -169,7 +169,8 @@ typedef struct {
     const float* res_scale;
     const float* res_shift;
     void* out;              /* bf16 NHWC (B,H,W,Cout) */
-    float* gn_partial;      /* optional: per-tile GroupNorm partial sums, see ofd_conv_gn_partial_count */
+    float* gn_partial;      /* optional: GroupNorm partial sums [b][tile][wave][Cout/8][2] (sum, sum of squares of
+                               the stored values), ofd_conv_gn_partial_count floats */
 } ofd_conv_args;
 
 int ofd_conv_forward(const ofd_conv_args* a, void* stream);

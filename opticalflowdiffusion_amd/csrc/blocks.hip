@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) block_mlp_kernel(const float* __restrict_
 }
 
 // ---- GroupNorm(8) statistics -> per-(sample, channel) affine (DD:181-185) -------------------------
-// partial: [B][tiles][C/8][2] from the conv epilogue.  y = x*a + s with
+// partial: [B][tiles*4 waves][C/8][2] from the conv epilogue.  y = x*a + s with
 //   a = gamma*rstd*(scale+1), s = (beta - mean*rstd*gamma)*(scale+1) + shift.   grid (B, 8)
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial, int tiles, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -470,22 +470,36 @@ __global__ void __launch_bounds__(256) flash_attn_d32_kernel(const bf16_t* __res
 }
 
 // ---- DD:361,417: final 1x1 conv (fp32 weights) -> NCHW fp32 -------------------------------------
+// C/8 lanes cooperate on one pixel (16 B each, so a wave reads whole 128-B lines); shuffle-reduce.
 __global__ void __launch_bounds__(256) final_conv_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ out, int C, int out_dim, size_t plane, size_t total) {
-    extern __shared__ float wsm[];     // [out_dim][C]
-    for (int i = threadIdx.x; i < out_dim * C; i += 256) wsm[i] = w[i];
-    __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t n = i / plane, pix = i % plane;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < C; c += 8) {
-            float f[8];
-            unpack8(*(const uint4*)(x + i * C + c), f);
-            for (int o = 0; o < out_dim; ++o)
+    const int lpp = C / 8, lane = threadIdx.x & 63, sub = lane % lpp, slot = lane / lpp, ppw = 64 / lpp;
+    float wv[4][8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[o] += f[j] * wsm[o * C + c + j];
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[o][j] = (o < out_dim) ? w[o * C + sub * 8 + j] : 0.0f;
+    const size_t wave_global = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t p0 = wave_global * ppw; p0 < total; p0 += nwaves * ppw) {
+        const size_t i = min(p0 + slot, total - 1);
+        float f[8];
+        unpack8(*(const uint4*)(x + i * C + sub * 8), f);
+        float acc[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            acc[o] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[o] += f[j] * wv[o][j];
+            for (int k = 1; k < lpp; k <<= 1) acc[o] += __shfl_xor(acc[o], k, 64);
         }
-        for (int o = 0; o < out_dim; ++o) out[(n * out_dim + o) * plane + pix] = acc[o] + bias[o];
+        if (sub < out_dim && p0 + slot < total) {
+            const size_t n = i / plane, pix = i % plane;
+            float r = acc[0];
+            if (sub == 1) r = acc[1];
+            if (sub == 2) r = acc[2];
+            if (sub == 3) r = acc[3];
+            out[(n * out_dim + sub) * plane + pix] = r + bias[sub];
+        }
     }
 }
 
@@ -533,7 +547,7 @@ int k_block_mlp(const float* temb_silu, const MlpDesc* descs, int n_desc, float*
 int k_gn_finalize(const float* partial, int B, int H, int W, int C, const float* gamma, const float* beta, const float* ss, int ss_stride,
                   int ss_offset, float* a_out, float* s_out, hipStream_t s) {
     OFD_CHECK_ARG(C % 64 == 0, "gn_finalize: C=%d", C);
-    const int tiles = cdiv(H, 8) * cdiv(W, 32);
+    const int tiles = cdiv(H, 8) * cdiv(W, 32) * 4;    // one partial per (tile, wave) from the conv epilogue
     gn_finalize_kernel<<<dim3(B, 8), 256, 0, s>>>(partial, tiles, C, (double)H * W * (C / 8), gamma, beta, ss, ss_stride, ss_offset, a_out, s_out);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
@@ -569,7 +583,8 @@ int k_flash_attention(const bf16_t* qkv, bf16_t* out, int B, int n, hipStream_t 
 }
 int k_final_conv(const bf16_t* x, const float* w, const float* bias, float* out, int B, int H, int W, int C, int out_dim, hipStream_t s) {
     OFD_CHECK_ARG(out_dim >= 1 && out_dim <= 4 && C % 8 == 0, "final_conv: out_dim=%d C=%d", out_dim, C);
-    final_conv_kernel<<<sgrid((size_t)B * H * W), 256, out_dim * C * sizeof(float), s>>>(x, w, bias, out, C, out_dim, (size_t)H * W, (size_t)B * H * W);
+    OFD_CHECK_ARG(C == 64 || C == 128 || C == 256 || C == 512, "final_conv: C=%d unsupported", C);
+    final_conv_kernel<<<sgrid(((size_t)B * H * W + (512 / C) - 1) / (512 / C) * 64), 256, 0, s>>>(x, w, bias, out, C, out_dim, (size_t)H * W, (size_t)B * H * W);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

@@ -17,6 +17,7 @@
 // from XOR-swizzled images (conflict-free, see swz()).  The MFMA is issued "swapped"
 // (A = weights, B = pixels) so that a lane's accumulator registers are 4 consecutive output
 // channels of one pixel -> 8-byte NHWC stores.
+#include <cstdlib>
 #include "common.h"
 
 namespace ofd {
@@ -49,6 +50,7 @@ struct ConvParams {
     const float* res_shift;
     bf16_t* out;
     float* gn_partial;
+    int dbg;            // diagnostic ablation bits (OFD_CONV_DBG), 0 in production
 };
 
 template <int KS, int BN>
@@ -117,6 +119,8 @@ template <int KS, int BN>
 __device__ __forceinline__ void conv_load_w(U4Arr<Cfg<KS, BN>::WPT>& wr, const bf16_t* __restrict__ weight, int cin8, int Cout, int n0,
                                             int kc, int st, int tid) {
     using C = Cfg<KS, BN>;
+    kc += st / C::STAGES;      // the slab index runs on into the following chunks
+    st %= C::STAGES;
 #pragma unroll
     for (int i = 0; i < C::WPT; ++i) {
         int u = tid + i * NTHREADS;
@@ -125,7 +129,7 @@ __device__ __forceinline__ void conv_load_w(U4Arr<Cfg<KS, BN>::WPT>& wr, const b
         size_t row;
         if (KS == 7) row = (size_t)(st * 7 + r / 2) * 2 + (r & 1);
         else row = (size_t)st * cin8 + kc * 8 + r;
-        wr.v[i] = *(const u32x4*)(weight + (row * Cout + n0 + n) * 8);
+        wr.v[i] = *(const u32x4*)(weight + (row * Cout + n0 + n) * 8);   // (diagnostic bit 2 handled by the caller)
     }
 }
 template <int KS, int BN>
@@ -170,11 +174,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.0f;
 
-    U4Arr<C::WPT> wreg;
-
-    // No predication anywhere in the staging code: indices past the end are clamped (duplicates
-    // rewrite identical bytes), so the loads issue back to back and stay in registers.
+    // Weight pipeline: slab g = kc*STAGES + st lives in registers for two stages before it is written
+    // to its LDS buffer (g & 1): the global load of slab g+2 is issued at the top of stage g and
+    // consumed at the end of stage g+1, so ~2 stages of MFMA work cover the L2 latency.  The
+    // pipeline runs on across chunk boundaries.  No predication anywhere in the staging code:
+    // indices past the end are clamped (duplicates rewrite identical bytes).
+    // (BN = 128 has no registers to spare for the second set: there the load of slab g+1 is issued
+    // at the top of stage g and consumed at its end.)
+    constexpr bool DEEP = (BN == 64);
+    U4Arr<C::WPT> w1, w2;     // slabs g+1 and g+2
     const int cin8 = P.Cin_total / 8;
+    const int total_slabs = P.total_chunks * C::STAGES;
+    const int dbg = P.dbg;
+    conv_load_w<KS, BN>(w1, P.weight, cin8, P.Cout, n0, 0, 0, tid);                                   // slab 0
+    if (DEEP) conv_load_w<KS, BN>(w2, P.weight, cin8, P.Cout, n0, 0, (total_slabs > 1) ? 1 : 0, tid);   // slab 1
+
     int src_i = 0, src_first = 0;   // source that owns chunk kc, and its first chunk
     for (int kc = 0; kc < P.total_chunks; ++kc) {
         while (kc >= src_first + P.src[src_i].chunks) {
@@ -185,6 +199,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
         const int s_ch = P.src[src_i].src_channels, s_off = P.src[src_i].ch_offset, s_SH = P.src[src_i].SH, s_SW = P.src[src_i].SW;
         const int s_mode = P.src[src_i].mode, s_p1 = P.src[src_i].p1, s_p2 = P.src[src_i].p2;
         const int kcl = kc - src_first;
+        const int g0 = kc * C::STAGES;
 
         // ---- stage the input tile (+halo) of this chunk: global -> regs -> (affine+SiLU) -> LDS
         uint4 xreg[C::XPT];
@@ -202,9 +217,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             int sy = cy, sx = cx;
             if (s_mode == 1) { sy = cy >> 1; sx = cx >> 1; }
             else if (s_mode == 2) { sy = 2 * cy + s_p1; sx = 2 * cx + s_p2; }
-            xreg[i] = *(const uint4*)(s_base + ((size_t)sy * s_SW + sx) * s_ch);
+            xreg[i] = (dbg & 1) ? make_uint4(tid, i, 0, 0) : *(const uint4*)(s_base + ((size_t)sy * s_SW + sx) * s_ch);
         }
-        conv_load_w<KS, BN>(wreg, P.weight, cin8, P.Cout, n0, kc, 0, tid);
         float ps[8], pb[8];
         if (P.in_scale) {
             const int cg = kc * C::CK + c8 * 8;
@@ -214,7 +228,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
                 pb[j] = P.in_shift[(size_t)b * P.Cin_total + cg + j];
             }
         }
-        __syncthreads();   // every wave has finished reading lds_x / lds_w of the previous chunk
+        __syncthreads();   // every wave has finished reading lds_x (and the W buffer of slab g0-1)
 #pragma unroll
         for (int i = 0; i < C::XPT; ++i) {
             const int p = min(tid / C::NC + i * (NTHREADS / C::NC), C::NPIX - 1);
@@ -233,14 +247,22 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
             *(uint4*)(lds_x + p * (C::CK * 2) + ((c8 ^ swz<C::CK>(p)) * 16)) = v;
         }
-        conv_store_w<KS, BN>(wreg, lds_w, tid);
+        if (kc == 0) {     // slab 0 -> LDS buffer 0; rotate: w1 <- slab 1, w2 <- slab 2
+            conv_store_w<KS, BN>(w1, lds_w, tid);
+            if (DEEP) {
+                w1 = w2;
+                conv_load_w<KS, BN>(w2, P.weight, cin8, P.Cout, n0, 0, (total_slabs > 2) ? 2 : 0, tid);
+            }
+        }
 
-        // ---- weight slabs: prefetch slab st+1 to registers while slab st feeds the MFMAs
-#pragma unroll 1
+        // ---- stages of this chunk (BN = 64: fully unrolled, tap offsets become compile-time constants)
+        constexpr int UNR = DEEP ? C::STAGES : 1;
+#pragma unroll UNR
         for (int st = 0; st < C::STAGES; ++st) {
-            if (st + 1 < C::STAGES) conv_load_w<KS, BN>(wreg, P.weight, cin8, P.Cout, n0, kc, st + 1, tid);
-            __syncthreads();   // lds_x (st == 0) and lds_w[st & 1] are complete
-            const unsigned char* wbuf = lds_w + (st & 1) * C::W_BYTES;
+            const int g = g0 + st;
+            if (!DEEP && g + 1 < total_slabs) conv_load_w<KS, BN>(w1, P.weight, cin8, P.Cout, n0, kc, st + 1, tid);
+            __syncthreads();   // lds_x (st == 0) and the W buffer of slab g are complete
+            const unsigned char* wbuf = lds_w + (g & 1) * C::W_BYTES;
             const int ky = (KS == 3) ? st / 3 : (KS == 7 ? st : 0);
             const int kx3 = (KS == 3) ? st % 3 : 0;
 #pragma unroll
@@ -256,13 +278,26 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
 #pragma unroll
                 for (int nt = 0; nt < C::NTN; ++nt)
                     wf[nt] = *(const bf16x8*)(wbuf + ((ks * 2 + half) * BN + nt * 32 + l31) * 16);
+                if (!(dbg & 4)) {
 #pragma unroll
-                for (int nt = 0; nt < C::NTN; ++nt)
+                    for (int nt = 0; nt < C::NTN; ++nt)
 #pragma unroll
-                    for (int pt = 0; pt < 2; ++pt)
-                        acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[pt], acc[nt][pt], 0, 0, 0);
+                        for (int pt = 0; pt < 2; ++pt)
+                            acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[pt], acc[nt][pt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < C::NTN; ++nt) asm volatile("" ::"v"(wf[nt]));
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) asm volatile("" ::"v"(xf[pt]));
+                }
             }
-            if (st + 1 < C::STAGES) conv_store_w<KS, BN>(wreg, lds_w + ((st + 1) & 1) * C::W_BYTES, tid);   // other buffer: last read in stage st-1
+            // slab g+1 (loaded two stages ago) -> the other LDS buffer (last read in stage g-1, and
+            // every wave is past this stage's barrier); then start the load of slab g+3
+            if (g + 1 < total_slabs) conv_store_w<KS, BN>(w1, lds_w + ((g + 1) & 1) * C::W_BYTES, tid);
+            if (DEEP) {
+                w1 = w2;
+                if (g + 3 < total_slabs) conv_load_w<KS, BN>(w2, P.weight, cin8, P.Cout, n0, kc, st + 3, tid);
+            }
         }
     }
 
@@ -289,7 +324,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
                     const float4 bv = *(const float4*)(P.bias + c);
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                 }
-                if (ok) {
+                if (ok && !(dbg & 16)) {
                     if (P.res_act) {
                         const uint2 r = *(const uint2*)(P.res_act + pix * P.Cout + c);
                         const float4 sc = *(const float4*)(P.res_scale + (size_t)b * P.Cout + c);
@@ -319,19 +354,241 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
         }
     }
 
-    if (P.gn_partial) {
+    if (P.gn_partial) {   // per-wave partial sums: [b][tile][wave][Cout/8][2]; gn_finalize adds them up
         wave_reduce_multi<NV>(stat);
-        __syncthreads();                           // all MFMA reads of LDS are done: reuse it
-        float* red = (float*)smem;                 // [4 waves][NV]
         constexpr int SH_ = (NV == 32) ? 1 : 2;    // lane l holds value index l >> SH_
-        if ((lane & ((1 << SH_) - 1)) == 0) red[wave * NV + (lane >> SH_)] = stat[0];
-        __syncthreads();
-        if (tid < NV) {
-            const float s = (red[tid] + red[NV + tid]) + (red[2 * NV + tid] + red[3 * NV + tid]);
-            const size_t base = ((size_t)b * (P.tiles_x * P.tiles_y) + t_in) * (P.Cout / 8) * 2;
-            P.gn_partial[base + (n0 / 8) * 2 + tid] = s;
+        if ((lane & ((1 << SH_) - 1)) == 0) {
+            const size_t base = (((size_t)b * (P.tiles_x * P.tiles_y) + t_in) * 4 + wave) * (P.Cout / 8) * 2;
+            P.gn_partial[base + (n0 / 8) * 2 + (lane >> SH_)] = stat[0];
         }
     }
+}
+
+// ================================================================================================
+// Persistent ping-pong variant for the full-resolution workhorse: 3x3, Cin = Cout = 64, one source.
+// The generic kernel above re-streams the 73.7 KB of weights for every 8x32 tile and runs its
+// phases (stage X, 9 weight slabs, epilogue) back to back, which leaves the MFMA pipe idle ~75 %
+// of the time at N = 64.  Here a workgroup of 8 waves stays resident (one per CU):
+//   * all 9 taps of weights live in LDS for the whole launch (loaded once);
+//   * the waves form two groups of 4 that work on neighbouring tiles in opposite phases: while
+//     group A issues the 144 MFMAs per wave of its tile, group B runs its epilogue (bias, bf16
+//     store, GroupNorm partials) and stages its next input tile (prologue affine+SiLU, LDS
+//     write) -- then they swap.  One workgroup barrier per phase;
+//   * the global loads of a group's NEXT input tile are issued at the start of its MFMA phase
+//     and consumed in the following staging phase, so their latency hides behind the MFMAs.
+// LDS: 73,728 B weights + 2 x 43,520 B input tiles = 160,768 B.
+constexpr int PP_THREADS = 512;
+// X tile in LDS is unit-major: [8 channel-octets][341 pixel slots][16 B].  Consecutive pixels of one
+// octet are consecutive 16-B slots (conflict-free ds_read_b128 with no swizzle), taps and k-steps are
+// immediate offsets from ONE base address per output row, and 341 (odd multiple of 4 banks off 32)
+// keeps the 8 octets of a pixel on distinct banks for the staging writes.
+constexpr int PP_US = 341 * 16;   // bytes per octet row
+constexpr int PP_XB = 8 * PP_US, PP_WB = 9 * 8 * 64 * 16, PP_LDS = PP_WB + 2 * PP_XB + 256;
+
+struct PPTile {
+    int b, oy0, ox0, t_in;
+    bool valid;
+};
+
+__device__ __forceinline__ PPTile pp_tile(int t, int ntiles, int tiles_x, int tpi) {
+    PPTile r;
+    r.valid = t < ntiles;
+    t = min(t, ntiles - 1);
+    r.b = t / tpi;
+    r.t_in = t - r.b * tpi;
+    r.oy0 = (r.t_in / tiles_x) * TH;
+    r.ox0 = (r.t_in % tiles_x) * TW;
+    return r;
+}
+
+struct PPX {
+    u32x4 v[11];
+    unsigned okmask;
+};
+
+__device__ __forceinline__ void pp_load_x(PPX& xr, const ConvParams& P, const PPTile& T, int gt) {
+    const int c8 = gt & 7;
+    const bf16_t* base = P.src[0].ptr + (size_t)T.b * P.H * P.W * P.src[0].src_channels + P.src[0].ch_offset + c8 * 8;
+    unsigned ok_all = 0;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int p = min((gt >> 3) + i * 32, 339);
+        const int ty = p / 34, tx = p - ty * 34;
+        const int iy = T.oy0 - 1 + ty, ix = T.ox0 - 1 + tx;
+        const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+        ok_all |= (ok ? 1u : 0u) << i;
+        const int cy = min(max(iy, 0), P.H - 1), cx = min(max(ix, 0), P.W - 1);
+        xr.v[i] = *(const u32x4*)(base + ((size_t)cy * P.W + cx) * P.src[0].src_channels);
+    }
+    xr.okmask = ok_all;
+}
+
+__device__ __forceinline__ void pp_write_x(const PPX& xr, const ConvParams& P, const PPTile& T, unsigned char* xbuf, int gt) {
+    const int c8 = gt & 7;
+    float ps[8], pb[8];
+    if (P.in_scale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ps[j] = P.in_scale[(size_t)T.b * 64 + c8 * 8 + j];
+            pb[j] = P.in_shift[(size_t)T.b * 64 + c8 * 8 + j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int p = min((gt >> 3) + i * 32, 339);
+        u32x4 v = xr.v[i];
+        if (P.in_scale) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = silu_f(bf2f((bf16_t)(v[j] & 0xffffu)) * ps[2 * j] + pb[2 * j]);
+                const float hi = silu_f(bf2f((bf16_t)(v[j] >> 16)) * ps[2 * j + 1] + pb[2 * j + 1]);
+                v[j] = pack2(lo, hi);
+            }
+        }
+        const bool ok = (xr.okmask >> i) & 1u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
+        *(u32x4*)(xbuf + c8 * PP_US + p * 16) = v;
+    }
+}
+
+__device__ __forceinline__ void pp_mfma(f32x16 (&acc)[2][2], const unsigned char* lds_w, const unsigned char* xbuf, int wv, int l31, int half) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.0f;
+    // 36 k-steps (9 taps x 4); the operand fragments of step s+1 are read from LDS before the
+    // MFMAs of step s are issued (one wave per SIMD is in its MFMA phase: nobody else hides the
+    // ds_read latency)
+    const unsigned char* xrow = xbuf + half * PP_US + (wv * 2 * 34 + l31) * 16;   // every operand read = base + immediate
+    const unsigned char* wrow = lds_w + (half * 64 + l31) * 16;
+    bf16x8 xf[3][2], wf[3][2];
+    auto read_frags = [&](int step, bf16x8 (&x2)[2], bf16x8 (&w2)[2]) {
+        const int tap = step >> 2, ks = step & 3, ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) x2[pt] = *(const bf16x8*)(xrow + ((pt + ky) * 34 + kx) * 16 + ks * 2 * PP_US);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) w2[nt] = *(const bf16x8*)(wrow + ((tap * 8 + ks * 2) * 64 + nt * 32) * 16);
+    };
+    read_frags(0, xf[0], wf[0]);
+    read_frags(1, xf[1], wf[1]);
+#pragma unroll
+    for (int step = 0; step < 36; ++step) {
+        if (step + 2 < 36) read_frags(step + 2, xf[(step + 2) % 3], wf[(step + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads two steps ahead of the MFMAs that consume them
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+                acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[step % 3][nt], xf[step % 3][pt], acc[nt][pt], 0, 0, 0);
+    }
+}
+
+// Epilogue with 16-byte stores: a lane holds 4 consecutive channels (8 B) per register quad; one
+// v_permlane32_swap per dword between quads g and g+1 gives the lower half-wave 8 consecutive
+// channels of quad g and the upper half-wave those of quad g+1 -> half as many store instructions
+// (the 8-byte form is store-issue bound).
+__device__ __forceinline__ void pp_epilogue(const f32x16 (&acc)[2][2], const ConvParams& P, const PPTile& T, const float* s_bias, int wv, int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+    float stat[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) stat[i] = 0.0f;
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int oy = T.oy0 + wv * 2 + pt, ox = T.ox0 + l31;
+        const bool ok = oy < P.H && ox < P.W;
+        const size_t pix = ((size_t)T.b * P.H + oy) * P.W + ox;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            uint2 q[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *(const float4*)(s_bias + nt * 32 + 8 * g + 4 * half);
+                q[g] = make_uint2(pack2(acc[nt][pt][4 * g] + bv.x, acc[nt][pt][4 * g + 1] + bv.y),
+                                  pack2(acc[nt][pt][4 * g + 2] + bv.z, acc[nt][pt][4 * g + 3] + bv.w));
+                if (P.gn_partial && ok) {
+                    const float q0 = bf2f((bf16_t)(q[g].x & 0xffffu)), q1 = bf2f((bf16_t)(q[g].x >> 16));
+                    const float q2 = bf2f((bf16_t)(q[g].y & 0xffffu)), q3 = bf2f((bf16_t)(q[g].y >> 16));
+                    stat[(nt * 4 + g) * 2] += (q0 + q1) + (q2 + q3);
+                    stat[(nt * 4 + g) * 2 + 1] += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
+                const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
+                if (ok) *(uint4*)(P.out + pix * 64 + nt * 32 + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            }
+        }
+    }
+    if (P.gn_partial) {
+        wave_reduce_multi<16>(stat);
+        if ((lane & 3) == 0) {
+            const size_t base = (((size_t)T.b * (P.tiles_x * P.tiles_y) + T.t_in) * 4 + wv) * 16;
+            P.gn_partial[base + (lane >> 2)] = stat[0];
+        }
+    }
+}
+
+// Phase barrier: only LDS traffic has to be complete (lgkmcnt).  __syncthreads() would also drain
+// vmcnt, i.e. wait for the epilogue's global stores and the in-flight prefetch of the next tile.
+__device__ __forceinline__ void pp_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ void __launch_bounds__(PP_THREADS, 1) conv3x3_c64_pingpong_kernel(const ConvParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lds_w = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int group = wave >> 2, wv = wave & 3, gt = tid & 255;
+    unsigned char* xbuf = smem + PP_WB + group * PP_XB;
+    const int tpi = P.tiles_x * P.tiles_y, ntiles = tpi * P.B;
+    const int npairs = (ntiles + 1) / 2;
+    const int n_iter = (npairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // pairs of this workgroup
+
+    // weights: resident for the whole launch
+#pragma unroll
+    for (int i = 0; i < PP_WB / 16 / PP_THREADS; ++i)
+        *(u32x4*)(lds_w + (tid + i * PP_THREADS) * 16) = *(const u32x4*)(P.weight + (size_t)(tid + i * PP_THREADS) * 8);
+
+    float* s_bias = (float*)(smem + PP_WB + 2 * PP_XB);
+    if (tid < 64) s_bias[tid] = P.bias ? P.bias[tid] : 0.0f;
+
+    auto my_tile = [&](int i) { return pp_tile(((int)blockIdx.x + i * (int)gridDim.x) * 2 + group, ntiles, P.tiles_x, tpi); };
+
+    PPX xr;
+    PPTile cur = my_tile(0), prev = cur;
+    pp_load_x(xr, P, cur, gt);
+    pp_write_x(xr, P, cur, xbuf, gt);
+    __syncthreads();
+
+    f32x16 acc[2][2];
+    for (int i = 0; i < n_iter; ++i) {
+        const PPTile nxt = my_tile(i + 1);        // (clamped to a valid tile past the end; never stored)
+        if (group == 0) {
+            if (!(P.dbg & 1)) pp_load_x(xr, P, nxt, gt);
+            if (!(P.dbg & 4)) pp_mfma(acc, lds_w, xbuf, wv, l31, half);
+        } else if (i > 0) {
+            if (prev.valid && !(P.dbg & 16)) pp_epilogue(acc, P, prev, s_bias, wv, lane);
+            if (!(P.dbg & 32)) pp_write_x(xr, P, cur, xbuf, gt);
+        }
+        pp_barrier();
+        if (group == 0) {
+            if (cur.valid && !(P.dbg & 16)) pp_epilogue(acc, P, cur, s_bias, wv, lane);
+            if (!(P.dbg & 32)) pp_write_x(xr, P, nxt, xbuf, gt);
+        } else {
+            if (!(P.dbg & 1)) pp_load_x(xr, P, nxt, gt);
+            if (!(P.dbg & 4)) pp_mfma(acc, lds_w, xbuf, wv, l31, half);
+        }
+        pp_barrier();
+        prev = cur;
+        cur = nxt;
+    }
+    if (group == 1 && n_iter > 0 && prev.valid) pp_epilogue(acc, P, prev, s_bias, wv, lane);
 }
 
 // ---- weight preparation: OIHW fp32 -> [tap][Cin_pad/8][Cout][8] bf16 (+ weight standardisation)
@@ -423,7 +680,23 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     P.weight = (const bf16_t*)a->weight; P.bias = a->bias; P.in_scale = a->in_scale; P.in_shift = a->in_shift;
     P.residual = (const bf16_t*)a->residual; P.res_act = (const bf16_t*)a->res_act; P.res_scale = a->res_scale; P.res_shift = a->res_shift;
     P.out = (bf16_t*)a->out; P.gn_partial = a->gn_partial;
+    { static int dbg_env = -1; if (dbg_env < 0) { const char* e = getenv("OFD_CONV_DBG"); dbg_env = e ? atoi(e) : 0; } P.dbg = dbg_env; }
     const bool wide = (a->Cout % 128 == 0);
+    static int no_pp = -1;
+    if (no_pp < 0) { const char* e = getenv("OFD_NO_PINGPONG"); no_pp = (e && atoi(e)) ? 1 : 0; }
+    if (a->ksize == 3 && a->Cout == 64 && P.Cin_total == 64 && a->n_src == 1 && P.src[0].mode == 0 && !a->residual && !a->res_act && !no_pp) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            OFD_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_pingpong_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
+            attr_set = true;
+        }
+        const int ntiles = P.tiles_x * P.tiles_y * P.B, npairs = (ntiles + 1) / 2;
+        static int pp_grid = -1;
+        if (pp_grid < 0) { const char* e = getenv("OFD_PP_GRID"); pp_grid = e ? atoi(e) : 256; }
+        conv3x3_c64_pingpong_kernel<<<npairs < pp_grid ? npairs : pp_grid, PP_THREADS, PP_LDS, s>>>(P);
+        OFD_LAUNCH_CHECK();
+        return OFD_OK;
+    }
     if (a->ksize == 3) return wide ? launch_conv<3, 128>(P, s) : launch_conv<3, 64>(P, s);
     if (a->ksize == 1) return wide ? launch_conv<1, 128>(P, s) : launch_conv<1, 64>(P, s);
     return launch_conv<7, 64>(P, s);
@@ -435,7 +708,7 @@ using namespace ofd;
 extern "C" int ofd_conv_forward(const ofd_conv_args* a, void* stream) { return conv_forward_impl(a, (hipStream_t)stream); }
 
 extern "C" size_t ofd_conv_gn_partial_count(int B, int H, int W, int Cout) {
-    return (size_t)B * cdiv(H, TH) * cdiv(W, TW) * (Cout / 8) * 2;
+    return (size_t)B * cdiv(H, TH) * cdiv(W, TW) * 4 * (Cout / 8) * 2;     // [b][tile][wave][Cout/8][2]
 }
 
 extern "C" size_t ofd_conv_weight_elems(int Cout, int Cin_pad, int ksize) { return (size_t)ksize * ksize * Cin_pad * Cout; }

@@ -28,21 +28,32 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s2) {
     return f;
 }
 
-// x tile of 32 pixels -> normalised (no gain) bf16 fragments; lane (pixel, half) holds channels
-// 16 s + 8 half .. + 7 of its pixel for every k-step s.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 template <int C>
-__device__ __forceinline__ void load_norm_x(const bf16_t* __restrict__ xrow, float eps, bf16x8 (&xs)[C / 16], int half) {
+struct XRaw {
+    u32x4 v[C / 16];
+};
+
+// raw x row of this lane's pixel: channels 16 s + 8 half .. + 7 for every k-step s
+template <int C>
+__device__ __forceinline__ void load_raw_x(const bf16_t* __restrict__ xrow, XRaw<C>& r, int half) {
+#pragma unroll
+    for (int s = 0; s < C / 16; ++s) r.v[s] = *(const u32x4*)(xrow + 16 * s + 8 * half);
+}
+
+// raw tile -> normalised (no gain) bf16 fragments (LayerNorm over channels, DD:121-125)
+template <int C>
+__device__ __forceinline__ void norm_x(const XRaw<C>& r, float eps, bf16x8 (&xs)[C / 16]) {
     constexpr int KS = C / 16;
     float v[KS][8];
     float sum = 0.0f;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const uint4 raw = *(const uint4*)(xrow + 16 * s + 8 * half);
-        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            v[s][2 * j] = bf2f((bf16_t)(w[j] & 0xffffu));
-            v[s][2 * j + 1] = bf2f((bf16_t)(w[j] >> 16));
+            const uint32_t w = r.v[s][j];
+            v[s][2 * j] = bf2f((bf16_t)(w & 0xffffu));
+            v[s][2 * j + 1] = bf2f((bf16_t)(w >> 16));
             sum += v[s][2 * j] + v[s][2 * j + 1];
         }
     }
@@ -84,13 +95,18 @@ __global__ void __launch_bounds__(256, 2) la_ctx_fused_kernel(const bf16_t* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) ctxT[hd][r] = 0.0f;
     }
+    const bf16_t* xb = x + (size_t)b * n * C;
+    XRaw<C> raw_next;
+    load_raw_x<C>(xb + (size_t)min(wave_id * 32 + l31, n - 1) * C, raw_next, half);
     for (int tile = wave_id; tile < ntiles; tile += nw) {
         // the weight fragments are loop-invariant LDS reads: without this the compiler hoists all of
         // them into registers (C=128: 512 VGPRs + scratch spills) instead of re-reading LDS per tile
         asm volatile("" ::: "memory");
-        const int pid = min(tile * 32 + l31, n - 1);
+        const XRaw<C> raw = raw_next;
+        // software prefetch of the next tile's rows (clamped: the last prefetch re-reads a valid row)
+        load_raw_x<C>(xb + (size_t)min((tile + nw) * 32 + l31, n - 1) * C, raw_next, half);
         bf16x8 xs[KS];
-        load_norm_x<C>(x + ((size_t)b * n + pid) * C, eps, xs, half);
+        norm_x<C>(raw, eps, xs);
 #pragma unroll
         for (int hd = 0; hd < 4; ++hd) {
             f32x16 ka, va;
@@ -145,32 +161,47 @@ __global__ void __launch_bounds__(256, 2) la_ctx_fused_kernel(const bf16_t* __re
 
 // combine partials -> context as pass 2's A fragments:
 // ctxfrag[bh][s2][lane][j] = ctx[d = 16 s2 + 8 (j>>2) + 4 (lane>>5) + (j&3)][e = lane & 31]
+// grid (B*4, 4): each workgroup produces 256 of the 1024 fragment elements of one (sample, head);
+// the per-part rescale weights exp(m_c - M) are computed once into LDS.
+constexpr int LA_MAX_PARTS = 256;
 __global__ void __launch_bounds__(256) la_ctx_combine_frag_kernel(const float* __restrict__ partial, bf16_t* __restrict__ ctxfrag,
                                                                   int nparts, float inv_n) {
-    __shared__ float M[32], Linv[32], cs[32][33];
-    const int tid = threadIdx.x, bh = blockIdx.x;
+    __shared__ float red[8][32], M[32], Linv[32], w_s[LA_MAX_PARTS][32];
+    const int tid = threadIdx.x, bh = blockIdx.x, dd = tid & 31, grp = tid >> 5;
     const float* base = partial + (size_t)bh * nparts * 1088;
+    float mx = -3.0e38f;
+    for (int c = grp; c < nparts; c += 8) mx = fmaxf(mx, base[(size_t)c * 1088 + dd]);
+    red[grp][dd] = mx;
+    __syncthreads();
     if (tid < 32) {
-        float mx = -3.0e38f;
-        for (int c = 0; c < nparts; ++c) mx = fmaxf(mx, base[(size_t)c * 1088 + tid]);
-        float l = 0.0f;
-        for (int c = 0; c < nparts; ++c) l += base[(size_t)c * 1088 + 32 + tid] * __expf(base[(size_t)c * 1088 + tid] - mx);
-        M[tid] = mx;
-        Linv[tid] = 1.0f / l;
+        float m = red[0][tid];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) m = fmaxf(m, red[g][tid]);
+        M[tid] = m;
     }
     __syncthreads();
-    for (int i = tid; i < 1024; i += 256) {
-        const int d = i >> 5, e = i & 31;
-        float a = 0.0f;
-        for (int c = 0; c < nparts; ++c) a += base[(size_t)c * 1088 + 64 + i] * __expf(base[(size_t)c * 1088 + d] - M[d]);
-        cs[d][e] = a * Linv[d] * inv_n;
+    float l = 0.0f;
+    for (int c = grp; c < nparts; c += 8) {
+        const float w = __expf(base[(size_t)c * 1088 + dd] - M[dd]);
+        w_s[c][dd] = w;
+        l += base[(size_t)c * 1088 + 32 + dd] * w;
     }
     __syncthreads();
-    for (int i = tid; i < 1024; i += 256) {
-        const int j = i & 7, lane = (i >> 3) & 63, s2 = i >> 9;
-        const int d = 16 * s2 + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3), e = lane & 31;
-        ctxfrag[(size_t)bh * 1024 + i] = f2bf(cs[d][e]);
+    red[grp][dd] = l;
+    __syncthreads();
+    if (tid < 32) {
+        float t = red[0][tid];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += red[g][tid];
+        Linv[tid] = 1.0f / t;
     }
+    __syncthreads();
+    const int i = blockIdx.y * 256 + tid;
+    const int j = i & 7, lane = (i >> 3) & 63, s2 = i >> 9;
+    const int d = 16 * s2 + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3), e = lane & 31;
+    float a = 0.0f;
+    for (int c = 0; c < nparts; ++c) a += base[(size_t)c * 1088 + 64 + d * 32 + e] * w_s[c][d];
+    ctxfrag[(size_t)bh * 1024 + i] = f2bf(a * Linv[d] * inv_n);
 }
 
 // ---- pass 2 ---------------------------------------------------------------------------------------
@@ -196,13 +227,18 @@ __global__ void __launch_bounds__(256, 2) la_out_fused_kernel(const bf16_t* __re
     __syncthreads();
     const int wave_id = blockIdx.x * 4 + wave, nw = gridDim.x * 4, ntiles = (n + 31) / 32;
 
+    const bf16_t* xb = x + (size_t)b * n * C;
+    XRaw<C> raw_next;
+    load_raw_x<C>(xb + (size_t)min(wave_id * 32 + l31, n - 1) * C, raw_next, half);
     for (int tile = wave_id; tile < ntiles; tile += nw) {
         asm volatile("" ::: "memory");   // keep the LDS weight reads inside the loop (see pass 1)
         const int pix = tile * 32 + l31;
         const int pid = min(pix, n - 1);
-        const bf16_t* xrow = x + ((size_t)b * n + pid) * C;
+        const bf16_t* xrow = xb + (size_t)pid * C;
+        const XRaw<C> raw = raw_next;
+        load_raw_x<C>(xb + (size_t)min((tile + nw) * 32 + l31, n - 1) * C, raw_next, half);
         bf16x8 xs[KS];
-        load_norm_x<C>(xrow, eps_pre, xs, half);
+        norm_x<C>(raw, eps_pre, xs);
         f32x16 acc_o[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -323,7 +359,7 @@ static int launch_la(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const
     }
     const int gx = la_fused_blocks(n);
     la_ctx_fused_kernel<C><<<dim3(gx, B), 256, LDS1, s>>>(x, wkv, partial, n, eps_pre);
-    la_ctx_combine_frag_kernel<<<B * 4, 256, 0, s>>>(partial, ctxfrag, gx * 4, 1.0f / (float)n);
+    la_ctx_combine_frag_kernel<<<dim3(B * 4, 4), 256, 0, s>>>(partial, ctxfrag, gx * 4, 1.0f / (float)n);
     int gx2 = cdiv(cdiv(n, 32), 4 * 4);     // >= 4 tiles per wave amortise the weight staging
     if (gx2 < 1) gx2 = 1;
     if (gx2 > 128) gx2 = 128;

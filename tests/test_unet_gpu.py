@@ -109,7 +109,7 @@ def test_conv3x3_plain_and_ws(L, B, H, W, Cin, Cout):
         # GroupNorm partial sums of the stored values -> per (sample, 8-channel oct) totals
         o = from_nhwc(out)
         tiles = math.ceil(H / 8) * math.ceil(W / 32)
-        p = gn.cpu().reshape(B, tiles, Cout // 8, 2).sum(1)
+        p = gn.cpu().reshape(B, tiles * 4, Cout // 8, 2).sum(1)     # [b][tile][wave][oct][2]
         oc = o.reshape(B, Cout // 8, 8, H, W)
         assert torch.allclose(p[..., 0], oc.sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
         assert torch.allclose(p[..., 1], (oc * oc).sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
