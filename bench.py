@@ -56,9 +56,8 @@ def main():
     ap.add_argument("--dump-launches", default=None, help="CSV path: one row per kernel launch of the timed region")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from opticalflowdiffusion_amd import parallel
+    rank, local_rank, world = parallel.env_rank_world()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -67,7 +66,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        parallel.init("nccl", dev)
 
     from opticalflowdiffusion_amd import Unet, ConditionalDiffusion
 
@@ -75,7 +74,7 @@ def main():
     H = (args.height + 7) // 8 * 8        # 436 -> 440: three 2x down-samplings
     W = (args.width + 7) // 8 * 8
     torch.manual_seed(0)
-    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    g = torch.Generator(device="cpu").manual_seed(parallel.rank_seed(1000, rank))
     unet = Unet(64, channels=5, out_dim=2, precision="bf16").to(dev)
     diff = ConditionalDiffusion(unet, (H, W), objective="pred_x0", channels=2, auto_normalize=False,
                                 noise_space="image", timesteps=1000, min_snr_loss_weight=True).to(dev)
@@ -89,9 +88,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        parallel.barrier(dev)
 
     T = 999
     with torch.no_grad():
@@ -109,13 +106,10 @@ def main():
     unet.set_profiling(False)
     assert torch.isfinite(img).all(), "non-finite samples"
 
-    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed = parallel.max_over_ranks(elapsed, dev)
 
     if rank == 0:
-        steps_per_s = world * args.steps / elapsed
+        steps_per_s = parallel.whole_job_rate(args.steps, world, elapsed)
         line = {
             "metric": "UNet denoise steps/sec @ 2x436x1024 flow, bs=16",
             "value": steps_per_s, "unit": "denoise_steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
