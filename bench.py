@@ -28,7 +28,12 @@ def cpu_baseline(H, W, batch):
     box's host cores on ONE sample of the workload; a batch-16 step is 16x that work."""
     from oracle import unet_ref as R
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
+    # the GPU box gives a one-GPU job a share of 16 host cores (cpu_count() reports the whole machine)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = int(os.environ.get("OFD_CPU_THREADS", min(avail, 16)))
     torch.set_num_threads(cores)
     P = R.closed_form_params(R.unet_param_shapes(64, 5, 2))
     x = torch.randn(1, 2, H, W)

@@ -11,12 +11,13 @@
 //     |displacement| > radius) are appended to a list by the workgroup that owns the SOURCE
 //     pixel and added with global atomics by a second, normally empty, kernel.
 // This file is compiled with -ffp-contract=off: corner indices must be bit-exact.
+#include <cstdlib>
 #include "common.h"
 
 namespace ofd {
 
 struct SplatGeom {
-    int B, C, H, W, Ho, Wo, scale, ox, oy, radius, ntx, nty;
+    int B, C, H, W, Ho, Wo, scale, ox, oy, radius, ntx, nty, dbg;
 };
 
 constexpr int S_TH = 64, S_TW = 64, S_CG = 4, S_NT = 512;
@@ -128,7 +129,12 @@ __global__ void __launch_bounds__(S_NT) splat_tile_kernel(const float* __restric
                 if (lx >= 0 && lx < S_TW && ly >= 0 && ly < S_TH && cx < g.Wo && cy < g.Ho) {
 #pragma unroll
                     for (int c = 0; c < S_CG; ++c)
-                        if (c < cg) atomicAdd(&acc[c][ly][lx], v[c] * w[k]);
+                        if (c < cg) {
+                            // LDS float atomics are the bottleneck (~0.55 lane-atomics/clk/CU measured): skip
+                            // products that are exactly zero (x + 0 == x; NaN/inf inputs are never zero)
+                            const float val = v[c] * w[k];
+                            if (val != 0.0f) atomicAdd(&acc[c][ly][lx], val);
+                        }
                 }
             }
         }
@@ -310,8 +316,88 @@ __device__ __forceinline__ void grid_coords(float flow_c0, float flow_c1, int x,
     iy = ((vy + 1.0f) / 2.0f) * (float)(H - 1);
 }
 
+// One thread = 4 consecutive output pixels: flow and outputs move as 16-byte accesses, and the two
+// corners of a row are ONE 8-byte (4-byte aligned) gather, so 6 gathers per pixel instead of 12.
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+
+template <int CT>   // CT > 0: channel count known at compile time (all gathers of a thread issue back to back)
 __global__ void __launch_bounds__(256) grid_warp_kernel(const float* __restrict__ second, const float* __restrict__ flow,
-                                                        float* __restrict__ out, float* __restrict__ mask, int B, int C, int H, int W) {
+                                                        float* __restrict__ out, float* __restrict__ mask, int B, int C_rt, int H, int W) {
+    const int C = CT > 0 ? CT : C_rt;
+    const size_t plane = (size_t)H * W;
+    const int wq = W / 4;                                   // host guarantees W % 4 == 0 and W >= 2 for this kernel
+    const size_t total = (size_t)B * H * wq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / ((size_t)H * wq);
+        const size_t rem = i % ((size_t)H * wq);
+        const int y = (int)(rem / wq), x4 = (int)(rem % wq) * 4;
+        const size_t pix = (size_t)y * W + x4;
+        const float4 f0 = *(const float4*)(flow + n * 2 * plane + pix);
+        const float4 f1 = *(const float4*)(flow + n * 2 * plane + plane + pix);
+        const float fl0[4] = {f0.x, f0.y, f0.z, f0.w}, fl1[4] = {f1.x, f1.y, f1.z, f1.w};
+        float w[4][4], m[4];
+        unsigned inb[4];
+        int xc[4], yr0[4], yr1[4];
+        bool sel[4][2];        // value of corner column x0 / x0+1 comes from .y of the pair (else .x)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float ix, iy;
+            grid_coords(fl0[j], fl1[j], x4 + j, y, H, W, ix, iy);
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            const bool finite = fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
+            const int x0 = finite ? (int)fx0 : -10, y0 = finite ? (int)fy0 : -10;
+            const float wx0 = fx0 + 1.0f - ix, wx1 = ix - fx0, wy0 = fy0 + 1.0f - iy, wy1 = iy - fy0;
+            const bool bx0 = x0 >= 0 && x0 < W, bx1 = x0 + 1 >= 0 && x0 + 1 < W, by0 = y0 >= 0 && y0 < H, by1 = y0 + 1 >= 0 && y0 + 1 < H;
+            w[j][0] = wx0 * wy0;
+            w[j][1] = wx1 * wy0;
+            w[j][2] = wx0 * wy1;
+            w[j][3] = wx1 * wy1;
+            inb[j] = (bx0 && by0 ? 1u : 0u) | (bx1 && by0 ? 2u : 0u) | (bx0 && by1 ? 4u : 0u) | (bx1 && by1 ? 8u : 0u);
+            float ms = 0.0f;                                   // sum of in-bounds weights = grid_sample(ones)
+            if (bx0 && by0) ms += wx0 * wy0;
+            if (bx1 && by0) ms += wx1 * wy0;
+            if (bx0 && by1) ms += wx0 * wy1;
+            if (bx1 && by1) ms += wx1 * wy1;
+            if (ms < 0.999f) ms = 0.0f;                        // WP:116-117
+            if (ms > 0.0f) ms = 1.0f;
+            m[j] = ms;
+            xc[j] = min(max(x0, 0), W - 2);                    // pair (xc, xc+1) always in bounds
+            sel[j][0] = (x0 != xc[j]);                         // x0 == xc+1  (x0 == W-1)
+            sel[j][1] = (x0 + 1 != xc[j]);                     // x0+1 == xc+1 (normal case); x0+1 == xc when x0 == -1
+            yr0[j] = min(max(y0, 0), H - 1);
+            yr1[j] = min(max(y0 + 1, 0), H - 1);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float* sp = second + (n * C + c) * plane;
+            f32x2u top[4], bot[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                top[j] = *(const f32x2u*)(sp + (size_t)yr0[j] * W + xc[j]);
+                bot[j] = *(const f32x2u*)(sp + (size_t)yr1[j] * W + xc[j]);
+            }
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // only in-bounds corners contribute (zeros padding); ATen's nw, ne, sw, se order
+                float acc = 0.0f;
+                const float t0 = sel[j][0] ? top[j].y : top[j].x, t1 = sel[j][1] ? top[j].y : top[j].x;
+                const float b0 = sel[j][0] ? bot[j].y : bot[j].x, b1 = sel[j][1] ? bot[j].y : bot[j].x;
+                if (inb[j] & 1u) acc += t0 * w[j][0];
+                if (inb[j] & 2u) acc += t1 * w[j][1];
+                if (inb[j] & 4u) acc += b0 * w[j][2];
+                if (inb[j] & 8u) acc += b1 * w[j][3];
+                o[j] = acc;
+            }
+            *(float4*)(out + (n * C + c) * plane + pix) = make_float4(o[0], o[1], o[2], o[3]);
+            if (mask) *(float4*)(mask + (n * C + c) * plane + pix) = make_float4(m[0], m[1], m[2], m[3]);
+        }
+    }
+}
+
+// scalar fallback (W % 4 != 0 or W < 2)
+__global__ void __launch_bounds__(256) grid_warp_scalar_kernel(const float* __restrict__ second, const float* __restrict__ flow,
+                                                               float* __restrict__ out, float* __restrict__ mask, int B, int C, int H, int W) {
     const size_t plane = (size_t)H * W, total = (size_t)B * plane;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t n = i / plane, pix = i % plane;
@@ -319,10 +405,7 @@ __global__ void __launch_bounds__(256) grid_warp_kernel(const float* __restrict_
         float ix, iy;
         grid_coords(flow[n * 2 * plane + pix], flow[n * 2 * plane + plane + pix], x, y, H, W, ix, iy);
         const float fx0 = floorf(ix), fy0 = floorf(iy);
-        const float w_nw = (fx0 + 1.0f - ix) * (fy0 + 1.0f - iy), w_ne = (ix - fx0) * (fy0 + 1.0f - iy);
-        const float w_sw = (fx0 + 1.0f - ix) * (iy - fy0), w_se = (ix - fx0) * (iy - fy0);
-        const float w[4] = {w_nw, w_ne, w_sw, w_se};
-        // NaN / huge coordinates: every corner is out of bounds
+        const float w[4] = {(fx0 + 1.0f - ix) * (fy0 + 1.0f - iy), (ix - fx0) * (fy0 + 1.0f - iy), (fx0 + 1.0f - ix) * (iy - fy0), (ix - fx0) * (iy - fy0)};
         const bool finite = fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
         const int x0 = finite ? (int)fx0 : -10, y0 = finite ? (int)fy0 : -10;
         bool inb[4];
@@ -334,7 +417,7 @@ __global__ void __launch_bounds__(256) grid_warp_kernel(const float* __restrict_
             if (inb[k]) msum += w[k];
         }
         float m = msum;
-        if (m < 0.999f) m = 0.0f;                                   // WP:116-117
+        if (m < 0.999f) m = 0.0f;
         if (m > 0.0f) m = 1.0f;
         for (int c = 0; c < C; ++c) {
             const float* sp = second + (n * C + c) * plane;
@@ -364,7 +447,8 @@ static int make_geom(SplatGeom& g, int B, int C, int H, int W, int scale, int ox
     OFD_CHECK_ARG(scale >= 1 && H / scale > 0 && W / scale > 0, "splat: bad scale %d for %dx%d", scale, H, W);
     OFD_CHECK_ARG(ox >= 0 && oy >= 0 && ox < scale && oy < scale, "splat: offset (%d,%d) must be in [0,scale)", ox, oy);
     OFD_CHECK_ARG((size_t)B * H * W < (1ull << 31), "splat: B*H*W must be < 2^31");
-    g = SplatGeom{B, C, H, W, H / scale, W / scale, scale, ox, oy, radius < 0 ? 0 : radius, 0, 0};
+    g = SplatGeom{B, C, H, W, H / scale, W / scale, scale, ox, oy, radius < 0 ? 0 : radius, 0, 0, 0};
+    { static int d = -1; if (d < 0) { const char* e = getenv("OFD_SPLAT_DBG"); d = e ? atoi(e) : 0; } g.dbg = d; }
     g.ntx = cdiv(g.Wo, S_TW);
     g.nty = cdiv(g.Ho, S_TH);
     return OFD_OK;
@@ -459,7 +543,16 @@ extern "C" int ofd_warp_holes(const float* splat, float* img, int B, int C, int 
 extern "C" int ofd_grid_warp_fwd(const float* second, const float* flow, float* out, float* mask, int B, int C, int H,
                                  int W, void* stream) {
     OFD_CHECK_ARG(second && flow && out && B > 0 && C > 0 && H > 0 && W > 0, "grid_warp_fwd: bad argument");
-    grid_warp_kernel<<<stream_grid((size_t)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(second, flow, out, mask, B, C, H, W);
+    if (W % 4 == 0 && W >= 4) {
+        const int gridn = stream_grid((size_t)B * H * W / 4, 256);
+        hipStream_t s_ = (hipStream_t)stream;
+        if (C == 3) grid_warp_kernel<3><<<gridn, 256, 0, s_>>>(second, flow, out, mask, B, C, H, W);
+        else if (C == 1) grid_warp_kernel<1><<<gridn, 256, 0, s_>>>(second, flow, out, mask, B, C, H, W);
+        else if (C == 2) grid_warp_kernel<2><<<gridn, 256, 0, s_>>>(second, flow, out, mask, B, C, H, W);
+        else grid_warp_kernel<0><<<gridn, 256, 0, s_>>>(second, flow, out, mask, B, C, H, W);
+    }
+    else
+        grid_warp_scalar_kernel<<<stream_grid((size_t)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(second, flow, out, mask, B, C, H, W);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
