@@ -62,7 +62,9 @@ struct Cfg {
     static constexpr int STAGES = (KS == 3) ? 9 : (KS == 7 ? 7 : 1);   // weight slabs per chunk
     static constexpr int KSTEPS = (KS == 7) ? 7 : 4;                    // MFMA k-steps per slab
     static constexpr int SC8 = KSTEPS * 2;                              // 8-channel rows per slab
-    static constexpr int X_BYTES = NPIX * CK * 2;
+    // X tile in LDS is unit-major: [NC channel-octets][NPIX+1 slots][16 B] (see PP_US below)
+    static constexpr int US = (NPIX + 1) * 16;
+    static constexpr int X_BYTES = NC * US;
     static constexpr int W_BYTES = SC8 * BN * 16;
     static constexpr int LDS_BYTES = X_BYTES + 2 * W_BYTES;
     static constexpr int XPT = (NPIX * NC + NTHREADS - 1) / NTHREADS;  // 16-B units per thread
@@ -166,6 +168,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
     const int oy0 = (t_in / P.tiles_x) * TH, ox0 = (t_in % P.tiles_x) * TW;
     const int n0 = blockIdx.y * BN;
 
+    const unsigned char* xrow = lds_x + half * C::US + (wave * 2 * C::IW + l31) * 16;
+
     f32x16 acc[C::NTN][2];
 #pragma unroll
     for (int i = 0; i < C::NTN; ++i)
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             }
             const bool ok = (okmask >> i) & 1u;                 // zero padding stays zero (applied AFTER the prologue)
             v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-            *(uint4*)(lds_x + p * (C::CK * 2) + ((c8 ^ swz<C::CK>(p)) * 16)) = v;
+            *(uint4*)(lds_x + c8 * C::US + p * 16) = v;
         }
         if (kc == 0) {     // slab 0 -> LDS buffer 0; rotate: w1 <- slab 1, w2 <- slab 2
             conv_store_w<KS, BN>(w1, lds_w, tid);
@@ -271,10 +275,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
                 const int unit = (KS == 7) ? half : (ks * 2 + half);
                 bf16x8 xf[2], wf[C::NTN];
 #pragma unroll
-                for (int pt = 0; pt < 2; ++pt) {
-                    const int p = (wave * 2 + pt + ky) * C::IW + l31 + kx;
-                    xf[pt] = *(const bf16x8*)(lds_x + p * (C::CK * 2) + ((unit ^ swz<C::CK>(p)) * 16));
-                }
+                for (int pt = 0; pt < 2; ++pt)   // base + (tap, k-step) offset: no per-read address math
+                    xf[pt] = *(const bf16x8*)(xrow + (pt * C::IW + ky * C::IW + kx) * 16 + (unit - half) * C::US);
 #pragma unroll
                 for (int nt = 0; nt < C::NTN; ++nt)
                     wf[nt] = *(const bf16x8*)(wbuf + ((ks * 2 + half) * BN + nt * 32 + l31) * 16);
@@ -310,10 +312,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
         const int oy = oy0 + wave * 2 + pt, ox = ox0 + l31;
-        const bool ok = oy < P.H && ox < P.W;
-        const size_t pix = ((size_t)b * P.H + oy) * P.W + ox;
+        const bool ok = oy < P.H && ox < P.W && !(dbg & 16);
+        const size_t pix = ((size_t)b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1);   // clamped: loads stay in bounds
 #pragma unroll
         for (int nt = 0; nt < C::NTN; ++nt) {
+            uint2 q[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = n0 + nt * 32 + 8 * g + 4 * half;
@@ -324,32 +327,37 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
                     const float4 bv = *(const float4*)(P.bias + c);
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                 }
-                if (ok && !(dbg & 16)) {
-                    if (P.res_act) {
-                        const uint2 r = *(const uint2*)(P.res_act + pix * P.Cout + c);
-                        const float4 sc = *(const float4*)(P.res_scale + (size_t)b * P.Cout + c);
-                        const float4 sh = *(const float4*)(P.res_shift + (size_t)b * P.Cout + c);
-                        v[0] += silu_f(bf2f((bf16_t)(r.x & 0xffffu)) * sc.x + sh.x);
-                        v[1] += silu_f(bf2f((bf16_t)(r.x >> 16)) * sc.y + sh.y);
-                        v[2] += silu_f(bf2f((bf16_t)(r.y & 0xffffu)) * sc.z + sh.z);
-                        v[3] += silu_f(bf2f((bf16_t)(r.y >> 16)) * sc.w + sh.w);
-                    }
-                    if (P.residual) {
-                        const uint2 r = *(const uint2*)(P.residual + pix * P.Cout + c);
-                        v[0] += bf2f((bf16_t)(r.x & 0xffffu));
-                        v[1] += bf2f((bf16_t)(r.x >> 16));
-                        v[2] += bf2f((bf16_t)(r.y & 0xffffu));
-                        v[3] += bf2f((bf16_t)(r.y >> 16));
-                    }
-                    const uint2 q = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
-                    *(uint2*)(P.out + pix * P.Cout + c) = q;
-                    if (P.gn_partial) {   // statistics of the values as stored (bf16), DD:181
-                        const float q0 = bf2f((bf16_t)(q.x & 0xffffu)), q1 = bf2f((bf16_t)(q.x >> 16));
-                        const float q2 = bf2f((bf16_t)(q.y & 0xffffu)), q3 = bf2f((bf16_t)(q.y >> 16));
-                        stat[(nt * 4 + g) * 2] += (q0 + q1) + (q2 + q3);
-                        stat[(nt * 4 + g) * 2 + 1] += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
-                    }
+                if (P.res_act) {
+                    const uint2 r = *(const uint2*)(P.res_act + pix * P.Cout + c);
+                    const float4 sc = *(const float4*)(P.res_scale + (size_t)b * P.Cout + c);
+                    const float4 sh = *(const float4*)(P.res_shift + (size_t)b * P.Cout + c);
+                    v[0] += silu_f(bf2f((bf16_t)(r.x & 0xffffu)) * sc.x + sh.x);
+                    v[1] += silu_f(bf2f((bf16_t)(r.x >> 16)) * sc.y + sh.y);
+                    v[2] += silu_f(bf2f((bf16_t)(r.y & 0xffffu)) * sc.z + sh.z);
+                    v[3] += silu_f(bf2f((bf16_t)(r.y >> 16)) * sc.w + sh.w);
                 }
+                if (P.residual) {
+                    const uint2 r = *(const uint2*)(P.residual + pix * P.Cout + c);
+                    v[0] += bf2f((bf16_t)(r.x & 0xffffu));
+                    v[1] += bf2f((bf16_t)(r.x >> 16));
+                    v[2] += bf2f((bf16_t)(r.y & 0xffffu));
+                    v[3] += bf2f((bf16_t)(r.y >> 16));
+                }
+                q[g] = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                if (P.gn_partial && ok) {   // statistics of the values as stored (bf16), DD:181
+                    const float q0 = bf2f((bf16_t)(q[g].x & 0xffffu)), q1 = bf2f((bf16_t)(q[g].x >> 16));
+                    const float q2 = bf2f((bf16_t)(q[g].y & 0xffffu)), q3 = bf2f((bf16_t)(q[g].y >> 16));
+                    stat[(nt * 4 + g) * 2] += (q0 + q1) + (q2 + q3);
+                    stat[(nt * 4 + g) * 2 + 1] += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+                }
+            }
+            // 16-byte stores: swap quad g's upper-half data with quad g+1's lower-half data, so the lower
+            // half-wave holds channels 8g..8g+7 and the upper half-wave 8(g+1)..8(g+1)+7 of its pixel
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
+                const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
+                if (ok) *(uint4*)(P.out + pix * P.Cout + n0 + nt * 32 + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
             }
         }
     }
