@@ -126,12 +126,22 @@ def main():
             "unet_mfma_frac_of_peak": steps_per_s / world * B * UNET_GFLOP_PER_SAMPLE * (H * W) / (440 * 1024) / 1e3 / PEAK_BF16_TFLOPS,
         }
         if prof:
-            k = prof["conv3x3_igemm"]
+            name = "conv_igemm_kernel<3,128>"          # dominant kernel: 27 of the 43 3x3 launches, largest total time
+            k = prof[name]
             per_launch_ms = k["ms"] / max(k["launches"], 1)
             achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
-            line["roofline"] = {"kernel": "conv_igemm_kernel<3,*> (3x3 implicit GEMM, 43 launches/step)", "bound": "mfma",
-                                "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                                "traffic": None, "avg_launch_ms": per_launch_ms, "launches": k["launches"]}
+            traffic = None       # HBM bytes per launch from separate rocprofv3 --pmc passes of this command (tools/pmc.sh)
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")
+            if os.path.exists(pmc):
+                e = json.load(open(pmc))["kernels"].get("void ofd::conv_igemm_kernel<3, 128>")
+                if e:
+                    traffic = (e["fetch_MB_per_launch"] + e["write_MB_per_launch"]) * 1e6
+            line["roofline"] = {"kernel": name + " (3x3 implicit GEMM, Cout % 128 == 0)", "bound": "mfma", "achieved": achieved,
+                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                                "algorithmic_flops_per_launch": k["flops"] / max(k["launches"], 1), "avg_launch_ms": per_launch_ms,
+                                "launches": k["launches"]}
+            c3 = [prof[n] for n in ("conv_igemm_kernel<3,128>", "conv_igemm_kernel<3,64>", "conv3x3_c64_pingpong_kernel")]
+            line["conv3x3_all_tflops"] = sum(v["flops"] for v in c3) / (sum(v["ms"] for v in c3) * 1e-3) / 1e12
             line["kernel_ms_per_step"] = {n: v["ms"] / args.steps for n, v in prof.items()}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(H, W, B)

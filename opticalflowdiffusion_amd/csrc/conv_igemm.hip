@@ -599,6 +599,313 @@ __global__ void __launch_bounds__(PP_THREADS, 1) conv3x3_c64_pingpong_kernel(con
     if (group == 1 && n_iter > 0 && prev.valid) pp_epilogue(acc, P, prev, s_bias, wv, lane);
 }
 
+// ================================================================================================
+// Warp-specialised persistent 3x3 kernel (all 3x3 layers except the 64->64 ping-pong case).
+// Workgroup = 8 waves, one per CU: waves 0-3 are CONSUMERS (ds_read + MFMA + epilogue only), waves
+// 4-7 are PRODUCERS (global loads, GroupNorm-affine+SiLU prologue, LDS writes).  A stage is one
+// kernel row (3 taps) of one K-chunk: 48 MFMAs per consumer wave between two workgroup barriers,
+// while the producers fill the other weight buffer (slab q+1, loaded two stages earlier into
+// registers) and, per chunk, the other input-tile buffer.  Raw s_barrier + lgkmcnt only, so the
+// producers' global loads stay in flight across barriers.  The workgroup walks many tiles
+// (persistent, grid = 256 / n-blocks), so the producers run ahead into the next tile while the
+// consumers are in their epilogue.
+//   BN = 64 : K-chunk 64 channels, input tile 43.6 KB x2, weight slab 24 KB x2  (135 KB LDS)
+//   BN = 128: K-chunk 32 channels, input tile 21.8 KB x2, weight slab 24 KB x2  ( 92 KB LDS)
+template <int BN>
+struct WsCfg {
+    static constexpr int CK = (BN == 64) ? 64 : 32;
+    static constexpr int NC = CK / 8;
+    static constexpr int IW = 34, NPIX = 340, US = 341 * 16;
+    static constexpr int XB = NC * US;
+    static constexpr int WROWS = 3 * NC;
+    static constexpr int WB = WROWS * BN * 16;
+    static constexpr int LDS = 2 * XB + 2 * WB;
+    static constexpr int XPT = (NPIX * NC + 255) / 256;
+    static constexpr int WPT = WROWS * BN / 256;
+    static constexpr int NTN = BN / 32;
+    static constexpr int KSTEPS = CK / 16;
+    static_assert(WROWS * BN % 256 == 0, "weight slab must divide over the producer threads");
+};
+
+template <int BN>
+struct WsX {
+    u32x4 v[WsCfg<BN>::XPT];
+    unsigned okmask;
+};
+
+// producer: global -> registers of K-chunk kc (CK-channel units over the concatenated sources)
+template <int BN>
+__device__ __forceinline__ void ws_load_x(WsX<BN>& xr, const ConvParams& P, const PPTile& T, int kc, int gt) {
+    using C = WsCfg<BN>;
+    constexpr int R = 64 / C::CK;          // chunks of this kernel per 64-channel chunk of the descriptors
+    int si = 0, first = 0;
+    while (si + 1 < P.n_src && kc >= first + P.src[si].chunks * R) {
+        first += P.src[si].chunks * R;
+        ++si;
+    }
+    const int kcl = kc - first;
+    const int s_ch = P.src[si].src_channels, s_SH = P.src[si].SH, s_SW = P.src[si].SW, s_mode = P.src[si].mode;
+    const int c8 = gt % C::NC;
+    const bf16_t* base = P.src[si].ptr + (size_t)T.b * s_SH * s_SW * s_ch + P.src[si].ch_offset + kcl * C::CK + c8 * 8;
+    unsigned ok_all = 0;
+#pragma unroll
+    for (int i = 0; i < C::XPT; ++i) {
+        const int p = min(gt / C::NC + i * (256 / C::NC), C::NPIX - 1);
+        const int ty = p / C::IW, tx = p - ty * C::IW;
+        const int iy = T.oy0 - 1 + ty, ix = T.ox0 - 1 + tx;
+        const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+        ok_all |= (ok ? 1u : 0u) << i;
+        const int cy = min(max(iy, 0), P.H - 1), cx = min(max(ix, 0), P.W - 1);
+        int sy = cy, sx = cx;
+        if (s_mode == 1) { sy = cy >> 1; sx = cx >> 1; }
+        else if (s_mode == 2) { sy = 2 * cy + P.src[si].p1; sx = 2 * cx + P.src[si].p2; }
+        xr.v[i] = *(const u32x4*)(base + ((size_t)sy * s_SW + sx) * s_ch);
+    }
+    xr.okmask = ok_all;
+}
+
+template <int BN>
+__device__ __forceinline__ void ws_write_x(const WsX<BN>& xr, const ConvParams& P, const PPTile& T, int kc, unsigned char* xbuf, int gt) {
+    using C = WsCfg<BN>;
+    const int c8 = gt % C::NC;
+    float ps[8], pb[8];
+    if (P.in_scale) {
+        const int cg = kc * C::CK + c8 * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ps[j] = P.in_scale[(size_t)T.b * P.Cin_total + cg + j];
+            pb[j] = P.in_shift[(size_t)T.b * P.Cin_total + cg + j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < C::XPT; ++i) {
+        const int p = min(gt / C::NC + i * (256 / C::NC), C::NPIX - 1);
+        u32x4 v = xr.v[i];
+        if (P.in_scale) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = silu_f(bf2f((bf16_t)(v[j] & 0xffffu)) * ps[2 * j] + pb[2 * j]);
+                const float hi = silu_f(bf2f((bf16_t)(v[j] >> 16)) * ps[2 * j + 1] + pb[2 * j + 1]);
+                v[j] = pack2(lo, hi);
+            }
+        }
+        const bool ok = (xr.okmask >> i) & 1u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
+        *(u32x4*)(xbuf + c8 * C::US + p * 16) = v;
+    }
+}
+
+// weight slab of (chunk kc, kernel row ky): rows r = kx * NC + c8
+template <int BN>
+__device__ __forceinline__ void ws_load_w(U4Arr<WsCfg<BN>::WPT>& w, const ConvParams& P, int n0, int kc, int ky, int gt) {
+    using C = WsCfg<BN>;
+    const int cin8 = P.Cin_total / 8;
+#pragma unroll
+    for (int i = 0; i < C::WPT; ++i) {
+        const int u = gt + i * 256;
+        const int r = u / BN, n = u % BN;
+        const size_t row = (size_t)(ky * 3 + r / C::NC) * cin8 + kc * C::NC + r % C::NC;
+        w.v[i] = *(const u32x4*)(P.weight + (row * P.Cout + n0 + n) * 8);
+    }
+}
+template <int BN>
+__device__ __forceinline__ void ws_store_w(const U4Arr<WsCfg<BN>::WPT>& w, unsigned char* wbuf, int gt) {
+#pragma unroll
+    for (int i = 0; i < WsCfg<BN>::WPT; ++i) *(u32x4*)(wbuf + (gt + i * 256) * 16) = w.v[i];
+}
+
+// consumer: one stage = 3 taps x KSTEPS k-steps, operand reads one k-step ahead of the MFMAs
+template <int BN>
+__device__ __forceinline__ void ws_compute(f32x16 (&acc)[WsCfg<BN>::NTN][2], const unsigned char* wbuf, const unsigned char* xbuf, int ky,
+                                           int wv, int l31, int half) {
+    using C = WsCfg<BN>;
+    constexpr int NS = 3 * C::KSTEPS;
+    const unsigned char* xrow = xbuf + half * C::US + ((wv * 2 + ky) * C::IW + l31) * 16;
+    const unsigned char* wrow = wbuf + (half * BN + l31) * 16;
+    bf16x8 xf[2][2], wf[2][C::NTN];
+    auto read_frags = [&](int step, bf16x8 (&x2)[2], bf16x8 (&w2)[C::NTN]) {
+        const int kx = step / C::KSTEPS, ks = step % C::KSTEPS;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) x2[pt] = *(const bf16x8*)(xrow + (pt * C::IW + kx) * 16 + ks * 2 * C::US);
+#pragma unroll
+        for (int nt = 0; nt < C::NTN; ++nt) w2[nt] = *(const bf16x8*)(wrow + ((kx * C::NC + ks * 2) * BN + nt * 32) * 16);
+    };
+    read_frags(0, xf[0], wf[0]);
+#pragma unroll
+    for (int step = 0; step < NS; ++step) {
+        if (step + 1 < NS) read_frags(step + 1, xf[(step + 1) & 1], wf[(step + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < C::NTN; ++nt)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+                acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[step & 1][nt], xf[step & 1][pt], acc[nt][pt], 0, 0, 0);
+    }
+}
+
+// shared epilogue of a 4-wave x (2 rows x 32 px) x BN tile: bias, residual forms, bf16 16-byte
+// stores through v_permlane32_swap, per-wave GroupNorm partial sums
+template <int BN>
+__device__ __forceinline__ void conv_tile_epilogue(const f32x16 (&acc)[BN / 32][2], const ConvParams& P, const PPTile& T, int n0, int wv, int lane) {
+    constexpr int NTN = BN / 32, NV = (BN / 8) * 2;
+    const int l31 = lane & 31, half = lane >> 5;
+    float stat[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) stat[i] = 0.0f;
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int oy = T.oy0 + wv * 2 + pt, ox = T.ox0 + l31;
+        const bool ok = oy < P.H && ox < P.W;
+        const size_t pix = ((size_t)T.b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1);
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) {
+            uint2 q[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = n0 + nt * 32 + 8 * g + 4 * half;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[nt][pt][4 * g + j];
+                if (P.bias) {
+                    const float4 bv = *(const float4*)(P.bias + c);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if (P.res_act) {
+                    const uint2 r = *(const uint2*)(P.res_act + pix * P.Cout + c);
+                    const float4 sc = *(const float4*)(P.res_scale + (size_t)T.b * P.Cout + c);
+                    const float4 sh = *(const float4*)(P.res_shift + (size_t)T.b * P.Cout + c);
+                    v[0] += silu_f(bf2f((bf16_t)(r.x & 0xffffu)) * sc.x + sh.x);
+                    v[1] += silu_f(bf2f((bf16_t)(r.x >> 16)) * sc.y + sh.y);
+                    v[2] += silu_f(bf2f((bf16_t)(r.y & 0xffffu)) * sc.z + sh.z);
+                    v[3] += silu_f(bf2f((bf16_t)(r.y >> 16)) * sc.w + sh.w);
+                }
+                if (P.residual) {
+                    const uint2 r = *(const uint2*)(P.residual + pix * P.Cout + c);
+                    v[0] += bf2f((bf16_t)(r.x & 0xffffu));
+                    v[1] += bf2f((bf16_t)(r.x >> 16));
+                    v[2] += bf2f((bf16_t)(r.y & 0xffffu));
+                    v[3] += bf2f((bf16_t)(r.y >> 16));
+                }
+                q[g] = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                if (P.gn_partial && ok) {
+                    const float q0 = bf2f((bf16_t)(q[g].x & 0xffffu)), q1 = bf2f((bf16_t)(q[g].x >> 16));
+                    const float q2 = bf2f((bf16_t)(q[g].y & 0xffffu)), q3 = bf2f((bf16_t)(q[g].y >> 16));
+                    stat[(nt * 4 + g) * 2] += (q0 + q1) + (q2 + q3);
+                    stat[(nt * 4 + g) * 2 + 1] += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
+                const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
+                if (ok) *(uint4*)(P.out + pix * P.Cout + n0 + nt * 32 + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            }
+        }
+    }
+    if (P.gn_partial) {
+        wave_reduce_multi<NV>(stat);
+        constexpr int SH_ = (NV == 32) ? 1 : 2;
+        if ((lane & ((1 << SH_) - 1)) == 0) {
+            const size_t base = (((size_t)T.b * (P.tiles_x * P.tiles_y) + T.t_in) * 4 + wv) * (P.Cout / 8) * 2;
+            P.gn_partial[base + (n0 / 8) * 2 + (lane >> SH_)] = stat[0];
+        }
+    }
+}
+
+template <int BN>
+__global__ void __launch_bounds__(512, 1) conv3x3_ws_kernel(const ConvParams P) {
+    using C = WsCfg<BN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xb = smem;                  // [2][XB]
+    unsigned char* wb = smem + 2 * C::XB;      // [2][WB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int role = wave >> 2, wv = wave & 3, gt = tid & 255;
+    const int tpi = P.tiles_x * P.tiles_y, ntiles = tpi * P.B;
+    const int n0 = blockIdx.y * BN;
+    const int n_my = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nchunks = P.total_chunks * (64 / C::CK);
+    const int S = nchunks * 3, Q = n_my * S, CT = n_my * nchunks;     // steps per tile, total steps, total chunks
+    auto tile_at = [&](int i) { return pp_tile((int)blockIdx.x + i * (int)gridDim.x, ntiles, P.tiles_x, tpi); };
+
+    if (role == 1) {
+        // ------------------------------------------------------------------ producers
+        WsX<BN> xr;
+        U4Arr<C::WPT> w1, w2;
+        {
+            const PPTile T0 = tile_at(0);
+            ws_load_x<BN>(xr, P, T0, 0, gt);
+            ws_load_w<BN>(w1, P, n0, 0, 0, gt);
+            ws_write_x<BN>(xr, P, T0, 0, xb, gt);
+            ws_store_w<BN>(w1, wb, gt);
+            const int g1 = (Q > 1) ? 1 : 0, g2 = (Q > 2) ? 2 : 0;
+            ws_load_w<BN>(w1, P, n0, (g1 % S) / 3, g1 % 3, gt);
+            ws_load_w<BN>(w2, P, n0, (g2 % S) / 3, g2 % 3, gt);
+        }
+        pp_barrier();
+        int q = 0, c = 0;
+        for (int i = 0; i < n_my; ++i) {
+            for (int kc = 0; kc < nchunks; ++kc, ++c) {
+                const bool has_next = (c + 1 < CT);
+                const int cn = c + 1, in_ = cn / nchunks, kcn = cn - in_ * nchunks;   // next chunk: tile index, local chunk
+                const PPTile Tn = tile_at(has_next ? in_ : i);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky, ++q) {
+                    if (q + 1 < Q) ws_store_w<BN>(w1, wb + ((q + 1) & 1) * C::WB, gt);   // slab q+1, loaded two stages ago
+                    w1 = w2;
+                    if (q + 3 < Q) {
+                        const int g = (q + 3) % S;
+                        ws_load_w<BN>(w2, P, n0, g / 3, g % 3, gt);
+                    }
+                    if (ky == 0 && has_next) ws_load_x<BN>(xr, P, Tn, kcn, gt);
+                    if (ky == 2 && has_next) ws_write_x<BN>(xr, P, Tn, kcn, xb + (cn & 1) * C::XB, gt);
+                    pp_barrier();
+                }
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ consumers
+        pp_barrier();
+        f32x16 acc[C::NTN][2];
+        int q = 0, c = 0;
+        for (int i = 0; i < n_my; ++i) {
+#pragma unroll
+            for (int a = 0; a < C::NTN; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[a][b2][k] = 0.0f;
+            for (int kc = 0; kc < nchunks; ++kc, ++c) {
+                const unsigned char* xbuf = xb + (c & 1) * C::XB;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky, ++q) {
+                    ws_compute<BN>(acc, wb + (q & 1) * C::WB, xbuf, ky, wv, l31, half);
+                    pp_barrier();
+                }
+            }
+            const PPTile T = tile_at(i);
+            if (T.valid) conv_tile_epilogue<BN>(acc, P, T, n0, wv, lane);
+        }
+    }
+}
+
+template <int BN>
+static int launch_conv_ws(const ConvParams& P, hipStream_t s) {
+    using C = WsCfg<BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OFD_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        attr_set = true;
+    }
+    const int ntiles = P.tiles_x * P.tiles_y * P.B, nb = P.Cout / BN;
+    int gx = 256 / nb;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    conv3x3_ws_kernel<BN><<<dim3(gx, nb), 512, C::LDS, s>>>(P);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
 // ---- weight preparation: OIHW fp32 -> [tap][Cin_pad/8][Cout][8] bf16 (+ weight standardisation)
 __global__ void __launch_bounds__(256) conv_weight_prep_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout,
                                                                int Cin, int Cin_pad, int ksize, float ws_eps, int unshuffle) {
@@ -705,6 +1012,11 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
         OFD_LAUNCH_CHECK();
         return OFD_OK;
     }
+    // warp-specialised variant: measured equal-to-slightly-slower than the generic kernel this round
+    // (DESIGN.md section 4), so it is opt-in for A/B runs: OFD_CONV_WS=1
+    static int use_ws = -1;
+    if (use_ws < 0) { const char* e = getenv("OFD_CONV_WS"); use_ws = (e && atoi(e)) ? 1 : 0; }
+    if (a->ksize == 3 && use_ws) return wide ? launch_conv_ws<128>(P, s) : launch_conv_ws<64>(P, s);
     if (a->ksize == 3) return wide ? launch_conv<3, 128>(P, s) : launch_conv<3, 64>(P, s);
     if (a->ksize == 1) return wide ? launch_conv<1, 128>(P, s) : launch_conv<1, 64>(P, s);
     return launch_conv<7, 64>(P, s);

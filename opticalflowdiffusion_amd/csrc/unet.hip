@@ -31,8 +31,8 @@ struct Tensor {
     int C = 0, H = 0, W = 0;
 };
 
-enum ProfClass { PC_CONV3 = 0, PC_CONV1, PC_CONV7, PC_GN, PC_RESOUT, PC_LN, PC_LINATTN, PC_FLASH, PC_MISC, PC_COUNT };
-static const char* kProfNames[PC_COUNT] = {"conv3x3_igemm", "conv1x1_igemm", "conv7x7_igemm", "gn_finalize", "resblock_out",
+enum ProfClass { PC_CONV3 = 0, PC_CONV3_64, PC_CONV3_PP, PC_CONV1, PC_CONV7, PC_GN, PC_RESOUT, PC_LN, PC_LINATTN, PC_FLASH, PC_MISC, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"conv_igemm_kernel<3,128>", "conv_igemm_kernel<3,64>", "conv3x3_c64_pingpong_kernel", "conv1x1_igemm", "conv7x7_igemm", "gn_finalize", "resblock_out",
                                            "layernorm_c", "linear_attention_core", "flash_attention_d32", "misc"};
 
 struct ProfRec {
@@ -280,7 +280,9 @@ static void conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& 
     const double px = (double)c.B * out.H * out.W;
     const double flops = 2.0 * px * d.Cout * (double)d.Cin * d.ksize * d.ksize;   // counted as the reference executes
     const double bytes = px * 2.0 * (d.Cout + (double)cin / ((srcs[0].upsample) ? 4 : 1)) + (double)d.ksize * d.ksize * d.Cin_pad * d.Cout * 2.0;
-    c.begin(d.ksize == 3 ? PC_CONV3 : (d.ksize == 1 ? PC_CONV1 : PC_CONV7), flops, bytes,
+    const bool pp = d.ksize == 3 && d.Cout == 64 && cin == 64 && srcs.size() == 1 && !srcs[0].upsample && !residual && !res_act;
+    const int cls3 = pp ? PC_CONV3_PP : (d.Cout % 128 == 0 ? PC_CONV3 : PC_CONV3_64);
+    c.begin(d.ksize == 3 ? cls3 : (d.ksize == 1 ? PC_CONV1 : PC_CONV7), flops, bytes,
             prefix + " " + std::to_string(d.Cin) + "->" + std::to_string(d.Cout) + " @" + std::to_string(out.H) + "x" + std::to_string(out.W));
     RUN(conv_forward_impl(&a, c.s));
     c.end();

@@ -1,0 +1,34 @@
+# PMC passes (one counter group per run, --kernel-trace only, as the MI355X guide prescribes)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+  tag=$(echo $grp | cut -d' ' -f1)
+  rm -rf gpurun_out/pmc_$tag
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/pmc_$tag -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > gpurun_out/pmc_$tag.log 2>&1
+  echo "== $grp: $(ls gpurun_out/pmc_$tag/*/ 2>/dev/null | tr '\n' ' ')"
+done
+python - <<'PY'
+import csv, glob, collections
+def load(tag):
+    f=glob.glob(f'gpurun_out/pmc_{tag}/*/*counter_collection.csv')
+    if not f: return {}
+    agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
+    for r in csv.DictReader(open(f[0])):
+        k=r['Kernel_Name'].split('(')[0][:60]
+        agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
+        if r['Counter_Name'] in ('GRBM_GUI_ACTIVE','FETCH_SIZE','WRITE_SIZE'): cnt[k]+=1
+    return agg,cnt
+a,ca=load('SQ_VALU_MFMA_BUSY_CYCLES'); f,cf=load('FETCH_SIZE'); w,cw=load('WRITE_SIZE')
+rows=[]
+for k,v in a.items():
+    gui=v.get('GRBM_GUI_ACTIVE',0)
+    rows.append((gui,k,v))
+rows.sort(reverse=True)
+print(f"{'kernel':60s} {'n':>4s} {'MFMA_BUSY/(GUI/8 *4SIMD*256CU)':>12s} {'fetch MB/launch(x2 corr)':>12s} {'write MB/launch':>12s}")
+for gui,k,v in rows[:14]:
+    n=ca[k] or 1
+    # GRBM_GUI_ACTIVE summed over 8 XCDs -> /8 = cycles; SQ_VALU_MFMA_BUSY_CYCLES summed over all SIMDs? report ratio to (cycles * 1024 SIMDs)
+    util=v.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/max(gui/8*1024,1)
+    fm=f.get(k,{}).get('FETCH_SIZE',0)/max(cf.get(k,1),1)*1024/1e6*2 if f else 0   # KB units, x2 gfx950 correction
+    wm=w.get(k,{}).get('WRITE_SIZE',0)/max(cw.get(k,1),1)*1024/1e6 if w else 0
+    print(f"{k:60s} {n:4d} {util:12.3f} {fm:12.1f} {wm:12.1f}")
+PY
