@@ -97,6 +97,18 @@ int ofd_ddim_update(const float* x_t, const float* model_out, const float* noise
  * result: 2 doubles {sum, count} (device), zeroed by the call. */
 int ofd_nan_mse_sum(const float* pred, const float* target, size_t n, double* result, void* stream);
 
+/* ---------------------------------------------------------------- optimiser (FD:131-134) ---
+ * torch.optim.Adam(lr, weight_decay) semantics (L2 in the gradient) preceded by
+ * clip_grad_norm_(max_norm) (exp_base.py:192,205), multi-tensor, no host synchronisation.
+ * table: device array of {float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+ * uint64 numel}; tasks: device arrays (tensor index, chunk index) with ofd_adam_chunk() elements
+ * per chunk.  sqnorm_acc (1 double), clip_coef (1 float) and optional total_norm are device
+ * scratch/outputs.  step counts from 1.  max_norm <= 0 disables clipping. */
+int ofd_adam_chunk(void);
+int ofd_adam_step(const void* table, const unsigned* task_tensor, const unsigned* task_chunk, int n_tasks,
+                  double* sqnorm_acc, float* clip_coef, float* total_norm, float max_norm, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
 /* ------------------------------------------------------------------------ UNet (DD:272-417) -
  * Handle-based executor of the whole forward: one call runs every kernel of the network on
  * `stream`.  Parameters keep the reference's state-dict names. */

@@ -51,6 +51,8 @@ SIGNATURES = {
     "ofd_ddpm_update": (c_int, [c_void_p] * 8 + [c_int, c_size_t, c_void_p]),
     "ofd_ddim_update": (c_int, [c_void_p] * 8 + [c_int] + [c_void_p] * 2 + [c_int, c_size_t, c_void_p]),
     "ofd_nan_mse_sum": (c_int, [c_void_p] * 2 + [c_size_t, c_void_p, c_void_p]),
+    "ofd_adam_chunk": (c_int, []),
+    "ofd_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_float] * 6 + [c_int, c_void_p]),
     "ofd_unet_create": (c_int, [ctypes.POINTER(UnetConfig), ctypes.POINTER(c_void_p)]),
     "ofd_unet_destroy": (None, [c_void_p]),
     "ofd_unet_num_params": (c_int, [c_void_p]),

@@ -141,7 +141,12 @@ class FlowDiffuser(_Base):
             timesteps=cfg.timesteps, sampling_timesteps=cfg.sampling_timesteps, min_snr_loss_weight=True)
 
     def configure_optimizers(self):                                         # FD:131-134
-        self.optimizers = torch.optim.Adam(self.model.parameters(), lr=self.cfg.lr, weight_decay=self.cfg.weight_decay)
+        """Adam(lr, weight_decay) as the reference; the HIP multi-tensor step (optim.FusedAdam) has
+        torch.optim.Adam's update rule and state-dict keys.  `cfg.clip` (optional) folds the trainer's
+        gradient_clip_val (exp_base.py:205) into the same launches."""
+        from .optim import FusedAdam
+        clip = getattr(self.cfg, "clip", 0.0) if "clip" in self.cfg else 0.0
+        self.optimizers = FusedAdam(self.model.parameters(), lr=self.cfg.lr, weight_decay=self.cfg.weight_decay, max_grad_norm=clip)
         return self.optimizers
 
     def preprocess(self, batch, aug=True):

@@ -120,3 +120,28 @@ def test_large_shapes_properties(B, H, W):
             assert torch.equal(y2.flip(0), y)            # deterministic kernels: bit-identical per sample
         y3 = unet(x, cond, t)
         assert torch.equal(y3, y)                        # run-to-run reproducible (no atomics in the forward)
+
+
+def test_fused_adam_matches_torch_adam_with_clipping():
+    """FD:131-134 optimiser + exp_base.py:205 clipping: same trajectory as
+    clip_grad_norm_ + torch.optim.Adam(weight_decay) over several steps."""
+    from opticalflowdiffusion_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(64, 64, 3, 3), (128,), (300, 257), (1, 64, 1, 1), (70001,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    my_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=1e-3, weight_decay=1e-2)
+    mine = FusedAdam(my_p, lr=1e-3, weight_decay=1e-2, max_grad_norm=5.0)
+    for it in range(4):
+        for a, b in zip(ref_p, my_p):
+            g = torch.randn_like(a) * (3.0 if it % 2 == 0 else 0.01)
+            a.grad = g.clone()
+            b.grad = g.clone()
+        total = torch.nn.utils.clip_grad_norm_(ref_p, 5.0)
+        ref.step()
+        mine.step()
+        assert float(mine.last_grad_norm) == pytest.approx(float(total), rel=1e-5)
+        for a, b in zip(ref_p, my_p):
+            assert rel_l2(b.detach().cpu(), a.detach().cpu()) < 1e-6, it
+    sd = mine.state_dict()
+    assert set(sd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"}
