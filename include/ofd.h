@@ -194,6 +194,23 @@ size_t ofd_conv_weight_elems(int Cout, int Cin_pad, int ksize);
 int ofd_conv_weight_prep(const float* w_oihw, void* w_out, int Cout, int Cin, int Cin_pad, int ksize,
                          float ws_eps, int unshuffle, void* stream);
 
+/* ---------------------------------------------------------------- conv backward (training) --
+ * data gradient  : run ofd_conv_forward on dY (source, Cout channels) with the weights produced by
+ *                  ofd_conv_dgrad_weight_prep (tap-flipped, in/out transposed); output has Cin channels;
+ *                  ofd_grad_scatter applies the adjoint of concat / up-sample (mode 1) / unshuffle (mode 2).
+ * weight gradient: ofd_conv_wgrad accumulates dW[tap][Cin][Cout] (fp32, zeroed by the caller) from the
+ *                  forward's input sources and dY; ofd_conv_wgrad_finish converts to the OIHW parameter
+ *                  gradient, through weight standardisation when ws_eps >= 0 (DD:109-112).
+ * bias gradient  : ofd_channel_sum (out[C] += column sums; zero it first). */
+int ofd_conv_dgrad_weight_prep(const void* w_fwd, void* w_t, int Cout, int Cin, int ksize, void* stream);
+int ofd_conv_wgrad(const ofd_conv_args* fwd, const void* dy, float* dw_acc, void* stream);
+int ofd_conv7_wgrad(const void* x16, const void* dy, float* dw_acc, int B, int H, int W, void* stream);
+int ofd_conv_wgrad_finish(const float* dw_acc, const float* w_oihw, float* dst_oihw, int Cout, int Cin, int Cin_pad,
+                          int ksize, float ws_eps, int unshuffle, int accumulate, void* stream);
+int ofd_grad_scatter(const void* D, int Ctot, int ch_off, void* dst, int C, int B, int H, int W, int mode,
+                     int p1, int p2, int accumulate, void* stream);
+int ofd_channel_sum(const void* dy, float* out, size_t npix, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,12 @@ SIGNATURES = {
     "ofd_conv_forward": (c_int, [ctypes.POINTER(ConvArgs), c_void_p]),
     "ofd_conv_gn_partial_count": (c_size_t, [c_int] * 4),
     "ofd_conv_weight_elems": (c_size_t, [c_int] * 3),
+    "ofd_conv_dgrad_weight_prep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ofd_conv_wgrad": (c_int, [ctypes.POINTER(ConvArgs), c_void_p, c_void_p, c_void_p]),
+    "ofd_conv7_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ofd_conv_wgrad_finish": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_float, c_int, c_int, c_void_p]),
+    "ofd_grad_scatter": (c_int, [c_void_p, c_int, c_int, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "ofd_channel_sum": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ofd_conv_weight_prep": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_float, c_int, c_void_p]),
 }
 

@@ -12,6 +12,15 @@ struct MlpDesc {            // one ResnetBlock's time-embedding Linear (DD:193-1
 };
 
 int conv_forward_impl(const ofd_conv_args* a, hipStream_t s);
+// conv backward (conv_bwd.hip)
+int k_wt_transpose(const bf16_t* w, bf16_t* wt, int taps, int Cin, int Cout, hipStream_t s);
+int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_t s);
+int k_conv7_wgrad(const bf16_t* x16, const bf16_t* dy, float* dw, int B, int H, int W, hipStream_t s);
+int k_channel_sum(const bf16_t* dy, float* out, size_t npix, int C, hipStream_t s);
+int k_wgrad_finish(const float* acc, const float* w_raw, float* dst, int Cout, int Cin, int Cin_pad, int ksize, float ws_eps, int unshuffle,
+                   int accumulate, hipStream_t s);
+int k_grad_scatter(const bf16_t* D, int Ctot, int ch_off, bf16_t* dst, int C, int B, int H, int W, int mode, int p1, int p2, int accumulate,
+                   hipStream_t s);
 
 int k_pack_input(const float* x, int Cx, const float* cond, int Cc, bf16_t* out, int B, int H, int W, hipStream_t s);
 int k_time_mlp(const int64_t* t, const float* w1, const float* b1, const float* w2, const float* b2, float* temb,

@@ -1,0 +1,435 @@
+// Backward of the implicit-GEMM convolutions (what autograd runs for F.conv2d in the reference's
+// training step, flow_diffuser.py:218-235 -> denoising_diffusion.py:823-891):
+//   * data gradient  = the FORWARD kernel (conv_igemm.hip) on dY with tap-flipped, in/out
+//     transposed weights (wt_transpose_kernel); concat / up-sample / unshuffle adjoints are the
+//     grad_scatter kernels (slice, 2x2 sum-pool, pixel shuffle);
+//   * weight gradient = conv_wgrad_kernel: dW[tap][ci][co] = sum_pixels X[p+tap][ci] dY[p][co], an MFMA
+//     GEMM whose contraction index is the PIXEL.  Both operands live pixel-major in LDS (NHWC
+//     rows) and are read with ds_read_b64_tr_b16, the transposing LDS read, so no transposed copy
+//     of any activation is ever written; fp32 partial tiles are added with global atomics once
+//     per workgroup (workgroups walk many pixel tiles);
+//   * wgrad_finish_kernel: layout back to OIHW and the backward of weight standardisation
+//     (denoising_diffusion.py:109-112).
+#include "blocks.h"
+#include "conv_params.h"
+
+namespace ofd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// prepared forward weights [tap][Cin/8][Cout][8]  ->  dgrad weights [T-1-tap][Cout/8][Cin][8]
+__global__ void __launch_bounds__(256) wt_transpose_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wt, int taps, int Cin, int Cout) {
+    const size_t total = (size_t)taps * Cin * Cout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        // i indexes the OUTPUT: [tap'][co8][ci][j]
+        const int j = (int)(i & 7);
+        const size_t r = i >> 3;
+        const int ci = (int)(r % Cin);
+        const size_t r2 = r / Cin;
+        const int co8 = (int)(r2 % (Cout / 8)), tapp = (int)(r2 / (Cout / 8));
+        const int co = co8 * 8 + j, tap = taps - 1 - tapp;
+        wt[i] = w[(((size_t)tap * (Cin / 8) + ci / 8) * Cout + co) * 8 + (ci & 7)];
+    }
+}
+
+struct WgradParams {
+    int B, H, W, Cout, Cin_total, n_src, tiles_x, tiles_y;
+    ConvSrcDev src[4];
+    const bf16_t* dy;
+    float* dw;           // [taps][Cin_total][Cout] fp32, accumulated with atomics (zeroed by the caller)
+};
+
+// two transposing reads = one MFMA operand fragment: 8 consecutive PIXELS (k) of this lane's channel
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base_px0, int row_stride_bytes, int lane) {
+    // lane -> (16-lane group: channel block cb, k half h), (q, p) inside the group
+    const int li = lane & 15, q = li >> 2, p = li & 3, cb = (lane >> 4) & 1, h = lane >> 5;
+    const unsigned char* a = base_px0 + (size_t)(8 * h + q) * row_stride_bytes + (cb * 16 + 4 * p) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 4 * row_stride_bytes));
+    // (whole-vector reinterpretation: per-element bit_casts of the builtin's result are miscompiled by
+    //  hipcc 7.2 into a splat of element 0 -- found with tools/probe/tr_probe2.hip)
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+// grid: (pixel-tile groups, KS kernel rows, (Cin/64)*(Cout/64)); workgroup = 4 waves, wave -> 32 ci x 32 co
+template <int KS>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams P) {
+    constexpr int IWK = 32 + KS - 1, XPIX = 8 * IWK, YPIX = 256;
+    constexpr int XPT = (XPIX * 8 + 255) / 256, YPT = YPIX * 8 / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xs = smem;                  // [XPIX][64 ch] bf16, pixel-major
+    unsigned char* ys = smem + XPIX * 128;     // [YPIX][64 co]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int ky = blockIdx.y, ncob = P.Cout / 64, kc = blockIdx.z / ncob, cob = blockIdx.z % ncob;
+    const int cit = wave & 1, cot = wave >> 1;
+    const int tpi = P.tiles_x * P.tiles_y, ntiles = tpi * P.B;
+    int si = 0, first = 0;
+    while (si + 1 < P.n_src && kc >= first + P.src[si].chunks) { first += P.src[si].chunks; ++si; }
+    const int kcl = kc - first;
+    const ConvSrcDev S = P.src[si];
+    const int c8 = tid & 7;
+
+    f32x16 acc[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int b = t / tpi, t_in = t - b * tpi;
+        const int oy0 = (t_in / P.tiles_x) * 8, ox0 = (t_in % P.tiles_x) * 32;
+        u32x4 xr[XPT], yr[YPT];
+        unsigned xok = 0, yok = 0;
+        const bf16_t* xbase = S.ptr + (size_t)b * S.SH * S.SW * S.src_channels + S.ch_offset + kcl * 64 + c8 * 8;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int p = min((tid >> 3) + i * 32, XPIX - 1);
+            const int ty = p / IWK, tx = p - ty * IWK;
+            const int iy = oy0 + ty + ky - KS / 2, ix = ox0 + tx - KS / 2;
+            const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+            xok |= (ok ? 1u : 0u) << i;
+            const int cy = min(max(iy, 0), P.H - 1), cx = min(max(ix, 0), P.W - 1);
+            int sy = cy, sx = cx;
+            if (S.mode == 1) { sy = cy >> 1; sx = cx >> 1; }
+            else if (S.mode == 2) { sy = 2 * cy + S.p1; sx = 2 * cx + S.p2; }
+            xr[i] = *(const u32x4*)(xbase + ((size_t)sy * S.SW + sx) * S.src_channels);
+        }
+#pragma unroll
+        for (int i = 0; i < YPT; ++i) {
+            const int p = (tid >> 3) + i * 32;
+            const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
+            const bool ok = oy < P.H && ox < P.W;
+            yok |= (ok ? 1u : 0u) << i;
+            yr[i] = *(const u32x4*)(P.dy + (((size_t)b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1)) * P.Cout + cob * 64 + c8 * 8);
+        }
+        __syncthreads();     // previous tile's operand reads are complete
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int p = min((tid >> 3) + i * 32, XPIX - 1);
+            u32x4 v = xr[i];
+            const bool ok = (xok >> i) & 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
+            *(u32x4*)(xs + p * 128 + c8 * 16) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < YPT; ++i) {
+            const int p = (tid >> 3) + i * 32;
+            u32x4 v = yr[i];
+            const bool ok = (yok >> i) & 1u;      // pixels of the tile overhang contribute nothing
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
+            *(u32x4*)(ys + p * 128 + c8 * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb) {
+                const bf16x8 yf = tr_frag(ys + ((r * 32 + xb * 16) * 64 + cot * 32) * 2, 128, lane);
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const bf16x8 xf = tr_frag(xs + ((r * IWK + xb * 16 + kx) * 64 + cit * 32) * 2, 128, lane);
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yf, acc[kx], 0, 0, 0);   // rows = ci, cols = co
+                }
+            }
+    }
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+        const int tap = ky * KS + kx;
+        float* d = P.dw + ((size_t)tap * P.Cin_total + kc * 64 + cit * 32) * P.Cout + cob * 64 + cot * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
+            atomicAdd(d + (size_t)ci * P.Cout, acc[kx][r]);
+        }
+    }
+}
+
+// 7x7 init conv (Cin padded to 16, Cout = 64): dW[tap][ci<16][co], VALU: one thread per (tap, co) pair
+// walks the pixels of its slice, 16 accumulators (ci); 226 GFLOP at the benchmark size.
+__global__ void __launch_bounds__(256) conv7_wgrad_kernel(const bf16_t* __restrict__ x16, const bf16_t* __restrict__ dy, float* __restrict__ dw,
+                                                          int B, int H, int W, int rows_per_block) {
+    // grid: (49 taps, row slices); block: 64 co x 4 column phases
+    const int tap = blockIdx.x, ky = tap / 7, kx = tap % 7, co = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+    const long total_rows = (long)B * H;
+    const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(total_rows, r0 + rows_per_block);
+    for (long row = r0; row < r1; ++row) {
+        const int b = (int)(row / H), y = (int)(row % H);
+        const int iy = y + ky - 3;
+        if (iy < 0 || iy >= H) continue;
+        for (int x = ph; x < W; x += 4) {
+            const int ix = x + kx - 3;
+            if (ix < 0 || ix >= W) continue;
+            const float g = bf2f(dy[(((size_t)b * H + y) * W + x) * 64 + co]);
+            const uint4* xp = (const uint4*)(x16 + (((size_t)b * H + iy) * W + ix) * 16);
+            const uint4 lo = xp[0], hi = xp[1];
+            const uint32_t w8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[2 * j] += g * bf2f((bf16_t)(w8[j] & 0xffffu));
+                acc[2 * j + 1] += g * bf2f((bf16_t)(w8[j] >> 16));
+            }
+        }
+    }
+    __shared__ float red[4][16][64];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) red[ph][c][co] = acc[c];
+    __syncthreads();
+    if (ph == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            atomicAdd(dw + ((size_t)tap * 16 + c) * 64 + co, (red[0][c][co] + red[1][c][co]) + (red[2][c][co] + red[3][c][co]));
+    }
+}
+
+// dY [npix][C] bf16 -> out[C] += column sums (bias gradients)
+__global__ void __launch_bounds__(256) channel_sum_kernel(const bf16_t* __restrict__ dy, float* __restrict__ out, size_t npix, int C, int pix_per_block) {
+    __shared__ float red[256][9];
+    const int c8n = C / 8, tid = threadIdx.x;
+    const size_t p0 = (size_t)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+    for (int cu = 0; cu < c8n; cu += 256) {       // (C <= 2048)
+        const int lanes_c = min(c8n - cu, 256);    // threads covering different channel octets
+        const int rows = 256 / lanes_c;            // pixel phases
+        const int my_c = tid % lanes_c, my_r = tid / lanes_c;
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (my_r < rows)
+            for (size_t p = p0 + my_r; p < p1; p += rows) {
+                const uint4 v = *(const uint4*)(dy + p * C + (cu + my_c) * 8);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[2 * j] += bf2f((bf16_t)(w[j] & 0xffffu));
+                    a[2 * j + 1] += bf2f((bf16_t)(w[j] >> 16));
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid][j] = a[j];
+        __syncthreads();
+        if (tid < lanes_c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float s = 0.0f;
+                for (int r = 0; r < rows; ++r) s += red[r * lanes_c + tid][j];
+                atomicAdd(out + (cu + tid) * 8 + j, s);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dW accumulator [tap][Cin_pad (engine channel order)][Cout] -> gradient of the fp32 OIHW parameter,
+// through weight standardisation when ws_eps >= 0 (DD:109-112):
+//   w^ = (w - mean) * rstd ;  dw = rstd * (g - mean(g) - w^ * mean(g * w^))
+// one workgroup per output channel; accumulate != 0 adds to dst
+__global__ void __launch_bounds__(256) wgrad_finish_kernel(const float* __restrict__ acc, const float* __restrict__ w_raw, float* __restrict__ dst,
+                                                           int Cout, int Cin, int Cin_pad, int ksize, float ws_eps, int unshuffle, int accumulate) {
+    const int o = blockIdx.x, tid = threadIdx.x, taps = ksize * ksize, n = Cin * taps;
+    __shared__ double sh[256];
+    auto block_sum = [&](double v) {
+        sh[tid] = v;
+        __syncthreads();
+        for (int k = 128; k > 0; k >>= 1) { if (tid < k) sh[tid] += sh[tid + k]; __syncthreads(); }
+        const double r = sh[0];
+        __syncthreads();
+        return r;
+    };
+    auto gval = [&](int i) {          // i over the reference's (ci, tap) order
+        const int ci = i / taps, tap = i % taps;
+        int cp = ci;
+        if (unshuffle) { const int Cq = Cin / 4; cp = (ci & 3) * Cq + (ci >> 2); }   // reference c*4+sub -> engine sub*Cq+c
+        return acc[((size_t)tap * Cin_pad + cp) * Cout + o];
+    };
+    const float* wo = w_raw + (size_t)o * n;
+    float mean = 0.0f, rstd = 1.0f, mg = 0.0f, mgw = 0.0f;
+    if (ws_eps >= 0.0f) {
+        double s = 0.0;
+        for (int i = tid; i < n; i += 256) s += (double)wo[i];
+        const double m = block_sum(s) / n;
+        double v = 0.0;
+        for (int i = tid; i < n; i += 256) { const double d = (double)wo[i] - m; v += d * d; }
+        const double var = block_sum(v) / n;
+        mean = (float)m;
+        rstd = rsqrtf((float)var + ws_eps);
+        double a = 0.0, b2 = 0.0;
+        for (int i = tid; i < n; i += 256) {
+            const double g = (double)gval(i);
+            a += g;
+            b2 += g * (double)((wo[i] - mean) * rstd);
+        }
+        mg = (float)(block_sum(a) / n);
+        mgw = (float)(block_sum(b2) / n);
+    }
+    for (int i = tid; i < n; i += 256) {
+        float g = gval(i);
+        if (ws_eps >= 0.0f) g = rstd * (g - mg - (wo[i] - mean) * rstd * mgw);
+        float* d = dst + (size_t)o * n + i;
+        *d = accumulate ? (*d + g) : g;
+    }
+}
+
+// adjoint of the loader's source modes: D [B][H][W][Ctot] (dgrad output) -> gradient of one source
+__global__ void __launch_bounds__(256) grad_scatter_kernel(const bf16_t* __restrict__ D, int Ctot, int ch_off, bf16_t* __restrict__ dst, int C,
+                                                           int B, int H, int W, int mode, int p1, int p2, int accumulate) {
+    // mode 0: same size; 1: dst is (H/2, W/2), sum over the 2x2 block; 2: dst is (2H, 2W), writes sub-pixel (p1, p2)
+    const int c8n = C / 8;
+    const int DH = mode == 1 ? H / 2 : H, DW_ = mode == 1 ? W / 2 : W;     // iteration space
+    const size_t total = (size_t)B * DH * DW_ * c8n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cu = (int)(i % c8n);
+        size_t r = i / c8n;
+        const int x = (int)(r % DW_);
+        r /= DW_;
+        const int y = (int)(r % DH), b = (int)(r / DH);
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int reps = mode == 1 ? 4 : 1;
+        for (int k = 0; k < reps; ++k) {
+            const int sy = mode == 1 ? 2 * y + (k >> 1) : y, sx = mode == 1 ? 2 * x + (k & 1) : x;
+            const uint4 v = *(const uint4*)(D + (((size_t)b * H + sy) * W + sx) * Ctot + ch_off + cu * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[2 * j] += bf2f((bf16_t)(w[j] & 0xffffu));
+                a[2 * j + 1] += bf2f((bf16_t)(w[j] >> 16));
+            }
+        }
+        size_t dpix;
+        if (mode == 2) dpix = ((size_t)b * (2 * H) + 2 * y + p1) * (2 * W) + 2 * x + p2;
+        else dpix = ((size_t)b * DH + y) * DW_ + x;
+        bf16_t* d = dst + dpix * C + cu * 8;
+        if (accumulate) {
+            const uint4 o = *(const uint4*)d;
+            const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[2 * j] += bf2f((bf16_t)(w[j] & 0xffffu));
+                a[2 * j + 1] += bf2f((bf16_t)(w[j] >> 16));
+            }
+        }
+        *(uint4*)d = make_uint4(f2bf2(a[0], a[1]), f2bf2(a[2], a[3]), f2bf2(a[4], a[5]), f2bf2(a[6], a[7]));
+    }
+}
+
+static inline int sgrid_b(size_t total, int block = 256, int cap = 4096) {
+    size_t b = (total + block - 1) / block;
+    return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
+}
+
+int k_wt_transpose(const bf16_t* w, bf16_t* wt, int taps, int Cin, int Cout, hipStream_t s) {
+    wt_transpose_kernel<<<sgrid_b((size_t)taps * Cin * Cout), 256, 0, s>>>(w, wt, taps, Cin, Cout);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+// dw (fp32 [taps][Cin_total][Cout]) must be zeroed by the caller; x sources as in the forward conv
+int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_t s) {
+    OFD_CHECK_ARG(a && dy && dw, "conv_wgrad: null argument");
+    OFD_CHECK_ARG(a->ksize == 1 || a->ksize == 3, "conv_wgrad: ksize %d (7x7 has its own kernel)", a->ksize);
+    OFD_CHECK_ARG(a->Cout % 64 == 0 && a->n_src >= 1 && a->n_src <= 4, "conv_wgrad: bad configuration");
+    WgradParams P{};
+    P.B = a->B; P.H = a->H; P.W = a->W; P.Cout = a->Cout; P.n_src = a->n_src;
+    P.tiles_x = cdiv(a->W, 32); P.tiles_y = cdiv(a->H, 8);
+    int cin = 0;
+    for (int i = 0; i < a->n_src; ++i) {
+        const ofd_conv_src& s_ = a->src[i];
+        OFD_CHECK_ARG(s_.src && s_.channels % 64 == 0, "conv_wgrad: source %d channels", i);
+        ConvSrcDev& d = P.src[i];
+        d.ptr = (const bf16_t*)s_.src; d.chunks = s_.channels / 64; d.src_channels = s_.src_channels; d.ch_offset = s_.ch_offset;
+        d.mode = s_.upsample ? 1 : (s_.unshuffle ? 2 : 0);
+        d.SH = s_.upsample ? a->H / 2 : (s_.unshuffle ? a->H * 2 : a->H);
+        d.SW = s_.upsample ? a->W / 2 : (s_.unshuffle ? a->W * 2 : a->W);
+        d.p1 = s_.p1; d.p2 = s_.p2;
+        cin += s_.channels;
+    }
+    P.Cin_total = cin; P.dy = dy; P.dw = dw;
+    const int ntiles = P.tiles_x * P.tiles_y * P.B, combos = (cin / 64) * (a->Cout / 64);
+    int gx = cdiv(1024, combos * a->ksize);     // ~4 workgroups per CU in total; each walks ntiles / gx pixel tiles
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    OFD_CHECK_ARG(combos <= 65535, "conv_wgrad: too many channel blocks");
+    if (a->ksize == 3) {
+        constexpr int LDS = 8 * 34 * 128 + 256 * 128;
+        static bool attr = false;
+        if (!attr) { OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+        conv_wgrad_kernel<3><<<dim3(gx, 3, combos), 256, LDS, s>>>(P);
+    } else {
+        constexpr int LDS = 8 * 32 * 128 + 256 * 128;
+        static bool attr = false;
+        if (!attr) { OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+        conv_wgrad_kernel<1><<<dim3(gx, 1, combos), 256, LDS, s>>>(P);
+    }
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+int k_conv7_wgrad(const bf16_t* x16, const bf16_t* dy, float* dw, int B, int H, int W, hipStream_t s) {
+    const long rows = (long)B * H;
+    int slices = (int)((rows + 15) / 16);
+    if (slices > 64) slices = 64;
+    const int rpb = (int)((rows + slices - 1) / slices);
+    conv7_wgrad_kernel<<<dim3(49, slices), 256, 0, s>>>(x16, dy, dw, B, H, W, rpb);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+int k_channel_sum(const bf16_t* dy, float* out, size_t npix, int C, hipStream_t s) {
+    OFD_CHECK_ARG(C % 8 == 0 && C <= 2048, "channel_sum: C=%d", C);
+    const int ppb = 2048;
+    channel_sum_kernel<<<(unsigned)((npix + ppb - 1) / ppb), 256, 0, s>>>(dy, out, npix, C, ppb);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+int k_wgrad_finish(const float* acc, const float* w_raw, float* dst, int Cout, int Cin, int Cin_pad, int ksize, float ws_eps, int unshuffle,
+                   int accumulate, hipStream_t s) {
+    wgrad_finish_kernel<<<Cout, 256, 0, s>>>(acc, w_raw, dst, Cout, Cin, Cin_pad, ksize, ws_eps, unshuffle, accumulate);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+int k_grad_scatter(const bf16_t* D, int Ctot, int ch_off, bf16_t* dst, int C, int B, int H, int W, int mode, int p1, int p2, int accumulate,
+                   hipStream_t s) {
+    OFD_CHECK_ARG(C % 8 == 0 && ch_off % 8 == 0, "grad_scatter: channel window");
+    const size_t total = (size_t)B * (mode == 1 ? H / 2 : H) * (mode == 1 ? W / 2 : W) * (C / 8);
+    grad_scatter_kernel<<<sgrid_b(total), 256, 0, s>>>(D, Ctot, ch_off, dst, C, B, H, W, mode, p1, p2, accumulate);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+}  // namespace ofd
+
+using namespace ofd;
+
+extern "C" int ofd_conv_dgrad_weight_prep(const void* w_fwd, void* w_t, int Cout, int Cin, int ksize, void* stream) {
+    OFD_CHECK_ARG(w_fwd && w_t && Cout % 8 == 0 && Cin % 8 == 0, "dgrad_weight_prep: bad argument");
+    return k_wt_transpose((const bf16_t*)w_fwd, (bf16_t*)w_t, ksize * ksize, Cin, Cout, (hipStream_t)stream);
+}
+extern "C" int ofd_conv_wgrad(const ofd_conv_args* fwd, const void* dy, float* dw_acc, void* stream) {
+    return k_conv_wgrad(fwd, (const bf16_t*)dy, dw_acc, (hipStream_t)stream);
+}
+extern "C" int ofd_conv7_wgrad(const void* x16, const void* dy, float* dw_acc, int B, int H, int W, void* stream) {
+    OFD_CHECK_ARG(x16 && dy && dw_acc, "conv7_wgrad: null argument");
+    return k_conv7_wgrad((const bf16_t*)x16, (const bf16_t*)dy, dw_acc, B, H, W, (hipStream_t)stream);
+}
+extern "C" int ofd_conv_wgrad_finish(const float* dw_acc, const float* w_oihw, float* dst_oihw, int Cout, int Cin, int Cin_pad, int ksize,
+                                     float ws_eps, int unshuffle, int accumulate, void* stream) {
+    OFD_CHECK_ARG(dw_acc && w_oihw && dst_oihw, "wgrad_finish: null argument");
+    return k_wgrad_finish(dw_acc, w_oihw, dst_oihw, Cout, Cin, Cin_pad, ksize, ws_eps, unshuffle, accumulate, (hipStream_t)stream);
+}
+extern "C" int ofd_grad_scatter(const void* D, int Ctot, int ch_off, void* dst, int C, int B, int H, int W, int mode, int p1, int p2,
+                                int accumulate, void* stream) {
+    OFD_CHECK_ARG(D && dst, "grad_scatter: null argument");
+    return k_grad_scatter((const bf16_t*)D, Ctot, ch_off, (bf16_t*)dst, C, B, H, W, mode, p1, p2, accumulate, (hipStream_t)stream);
+}
+extern "C" int ofd_channel_sum(const void* dy, float* out, size_t npix, int C, void* stream) {
+    OFD_CHECK_ARG(dy && out, "channel_sum: null argument");
+    return k_channel_sum((const bf16_t*)dy, out, npix, C, (hipStream_t)stream);
+}

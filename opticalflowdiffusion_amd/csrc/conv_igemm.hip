@@ -19,6 +19,7 @@
 // channels of one pixel -> 8-byte NHWC stores.
 #include <cstdlib>
 #include "common.h"
+#include "conv_params.h"
 
 namespace ofd {
 
@@ -26,32 +27,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int TH = 8, TW = 32, NTHREADS = 256;
-
-struct ConvSrcDev {
-    const bf16_t* ptr;
-    int chunks;         // K-chunks (of CK channels) taken from this source
-    int src_channels;   // pixel stride of the source tensor
-    int ch_offset;
-    int SH, SW;         // source spatial size
-    int mode;           // 0: same size, 1: nearest x2 up-sample, 2: pixel-unshuffle sub-pixel (p1,p2)
-    int p1, p2;
-};
-
-struct ConvParams {
-    int B, H, W, Cout, Cin_total, n_src, total_chunks, tiles_x, tiles_y;
-    ConvSrcDev src[4];
-    const bf16_t* weight;
-    const float* bias;
-    const float* in_scale;
-    const float* in_shift;
-    const bf16_t* residual;
-    const bf16_t* res_act;
-    const float* res_scale;
-    const float* res_shift;
-    bf16_t* out;
-    float* gn_partial;
-    int dbg;            // diagnostic ablation bits (OFD_CONV_DBG), 0 in production
-};
 
 template <int KS, int BN>
 struct Cfg {

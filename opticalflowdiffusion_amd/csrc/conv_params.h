@@ -1,0 +1,33 @@
+// Device-side descriptors shared by the forward (conv_igemm.hip) and backward (conv_bwd.hip) conv kernels.
+#pragma once
+#include "common.h"
+
+namespace ofd {
+
+struct ConvSrcDev {
+    const bf16_t* ptr;
+    int chunks;         // K-chunks (of CK channels) taken from this source
+    int src_channels;   // pixel stride of the source tensor
+    int ch_offset;
+    int SH, SW;         // source spatial size
+    int mode;           // 0: same size, 1: nearest x2 up-sample, 2: pixel-unshuffle sub-pixel (p1,p2)
+    int p1, p2;
+};
+
+struct ConvParams {
+    int B, H, W, Cout, Cin_total, n_src, total_chunks, tiles_x, tiles_y;
+    ConvSrcDev src[4];
+    const bf16_t* weight;
+    const float* bias;
+    const float* in_scale;
+    const float* in_shift;
+    const bf16_t* residual;
+    const bf16_t* res_act;
+    const float* res_scale;
+    const float* res_shift;
+    bf16_t* out;
+    float* gn_partial;
+    int dbg;            // diagnostic ablation bits (OFD_CONV_DBG), 0 in production
+};
+
+}  // namespace ofd

@@ -1,0 +1,143 @@
+"""GPU parity of the training-path backward kernels against torch autograd on the CPU oracle ops
+(the reference's backward IS autograd over these ops: FD:218-235 -> DD:823-891).
+Gradients flow as bf16 between kernels (as under autocast); tolerance rel-L2 <= 1e-2 per tensor."""
+import ctypes
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from oracle import unet_ref as R
+from test_unet_gpu import q, to_nhwc, from_nhwc, prep_weight, run_conv
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-2
+
+
+@pytest.fixture(scope="module")
+def L():
+    from opticalflowdiffusion_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def conv_args(L, B, H, W, ksize, srcs, Cout):
+    a = L.ConvArgs()
+    a.B, a.H, a.W, a.ksize, a.n_src, a.Cout = B, H, W, ksize, len(srcs), Cout
+    for i, s in enumerate(srcs):
+        t = s["t"]
+        a.src[i].src = t.data_ptr()
+        a.src[i].channels = t.shape[-1]
+        a.src[i].src_channels = t.shape[-1]
+        a.src[i].upsample = s.get("upsample", 0)
+        a.src[i].unshuffle = s.get("unshuffle", 0)
+        a.src[i].p1, a.src[i].p2 = s.get("p1", 0), s.get("p2", 0)
+    return a
+
+
+def wgrad(L, B, H, W, ksize, srcs, Cout, dy_nhwc, w_raw, ws_eps=-1.0, unshuffle=0):
+    a = conv_args(L, B, H, W, ksize, srcs, Cout)
+    cin = sum(s["t"].shape[-1] for s in srcs)
+    acc = torch.zeros(ksize * ksize * cin * Cout, device="cuda")
+    L.check(L.lib().ofd_conv_wgrad(ctypes.byref(a), L.ptr(dy_nhwc), L.ptr(acc), L.stream()))
+    dst = torch.empty(Cout, cin, ksize, ksize, device="cuda")
+    wr = w_raw.contiguous().cuda()
+    L.check(L.lib().ofd_conv_wgrad_finish(L.ptr(acc), L.ptr(wr), L.ptr(dst), Cout, cin, cin, ksize, ws_eps, unshuffle, 0, L.stream()))
+    torch.cuda.synchronize()
+    return dst.cpu()
+
+
+def dgrad(L, B, H, W, ksize, w_prepped, Cin, Cout, dy_nhwc):
+    wt = torch.empty_like(w_prepped)
+    L.check(L.lib().ofd_conv_dgrad_weight_prep(L.ptr(w_prepped), L.ptr(wt), Cout, Cin, ksize, L.stream()))
+    out, _ = run_conv(L, B, H, W, ksize, [dict(t=dy_nhwc)], Cin, wt)
+    return out
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 32, 64, 64), (2, 13, 40, 128, 64), (1, 16, 64, 192, 128)])
+def test_conv3x3_backward(L, B, H, W, Cin, Cout):
+    torch.manual_seed(0)
+    x = q(torch.randn(B, Cin, H, W)).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)).requires_grad_(True)
+    dy = q(torch.randn(B, Cout, H, W))
+    for eps in (-1.0, 1e-5):
+        x.grad = w.grad = None
+        wq = w if eps < 0 else R.standardize_weight(w, eps)
+        wq = wq + (q(wq) - wq).detach()                    # straight-through bf16 rounding of the weights
+        F.conv2d(x, wq, None, padding=1).backward(dy)
+        got_w = wgrad(L, B, H, W, 3, [dict(t=to_nhwc(x.detach()))], Cout, to_nhwc(dy), w.detach(), eps)
+        assert rel_l2(got_w, w.grad) < TOL, f"wgrad eps={eps}: {rel_l2(got_w, w.grad):.3e}"
+        got_x = from_nhwc(dgrad(L, B, H, W, 3, prep_weight(L, w.detach(), 3, eps), Cin, Cout, to_nhwc(dy)))
+        assert rel_l2(got_x, x.grad) < TOL, f"dgrad eps={eps}: {rel_l2(got_x, x.grad):.3e}"
+    # bias gradient
+    out = torch.zeros(Cout, device="cuda")
+    dyd = to_nhwc(dy)
+    L.check(L.lib().ofd_channel_sum(L.ptr(dyd), L.ptr(out), B * H * W, Cout, L.stream()))
+    assert rel_l2(out.cpu(), dy.sum(dim=(0, 2, 3))) < 1e-3
+
+
+def test_conv_backward_source_modes(L):
+    """concat, nearest-x2 up-sampling and pixel-unshuffle loaders: weight gradients through the same
+    loaders, data gradients through grad_scatter (slice / 2x2 sum / pixel shuffle)."""
+    torch.manual_seed(1)
+    B, H, W = 2, 16, 32
+    # concat of two sources, 1x1
+    x1 = q(torch.randn(B, 128, H, W)).requires_grad_(True)
+    x2 = q(torch.randn(B, 64, H, W)).requires_grad_(True)
+    w = (torch.randn(128, 192, 1, 1) / math.sqrt(192)).requires_grad_(True)
+    dy = q(torch.randn(B, 128, H, W))
+    F.conv2d(torch.cat((x1, x2), 1), w + (q(w) - w).detach()).backward(dy)
+    got_w = wgrad(L, B, H, W, 1, [dict(t=to_nhwc(x1.detach())), dict(t=to_nhwc(x2.detach()))], 128, to_nhwc(dy), w.detach())
+    assert rel_l2(got_w, w.grad) < TOL
+    D = dgrad(L, B, H, W, 1, prep_weight(L, w.detach(), 1), 192, 128, to_nhwc(dy))
+    g1 = torch.empty(B, H, W, 128, dtype=torch.bfloat16, device="cuda")
+    g2 = torch.full((B, H, W, 64), 1.0, dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().ofd_grad_scatter(L.ptr(D), 192, 0, L.ptr(g1), 128, B, H, W, 0, 0, 0, 0, L.stream()))
+    L.check(L.lib().ofd_grad_scatter(L.ptr(D), 192, 128, L.ptr(g2), 64, B, H, W, 0, 0, 0, 1, L.stream()))     # accumulate onto ones
+    assert rel_l2(from_nhwc(g1), x1.grad) < TOL and rel_l2(from_nhwc(g2) - 1.0, x2.grad) < 2e-2
+    # up-sampled source, 3x3 (DD:89-93)
+    xs = q(torch.randn(B, 128, H // 2, W // 2)).requires_grad_(True)
+    w = (torch.randn(64, 128, 3, 3) / math.sqrt(128 * 9)).requires_grad_(True)
+    dy = q(torch.randn(B, 64, H, W))
+    F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w + (q(w) - w).detach(), padding=1).backward(dy)
+    got_w = wgrad(L, B, H, W, 3, [dict(t=to_nhwc(xs.detach()), upsample=1)], 64, to_nhwc(dy), w.detach())
+    assert rel_l2(got_w, w.grad) < TOL
+    D = dgrad(L, B, H, W, 3, prep_weight(L, w.detach(), 3), 128, 64, to_nhwc(dy))
+    gs = torch.empty(B, H // 2, W // 2, 128, dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().ofd_grad_scatter(L.ptr(D), 128, 0, L.ptr(gs), 128, B, H, W, 1, 0, 0, 0, L.stream()))
+    assert rel_l2(from_nhwc(gs), xs.grad) < TOL
+    # pixel-unshuffle + 1x1 (DD:95-99)
+    xf = q(torch.randn(B, 64, 2 * H, 2 * W)).requires_grad_(True)
+    w = (torch.randn(128, 256, 1, 1) / 16).requires_grad_(True)
+    dy = q(torch.randn(B, 128, H, W))
+    P = {"m.1.weight": w + (q(w) - w).detach(), "m.1.bias": torch.zeros(128)}
+    R.downsample(P, "m", xf, R.q_id).backward(dy)
+    t = to_nhwc(xf.detach())
+    srcs = [dict(t=t, unshuffle=1, p1=s >> 1, p2=s & 1) for s in range(4)]
+    got_w = wgrad(L, B, H, W, 1, srcs, 128, to_nhwc(dy), w.detach(), unshuffle=1)
+    assert rel_l2(got_w, w.grad) < TOL
+    D = dgrad(L, B, H, W, 1, prep_weight(L, w.detach(), 1, unshuffle=1), 256, 128, to_nhwc(dy))
+    gf = torch.empty(B, 2 * H, 2 * W, 64, dtype=torch.bfloat16, device="cuda")
+    for s in range(4):
+        L.check(L.lib().ofd_grad_scatter(L.ptr(D), 256, s * 64, L.ptr(gf), 64, B, H, W, 2, s >> 1, s & 1, 0, L.stream()))
+    assert rel_l2(from_nhwc(gf), xf.grad) < TOL
+
+
+def test_conv7x7_weight_gradient(L):
+    torch.manual_seed(2)
+    B, H, W, Cin = 2, 24, 40, 5
+    x = q(torch.randn(B, Cin, H, W))
+    w = (torch.randn(64, Cin, 7, 7) / math.sqrt(Cin * 49)).requires_grad_(True)
+    dy = q(torch.randn(B, 64, H, W))
+    F.conv2d(x, w + (q(w) - w).detach(), None, padding=3).backward(dy)
+    xp = torch.zeros(B, 16, H, W)
+    xp[:, :Cin] = x
+    acc = torch.zeros(49 * 16 * 64, device="cuda")
+    xd, dyd = to_nhwc(xp), to_nhwc(dy)          # keep the device tensors alive across the async launch
+    L.check(L.lib().ofd_conv7_wgrad(L.ptr(xd), L.ptr(dyd), L.ptr(acc), B, H, W, L.stream()))
+    dst = torch.empty(64, Cin, 7, 7, device="cuda")
+    wd = w.detach().cuda()
+    L.check(L.lib().ofd_conv_wgrad_finish(L.ptr(acc), L.ptr(wd), L.ptr(dst), 64, Cin, 16, 7, -1.0, 0, 0, L.stream()))
+    assert rel_l2(dst.cpu(), w.grad) < TOL
