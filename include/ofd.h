@@ -211,6 +211,39 @@ int ofd_grad_scatter(const void* D, int Ctot, int ch_off, void* dst, int C, int 
                      int p1, int p2, int accumulate, void* stream);
 int ofd_channel_sum(const void* dy, float* out, size_t npix, int C, void* stream);
 
+/* --------------------------------------------------- Block / norm backward (training) --------
+ * ofd_gn_silu_backward: backward of out = SiLU(GroupNorm(h) * (scale+1) + shift) (DD:181-187) given
+ *   g = dL/dout.  (a, s) is the folded per-(sample, channel) affine of the forward, stats = [B][8][{mean,
+ *   rstd}].  Writes dh; ADDS into dgamma / dbeta (fp32 [C]); writes the scale|shift gradient rows into dss
+ *   (same indexing as ss; NULL when the block has no time-embedding input).  workspace:
+ *   ofd_gn_bwd_workspace_floats floats.
+ * ofd_layernorm_c_backward: DD:116-125; dx written (or added when accumulate != 0), dg ADDED.
+ * ofd_final_conv_backward: DD:361; dx written, dw / db ADDED. */
+size_t ofd_gn_bwd_workspace_floats(int B, int H, int W, int C);
+int ofd_gn_silu_backward(const void* g, const void* h, const float* a, const float* s, const float* stats,
+                         const float* gamma, const float* beta, const float* ss, int ss_stride, int ss_offset,
+                         void* dh, float* dgamma, float* dbeta, float* dss, float* workspace,
+                         int B, int H, int W, int C, void* stream);
+int ofd_affine_silu(const void* h, const float* a, const float* s, void* out, int B, int H, int W, int C, void* stream);
+int ofd_layernorm_c_backward(const void* x, const float* g, const void* dy, void* dx, float* dg, size_t npix, int C,
+                             float eps, int accumulate, void* stream);
+int ofd_final_conv_backward(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db,
+                            int B, int H, int W, int C, int out_dim, void* stream);
+
+/* --------------------------------------------------- attention cores, forward + backward -------
+ * qkv / dqkv: [B][n][384] bf16 (q | k | v, 4 heads x 32); out / dout: [B][n][128] bf16.
+ * LinearAttention core (DD:229-242): forward keeps ctx [B*4][32][32] and ml [B*4][64] (max and 1/sum of
+ *   the softmax over pixels) for the backward.  workspace: ofd_la_workspace_floats / ofd_la_bwd_workspace_floats.
+ * Softmax attention (DD:256-268): forward keeps lse [B*4][n]; backward needs delta scratch [B*4][n]. */
+size_t ofd_la_workspace_floats(int B, int n);
+size_t ofd_la_bwd_workspace_floats(int B, int n);
+int ofd_linear_attention_core(const void* qkv, void* out, float* ctx, float* ml, float* workspace, int B, int n, void* stream);
+int ofd_linear_attention_core_backward(const void* qkv, const void* dout, const float* ctx, const float* ml, void* dqkv,
+                                       float* workspace, int B, int n, void* stream);
+int ofd_flash_attention(const void* qkv, void* out, float* lse, int B, int n, void* stream);
+int ofd_flash_attention_backward(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                 float* delta, int B, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,18 +27,37 @@ int k_time_mlp(const int64_t* t, const float* w1, const float* b1, const float* 
                float* temb_silu, int B, int dim, hipStream_t s);
 int k_block_mlp(const float* temb_silu, const MlpDesc* descs, int n_desc, float* ss, int B, int tdim, int ss_stride, hipStream_t s);
 int k_gn_finalize(const float* partial, int B, int H, int W, int C, const float* gamma, const float* beta, const float* ss,
-                  int ss_stride, int ss_offset, float* a_out, float* s_out, hipStream_t s);
+                  int ss_stride, int ss_offset, float* a_out, float* s_out, hipStream_t s, float* stats_out = nullptr);
 int k_resblock_out(const bf16_t* h, const float* a, const float* sft, const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t s);
 int k_layernorm_c(const bf16_t* x, const float* g, const bf16_t* res, bf16_t* out, size_t npix, int C, float eps, hipStream_t s);
 int la_parts(int n);
-int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s);
+int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s, float* ml_out = nullptr);
 int la_fused_blocks(int n);
 int k_la_weight_prep(const float* wqkv, const float* g, const float* wout, bf16_t* wq, bf16_t* wkv, bf16_t* woutp, int C, hipStream_t s);
 int k_linear_attention_fused(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const bf16_t* woutp, const float* bias, const float* g2,
                              float* partial, bf16_t* ctxfrag, bf16_t* y, int B, int n, int C, float eps_pre, float eps_post, hipStream_t s);
-int k_flash_attention(const bf16_t* qkv, bf16_t* out, int B, int n, hipStream_t s);
+int k_flash_attention(const bf16_t* qkv, bf16_t* out, int B, int n, hipStream_t s, float* lse = nullptr);
 int k_final_conv(const bf16_t* x, const float* w, const float* bias, float* out, int B, int H, int W, int C, int out_dim, hipStream_t s);
 int k_nhwc_to_nchw(const bf16_t* x, float* out, int B, int H, int W, int C, hipStream_t s);
 int k_nchw_to_nhwc(const float* x, bf16_t* out, int B, int H, int W, int C, hipStream_t s);
+
+// training-path kernels (train_ops.hip)
+int k_affine_silu(const bf16_t* h, const float* a, const float* s, bf16_t* out, int B, int H, int W, int C, hipStream_t st);
+size_t gn_bwd_workspace_floats(int B, int H, int W, int C);
+int k_gn_silu_backward(const bf16_t* g, const bf16_t* h, const float* a, const float* s, const float* stats, const float* gamma,
+                       const float* beta, const float* ss, int ss_stride, int ss_offset, bf16_t* dh, float* dgamma, float* dbeta, float* dss,
+                       float* workspace, int B, int H, int W, int C, hipStream_t st);
+int k_layernorm_c_bwd(const bf16_t* x, const float* gw, const bf16_t* dy, bf16_t* dx, float* dg, size_t npix, int C, float eps, int accumulate,
+                      hipStream_t st);
+int k_final_conv_bwd(const bf16_t* x, const float* w, const float* dy, bf16_t* dx, float* dw, float* db, int B, int H, int W, int C, int out_dim,
+                     hipStream_t st);
+int k_grad_add(bf16_t* dst, const bf16_t* src, size_t elems, int accumulate, hipStream_t st);
+
+// attention backward (attn_bwd.hip)
+size_t la_bwd_workspace_floats(int B, int n);
+int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const float* ctx, const float* ml, bf16_t* dqkv, float* workspace, int B, int n,
+                                hipStream_t s);
+int k_flash_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, bf16_t* dqkv, float* delta, int B, int n,
+                          hipStream_t s);
 
 }  // namespace ofd

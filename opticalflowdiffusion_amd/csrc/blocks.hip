@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) block_mlp_kernel(const float* __restrict_
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial, int tiles, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ ss, int ss_stride, int ss_offset,
-                                                          float* __restrict__ a_out, float* __restrict__ s_out) {
+                                                          float* __restrict__ a_out, float* __restrict__ s_out, float* __restrict__ stats_out) {
     const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const int gs = C / 8, octs = gs / 8, noct = C / 8;
     double s1 = 0.0, s2 = 0.0;
@@ -116,6 +116,10 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
     double var_d = r2[0] / count - mean_d * mean_d;
     if (var_d < 0.0) var_d = 0.0;
     const float mean = (float)mean_d, rstd = rsqrtf((float)var_d + 1e-5f);
+    if (stats_out && tid == 0) {          // kept by the training forward for the GroupNorm backward
+        stats_out[((size_t)b * 8 + g) * 2] = mean;
+        stats_out[((size_t)b * 8 + g) * 2 + 1] = rstd;
+    }
     for (int c = g * gs + tid; c < (g + 1) * gs; c += 256) {
         float sc = 0.0f, sh = 0.0f;
         if (ss) {
@@ -279,7 +283,7 @@ __global__ void __launch_bounds__(256) la_ctx_partial_kernel(const bf16_t* __res
 }
 
 // combine the partials: ctx[bh][d][e] = sum_c exp(m_c - M) ctx_c / (sum_c exp(m_c - M) l_c) / n
-__global__ void __launch_bounds__(256) la_ctx_combine_kernel(const float* __restrict__ partial, float* __restrict__ ctx, int nparts, float inv_n) {
+__global__ void __launch_bounds__(256) la_ctx_combine_kernel(const float* __restrict__ partial, float* __restrict__ ctx, int nparts, float inv_n, float* __restrict__ ml_out) {
     __shared__ float M[32], Linv[32];
     const int tid = threadIdx.x, bh = blockIdx.x;
     const float* base = partial + (size_t)bh * nparts * 1088;
@@ -290,6 +294,10 @@ __global__ void __launch_bounds__(256) la_ctx_combine_kernel(const float* __rest
         for (int c = 0; c < nparts; ++c) l += base[(size_t)c * 1088 + 32 + tid] * __expf(base[(size_t)c * 1088 + tid] - mx);
         M[tid] = mx;
         Linv[tid] = 1.0f / l;
+        if (ml_out) {                     // softmax-over-pixels normalisers, kept for the backward
+            ml_out[(size_t)bh * 64 + tid] = mx;
+            ml_out[(size_t)bh * 64 + 32 + tid] = 1.0f / l;
+        }
     }
     __syncthreads();
     for (int i = tid; i < 1024; i += 256) {
@@ -367,7 +375,7 @@ __global__ void __launch_bounds__(256) la_out_kernel(const bf16_t* __restrict__ 
 // S^T = K.Q^T puts the query on the lane, so row max / sum are lane-local (+1 cross-half shuffle)
 // and the exponentiated accumulator is directly the B operand of O^T += V^T.P^T.
 constexpr int FA_KT = 64;
-__global__ void __launch_bounds__(256) flash_attn_d32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n, float scale) {
+__global__ void __launch_bounds__(256) flash_attn_d32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n, float scale, float* __restrict__ lse) {
     __shared__ __attribute__((aligned(16))) unsigned char k_lds[FA_KT * 80];      // [key][32 d], rows padded to 80 B
     __shared__ __attribute__((aligned(16))) unsigned char vt_lds[32 * 144];       // [d][64 keys permuted], rows padded to 144 B
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -459,6 +467,7 @@ __global__ void __launch_bounds__(256) flash_attn_d32_kernel(const bf16_t* __res
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int q = q0 + l31;
+    if (lse && q < n && half == 0) lse[(size_t)bh * n + q] = m_run + __logf(l_tot);     // kept for the backward
     if (q < n) {
         bf16_t* dst = out + ((size_t)b * n + q) * 128 + h * 32;
 #pragma unroll
@@ -545,10 +554,10 @@ int k_block_mlp(const float* temb_silu, const MlpDesc* descs, int n_desc, float*
     return OFD_OK;
 }
 int k_gn_finalize(const float* partial, int B, int H, int W, int C, const float* gamma, const float* beta, const float* ss, int ss_stride,
-                  int ss_offset, float* a_out, float* s_out, hipStream_t s) {
+                  int ss_offset, float* a_out, float* s_out, hipStream_t s, float* stats_out) {
     OFD_CHECK_ARG(C % 64 == 0, "gn_finalize: C=%d", C);
     const int tiles = cdiv(H, 8) * cdiv(W, 32) * 4;    // one partial per (tile, wave) from the conv epilogue
-    gn_finalize_kernel<<<dim3(B, 8), 256, 0, s>>>(partial, tiles, C, (double)H * W * (C / 8), gamma, beta, ss, ss_stride, ss_offset, a_out, s_out);
+    gn_finalize_kernel<<<dim3(B, 8), 256, 0, s>>>(partial, tiles, C, (double)H * W * (C / 8), gamma, beta, ss, ss_stride, ss_offset, a_out, s_out, stats_out);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -566,18 +575,18 @@ int k_layernorm_c(const bf16_t* x, const float* g, const bf16_t* res, bf16_t* ou
     return OFD_OK;
 }
 int la_parts(int n) { return cdiv(n, 4096); }
-int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s) {
+int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s, float* ml_out) {
     const int nparts = la_parts(n);
     la_ctx_partial_kernel<<<dim3(nparts, B * 4), 256, 0, s>>>(qkv, partial, n, 4096, nparts);
-    la_ctx_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, nparts, 1.0f / (float)n);
+    la_ctx_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, nparts, 1.0f / (float)n, ml_out);
     int gx = cdiv(n, 32);
     if (gx > 1024) gx = 1024;
     la_out_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, ctx, out, n, 0.17677669529663687f);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
-int k_flash_attention(const bf16_t* qkv, bf16_t* out, int B, int n, hipStream_t s) {
-    flash_attn_d32_kernel<<<dim3(cdiv(n, 128), B * 4), 256, 0, s>>>(qkv, out, n, 0.17677669529663687f);
+int k_flash_attention(const bf16_t* qkv, bf16_t* out, int B, int n, hipStream_t s, float* lse) {
+    flash_attn_d32_kernel<<<dim3(cdiv(n, 128), B * 4), 256, 0, s>>>(qkv, out, n, 0.17677669529663687f, lse);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

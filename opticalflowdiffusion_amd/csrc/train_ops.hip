@@ -1,0 +1,365 @@
+// Training-path kernels that are not convolutions (backward of DD:172-214 Block / ResnetBlock,
+// DD:116-125 LayerNorm, DD:361 final conv) plus the un-fused forward pieces the training forward
+// keeps (the inference path fuses them into conv loaders / epilogues).  NHWC bf16 activations and
+// activation gradients, fp32 statistics and parameter gradients.
+#include "blocks.h"
+
+namespace ofd {
+
+__device__ __forceinline__ void t_unpack8(const uint4& v, float (&f)[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = bf2f((bf16_t)(w[j] & 0xffffu));
+        f[2 * j + 1] = bf2f((bf16_t)(w[j] >> 16));
+    }
+}
+__device__ __forceinline__ uint4 t_pack8(const float (&f)[8]) {
+    return make_uint4(f2bf2(f[0], f[1]), f2bf2(f[2], f[3]), f2bf2(f[4], f[5]), f2bf2(f[6], f[7]));
+}
+__device__ __forceinline__ float t_sigmoid(float u) { return __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }
+// d silu(u) / du
+__device__ __forceinline__ float t_dsilu(float u) {
+    const float sg = t_sigmoid(u);
+    return sg * (1.0f + u * (1.0f - sg));
+}
+__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
+    *(float4*)&f[0] = *(const float4*)p;
+    *(float4*)&f[4] = *(const float4*)(p + 4);
+}
+
+// ---- forward: out = SiLU(h * a[b,c] + s[b,c])  (DD:181-187 after GroupNorm folded into (a, s)) ----
+__global__ void __launch_bounds__(256) affine_silu_kernel(const bf16_t* __restrict__ h, const float* __restrict__ a, const float* __restrict__ s,
+                                                          bf16_t* __restrict__ out, int C, size_t pix_per_sample, size_t total_units) {
+    const int c8n = C / 8;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total_units; u += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = u / c8n;
+        const int c = (int)(u % c8n) * 8;
+        const size_t b = pix / pix_per_sample;
+        float hv[8], av[8], sv[8];
+        t_unpack8(*(const uint4*)(h + u * 8), hv);
+        load8f(a + b * C + c, av);
+        load8f(s + b * C + c, sv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y = hv[j] * av[j] + sv[j];
+            hv[j] = y * t_sigmoid(y);
+        }
+        *(uint4*)(out + u * 8) = t_pack8(hv);
+    }
+}
+
+// ---- backward of out = SiLU(GN-affine(h)), pass 1: per (sample, channel) sums of du and du*h --------
+// du = g * silu'(a h + s).  grid (chunks, B); partial[b][chunk][C][2]
+__global__ void __launch_bounds__(256) gnbwd_reduce_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ h, const float* __restrict__ a,
+                                                           const float* __restrict__ s, float* __restrict__ partial, int C, size_t pix_per_sample,
+                                                           int pix_per_chunk) {
+    __shared__ float red[256][17];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, c8n = C / 8;
+    const size_t p0 = (size_t)chunk * pix_per_chunk, p1 = min(pix_per_sample, p0 + pix_per_chunk);
+    for (int cu0 = 0; cu0 < c8n; cu0 += 256) {
+        const int lanes_c = min(c8n - cu0, 256), rows = 256 / lanes_c, my_c = tid % lanes_c, my_r = tid / lanes_c;
+        float a1[8], a2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a1[j] = 0.0f; a2[j] = 0.0f; }
+        if (my_r < rows) {
+            float av[8], sv[8];
+            load8f(a + (size_t)b * C + (cu0 + my_c) * 8, av);
+            load8f(s + (size_t)b * C + (cu0 + my_c) * 8, sv);
+            for (size_t p = p0 + my_r; p < p1; p += rows) {
+                const size_t off = (((size_t)b * pix_per_sample + p) * c8n + cu0 + my_c) * 8;
+                float gv[8], hv[8];
+                t_unpack8(*(const uint4*)(g + off), gv);
+                t_unpack8(*(const uint4*)(h + off), hv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float du = gv[j] * t_dsilu(hv[j] * av[j] + sv[j]);
+                    a1[j] += du;
+                    a2[j] += du * hv[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[tid][j] = a1[j]; red[tid][8 + j] = a2[j]; }
+        __syncthreads();
+        if (tid < lanes_c) {
+            float* o = partial + (((size_t)b * gridDim.x + chunk) * C + (cu0 + tid) * 8) * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float s1 = 0.0f, s2 = 0.0f;
+                for (int r = 0; r < rows; ++r) { s1 += red[r * lanes_c + tid][j]; s2 += red[r * lanes_c + tid][8 + j]; }
+                o[2 * j] = s1;
+                o[2 * j + 1] = s2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// pass 2 (tiny): grid (B, 8 groups).  stats[b][g] = {mean, rstd} saved by the forward.
+//   dh = a*du + c2*h + c3 ; c2 = -r^2 G2/N ; c3 = -r G1/N + r^2 mu G2/N
+//   dgamma += scp*S ; dbeta += scp*A1 ; dscale[b,c] = gamma*S + beta*A1 ; dshift[b,c] = A1     (S = r (A2 - mu A1))
+__global__ void __launch_bounds__(256) gnbwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, double count,
+                                                             const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ ss, int ss_stride, int ss_offset, float* __restrict__ c2c3,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dss) {
+    __shared__ double g1s[256], g2s[256];
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, gs = C / 8;
+    const float mu = stats[((size_t)b * 8 + g) * 2], r = stats[((size_t)b * 8 + g) * 2 + 1];
+    double G1 = 0.0, G2 = 0.0;
+    for (int cc = tid; cc < gs; cc += 256) {
+        const int c = g * gs + cc;
+        double A1 = 0.0, A2 = 0.0;
+        for (int k = 0; k < chunks; ++k) {
+            const float* p = partial + (((size_t)b * chunks + k) * C + c) * 2;
+            A1 += (double)p[0];
+            A2 += (double)p[1];
+        }
+        const float scp = ss ? ss[(size_t)b * ss_stride + ss_offset + c] + 1.0f : 1.0f;
+        const double S = (double)r * (A2 - (double)mu * A1);
+        atomicAdd(dgamma + c, (float)(scp * S));
+        atomicAdd(dbeta + c, (float)(scp * A1));
+        if (dss) {
+            dss[(size_t)b * ss_stride + ss_offset + c] = (float)(gamma[c] * S + beta[c] * A1);
+            dss[(size_t)b * ss_stride + ss_offset + C + c] = (float)A1;
+        }
+        G1 += (double)gamma[c] * scp * A1;
+        G2 += (double)gamma[c] * scp * S;
+    }
+    g1s[tid] = G1;
+    g2s[tid] = G2;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (tid < k) { g1s[tid] += g1s[tid + k]; g2s[tid] += g2s[tid + k]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double rr = (double)r, N = count;
+        c2c3[((size_t)b * 8 + g) * 2] = (float)(-rr * rr * g2s[0] / N);
+        c2c3[((size_t)b * 8 + g) * 2 + 1] = (float)(-rr * g1s[0] / N + rr * rr * (double)mu * g2s[0] / N);
+    }
+}
+
+// pass 3: dh = a * g * silu'(a h + s) + c2[b,grp] * h + c3[b,grp]
+__global__ void __launch_bounds__(256) gnbwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ h, const float* __restrict__ a,
+                                                          const float* __restrict__ s, const float* __restrict__ c2c3, bf16_t* __restrict__ dh, int C,
+                                                          size_t pix_per_sample, size_t total_units) {
+    const int c8n = C / 8, gs = C / 8;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total_units; u += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = u / c8n;
+        const int c = (int)(u % c8n) * 8;
+        const size_t b = pix / pix_per_sample;
+        float gv[8], hv[8], av[8], sv[8];
+        t_unpack8(*(const uint4*)(g + u * 8), gv);
+        t_unpack8(*(const uint4*)(h + u * 8), hv);
+        load8f(a + b * C + c, av);
+        load8f(s + b * C + c, sv);
+        const int grp = c / gs;                      // 8 channels never straddle a group (gs >= 8)
+        const float c2 = c2c3[(b * 8 + grp) * 2], c3 = c2c3[(b * 8 + grp) * 2 + 1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[j] = av[j] * gv[j] * t_dsilu(hv[j] * av[j] + sv[j]) + c2 * hv[j] + c3;
+        *(uint4*)(dh + u * 8) = t_pack8(gv);
+    }
+}
+
+// ---- LayerNorm over channels backward (DD:116-125): y = x^ * g (+ residual); lpp lanes per pixel ----
+// dx = r (t - mean(t) - x^ mean(t x^)), t = dy*g ; dg[c] += sum_pixels dy * x^   (per-workgroup partial -> atomics)
+__global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gw, const bf16_t* __restrict__ dy,
+                                                              bf16_t* __restrict__ dx, float* __restrict__ dg, int C, float eps, size_t npix, int accumulate) {
+    extern __shared__ float dg_s[];       // [C]
+    for (int i = threadIdx.x; i < C; i += 256) dg_s[i] = 0.0f;
+    __syncthreads();
+    const int lpp = C / 8, lane = threadIdx.x & 63, sub = lane % lpp, slot = lane / lpp, ppw = 64 / lpp;
+    const size_t wave_global = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    float gv[8], dgl[8];
+    load8f(gw + sub * 8, gv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dgl[j] = 0.0f;
+    const float inv_c = 1.0f / (float)C;
+    for (size_t p0 = wave_global * ppw; p0 < npix; p0 += nwaves * ppw) {
+        const size_t p = min(p0 + slot, npix - 1);
+        const bool ok = p0 + slot < npix;
+        float v[8], d[8];
+        t_unpack8(*(const uint4*)(x + p * C + sub * 8), v);
+        t_unpack8(*(const uint4*)(dy + p * C + sub * 8), d);
+        float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        for (int o = 1; o < lpp; o <<= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * inv_c;
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] -= mean; q += v[j] * v[j]; }
+        for (int o = 1; o < lpp; o <<= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = rsqrtf(q * inv_c + eps);
+        float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] *= rstd;                              // x^
+            if (ok) dgl[j] += d[j] * v[j];
+            d[j] *= gv[j];                             // t
+            m1 += d[j];
+            m2 += d[j] * v[j];
+        }
+        for (int o = 1; o < lpp; o <<= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+        m1 *= inv_c;
+        m2 *= inv_c;
+        if (ok) {
+            float r8[8];
+            if (accumulate) t_unpack8(*(const uint4*)(dx + p * C + sub * 8), r8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = rstd * (d[j] - m1 - v[j] * m2) + (accumulate ? r8[j] : 0.0f);
+            *(uint4*)(dx + p * C + sub * 8) = t_pack8(d);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&dg_s[sub * 8 + j], dgl[j]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(dg + i, dg_s[i]);
+}
+
+// ---- final 1x1 conv backward (DD:361,417): y[o] = sum_c w[o,c] x[c] + b[o], y NCHW fp32, x NHWC bf16 -----
+// dx[c] = sum_o w[o,c] dy[o] ; dw[o,c] += sum_p dy[o] x[c] ; db[o] += sum_p dy[o]
+__global__ void __launch_bounds__(256) final_conv_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+                                                             bf16_t* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int C, int out_dim,
+                                                             size_t plane, size_t total) {
+    extern __shared__ float sm[];          // dw_s[out_dim*C] + db_s[4]
+    float* dw_s = sm;
+    float* db_s = sm + out_dim * C;
+    for (int i = threadIdx.x; i < out_dim * C + 4; i += 256) sm[i] = 0.0f;
+    __syncthreads();
+    const int lpp = C / 8, lane = threadIdx.x & 63, sub = lane % lpp, slot = lane / lpp, ppw = 64 / lpp;
+    float wv[4][8], dwl[4][8], dbl[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wv[o][j] = (o < out_dim) ? w[o * C + sub * 8 + j] : 0.0f; dwl[o][j] = 0.0f; }
+    const size_t wave_global = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t p0 = wave_global * ppw; p0 < total; p0 += nwaves * ppw) {
+        const size_t i = min(p0 + slot, total - 1);
+        const bool ok = p0 + slot < total;
+        const size_t n = i / plane, pix = i % plane;
+        float f[8], dxv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        t_unpack8(*(const uint4*)(x + i * C + sub * 8), f);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (o < out_dim) {
+                const float d = ok ? dy[(n * out_dim + o) * plane + pix] : 0.0f;
+                if (sub == 0) dbl[o] += d;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { dxv[j] += wv[o][j] * d; dwl[o][j] += d * f[j]; }
+            }
+        }
+        if (ok) *(uint4*)(dx + i * C + sub * 8) = t_pack8(dxv);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        if (o < out_dim) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(&dw_s[o * C + sub * 8 + j], dwl[o][j]);
+            if (sub == 0) atomicAdd(&db_s[o], dbl[o]);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < out_dim * C; i += 256) atomicAdd(dw + i, dw_s[i]);
+    if (threadIdx.x < out_dim) atomicAdd(db + threadIdx.x, db_s[threadIdx.x]);
+}
+
+// dst (+)= src, bf16 (gradient fan-in of skip connections / residual paths)
+__global__ void __launch_bounds__(256) grad_add_kernel(bf16_t* __restrict__ dst, const bf16_t* __restrict__ src, size_t units, int accumulate) {
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+        float a[8];
+        t_unpack8(*(const uint4*)(src + u * 8), a);
+        if (accumulate) {
+            float b[8];
+            t_unpack8(*(const uint4*)(dst + u * 8), b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += b[j];
+        }
+        *(uint4*)(dst + u * 8) = t_pack8(a);
+    }
+}
+
+static inline int tgrid(size_t total, int cap = 4096) {
+    size_t b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
+}
+
+int k_affine_silu(const bf16_t* h, const float* a, const float* s, bf16_t* out, int B, int H, int W, int C, hipStream_t st) {
+    const size_t units = (size_t)B * H * W * (C / 8);
+    affine_silu_kernel<<<tgrid(units), 256, 0, st>>>(h, a, s, out, C, (size_t)H * W, units);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+size_t gn_bwd_workspace_floats(int B, int H, int W, int C) {
+    const int chunks = cdiv((long)H * W, 2048);
+    return (size_t)B * chunks * C * 2 + (size_t)B * 16;
+}
+
+// g: gradient w.r.t. SiLU output; h: the conv output GroupNorm normalised; (a, s): the folded affine;
+// stats: [B][8][{mean, rstd}]; ss/dss: per-sample scale|shift rows of this block (NULL for block2)
+int k_gn_silu_backward(const bf16_t* g, const bf16_t* h, const float* a, const float* s, const float* stats, const float* gamma,
+                       const float* beta, const float* ss, int ss_stride, int ss_offset, bf16_t* dh, float* dgamma, float* dbeta, float* dss,
+                       float* workspace, int B, int H, int W, int C, hipStream_t st) {
+    OFD_CHECK_ARG(C % 64 == 0, "gn_silu_backward: C=%d", C);
+    const size_t pps = (size_t)H * W;
+    const int ppc = 2048, chunks = cdiv((long)pps, ppc);
+    float* partial = workspace;
+    float* c2c3 = workspace + (size_t)B * chunks * C * 2;
+    gnbwd_reduce_kernel<<<dim3(chunks, B), 256, 0, st>>>(g, h, a, s, partial, C, pps, ppc);
+    gnbwd_finalize_kernel<<<dim3(B, 8), 256, 0, st>>>(partial, chunks, C, (double)pps * (C / 8), stats, gamma, beta, ss, ss_stride, ss_offset, c2c3,
+                                                    dgamma, dbeta, dss);
+    const size_t units = (size_t)B * pps * (C / 8);
+    gnbwd_apply_kernel<<<tgrid(units), 256, 0, st>>>(g, h, a, s, c2c3, dh, C, pps, units);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+int k_layernorm_c_bwd(const bf16_t* x, const float* gw, const bf16_t* dy, bf16_t* dx, float* dg, size_t npix, int C, float eps, int accumulate,
+                      hipStream_t st) {
+    OFD_CHECK_ARG(C == 64 || C == 128 || C == 256 || C == 512, "layernorm_c_bwd: C=%d", C);
+    const size_t waves = (npix + (512 / C) - 1) / (512 / C);
+    layernorm_c_bwd_kernel<<<tgrid(waves * 64, 1024), 256, C * sizeof(float), st>>>(x, gw, dy, dx, dg, C, eps, npix, accumulate);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+int k_final_conv_bwd(const bf16_t* x, const float* w, const float* dy, bf16_t* dx, float* dw, float* db, int B, int H, int W, int C, int out_dim,
+                     hipStream_t st) {
+    OFD_CHECK_ARG(out_dim >= 1 && out_dim <= 4 && (C == 64 || C == 128), "final_conv_bwd: out_dim=%d C=%d", out_dim, C);
+    const size_t total = (size_t)B * H * W;
+    final_conv_bwd_kernel<<<tgrid((total + (512 / C) - 1) / (512 / C) * 64, 1024), 256, (out_dim * C + 4) * sizeof(float), st>>>(
+        x, w, dy, dx, dw, db, C, out_dim, (size_t)H * W, total);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+int k_grad_add(bf16_t* dst, const bf16_t* src, size_t elems, int accumulate, hipStream_t st) {
+    grad_add_kernel<<<tgrid(elems / 8), 256, 0, st>>>(dst, src, elems / 8, accumulate);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+}  // namespace ofd
+using namespace ofd;
+
+extern "C" size_t ofd_gn_bwd_workspace_floats(int B, int H, int W, int C) { return gn_bwd_workspace_floats(B, H, W, C); }
+extern "C" int ofd_gn_silu_backward(const void* g, const void* h, const float* a, const float* s, const float* stats, const float* gamma,
+                                    const float* beta, const float* ss, int ss_stride, int ss_offset, void* dh, float* dgamma, float* dbeta,
+                                    float* dss, float* workspace, int B, int H, int W, int C, void* stream) {
+    OFD_CHECK_ARG(g && h && a && s && stats && gamma && beta && dh && dgamma && dbeta && workspace, "gn_silu_backward: null argument");
+    return k_gn_silu_backward((const bf16_t*)g, (const bf16_t*)h, a, s, stats, gamma, beta, ss, ss_stride, ss_offset, (bf16_t*)dh, dgamma, dbeta, dss,
+                              workspace, B, H, W, C, (hipStream_t)stream);
+}
+extern "C" int ofd_affine_silu(const void* h, const float* a, const float* s, void* out, int B, int H, int W, int C, void* stream) {
+    OFD_CHECK_ARG(h && a && s && out && C % 8 == 0, "affine_silu: bad argument");
+    return k_affine_silu((const bf16_t*)h, a, s, (bf16_t*)out, B, H, W, C, (hipStream_t)stream);
+}
+extern "C" int ofd_layernorm_c_backward(const void* x, const float* g, const void* dy, void* dx, float* dg, size_t npix, int C, float eps,
+                                        int accumulate, void* stream) {
+    OFD_CHECK_ARG(x && g && dy && dx && dg, "layernorm_c_backward: null argument");
+    return k_layernorm_c_bwd((const bf16_t*)x, g, (const bf16_t*)dy, (bf16_t*)dx, dg, npix, C, eps, accumulate, (hipStream_t)stream);
+}
+extern "C" int ofd_final_conv_backward(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db, int B, int H, int W, int C,
+                                       int out_dim, void* stream) {
+    OFD_CHECK_ARG(x && w && dy && dx && dw && db, "final_conv_backward: null argument");
+    return k_final_conv_bwd((const bf16_t*)x, w, dy, (bf16_t*)dx, dw, db, B, H, W, C, out_dim, (hipStream_t)stream);
+}

@@ -141,3 +141,142 @@ def test_conv7x7_weight_gradient(L):
     wd = w.detach().cuda()
     L.check(L.lib().ofd_conv_wgrad_finish(L.ptr(acc), L.ptr(wd), L.ptr(dst), 64, Cin, 16, 7, -1.0, 0, 0, L.stream()))
     assert rel_l2(dst.cpu(), w.grad) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,C,with_ss", [(2, 8, 16, 64, True), (2, 24, 100, 128, True), (1, 16, 24, 256, False), (3, 50, 60, 64, False)])
+def test_gn_silu_backward(L, B, H, W, C, with_ss):
+    """DD:181-187: out = SiLU(GN(h) * (scale + 1) + shift); grads of h, gamma, beta, scale, shift."""
+    torch.manual_seed(1)
+    h = q(torch.randn(B, C, H, W) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C)).requires_grad_(True)
+    ss = (0.3 * torch.randn(B, 2 * C + 10)).requires_grad_(True)        # rows wider than this block's slice
+    off = 4
+    g = q(torch.randn(B, C, H, W))
+    eps = 1e-5
+    y = F.group_norm(h, 8, gamma, beta, eps)
+    if with_ss:
+        y = y * (ss[:, off:off + C, None, None] + 1) + ss[:, off + C:off + 2 * C, None, None]
+    F.silu(y).backward(g)
+    # folded affine + statistics, as the forward's gn_finalize leaves them
+    hd = h.detach().view(B, 8, -1)
+    mean, var = hd.mean(-1), hd.var(-1, unbiased=False)
+    rstd = (var + eps).rsqrt()
+    scp = (ss.detach()[:, off:off + C] + 1) if with_ss else torch.ones(B, C)
+    shf = ss.detach()[:, off + C:off + 2 * C] if with_ss else torch.zeros(B, C)
+    a = gamma.detach()[None] * rstd.repeat_interleave(C // 8, 1) * scp
+    s = (beta.detach()[None] - gamma.detach()[None] * (mean * rstd).repeat_interleave(C // 8, 1)) * scp + shf
+    stats = torch.stack([mean, rstd], -1).contiguous()
+    dev = lambda t: t.detach().float().contiguous().cuda()
+    gd, hd_, ad, sd, std, gam, bet, ssd = to_nhwc(g), to_nhwc(h.detach()), dev(a), dev(s), dev(stats), dev(gamma), dev(beta), dev(ss)
+    dh = torch.empty_like(hd_)
+    dgam, dbet = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dss = torch.zeros_like(ssd)
+    wsp = torch.empty(L.lib().ofd_gn_bwd_workspace_floats(B, H, W, C), device="cuda")
+    L.check(L.lib().ofd_gn_silu_backward(L.ptr(gd), L.ptr(hd_), L.ptr(ad), L.ptr(sd), L.ptr(std), L.ptr(gam), L.ptr(bet),
+                                         L.ptr(ssd) if with_ss else None, ssd.shape[1], off, L.ptr(dh), L.ptr(dgam), L.ptr(dbet),
+                                         L.ptr(dss) if with_ss else None, L.ptr(wsp), B, H, W, C, L.stream()))
+    torch.cuda.synchronize()
+    assert rel_l2(from_nhwc(dh), h.grad) < TOL
+    assert rel_l2(dgam.cpu(), gamma.grad) < TOL and rel_l2(dbet.cpu(), beta.grad) < TOL
+    if with_ss:
+        assert rel_l2(dss.cpu(), ss.grad) < TOL
+    # forward companion kernel
+    out = torch.empty_like(hd_)
+    L.check(L.lib().ofd_affine_silu(L.ptr(hd_), L.ptr(ad), L.ptr(sd), L.ptr(out), B, H, W, C, L.stream()))
+    assert rel_l2(from_nhwc(out), F.silu(y.detach())) < TOL
+
+
+@pytest.mark.parametrize("npix,C,acc", [(1000, 64, 0), (333, 128, 1), (77, 256, 0), (50, 512, 1)])
+def test_layernorm_backward(L, npix, C, acc):
+    """DD:116-125 LayerNorm over channels (no bias), eps 1e-5 / 1e-3 rule."""
+    torch.manual_seed(2)
+    x = q(torch.randn(1, C, npix, 1) * 2 + 0.5).requires_grad_(True)
+    gw = (1 + 0.3 * torch.randn(C)).requires_grad_(True)
+    dy = q(torch.randn(1, C, npix, 1))
+    eps = 1e-5
+    var = x.var(dim=1, unbiased=False, keepdim=True)
+    mean = x.mean(dim=1, keepdim=True)
+    ((x - mean) * (var + eps).rsqrt() * gw[None, :, None, None]).backward(dy)
+    xd, dyd, gd = to_nhwc(x.detach()), to_nhwc(dy), gw.detach().cuda()
+    prev = q(torch.randn(1, C, npix, 1))
+    dx = to_nhwc(prev).clone()
+    dg = torch.zeros(C, device="cuda")
+    L.check(L.lib().ofd_layernorm_c_backward(L.ptr(xd), L.ptr(gd), L.ptr(dyd), L.ptr(dx), L.ptr(dg), npix, C, eps, acc, L.stream()))
+    torch.cuda.synchronize()
+    want = x.grad + (prev if acc else 0)
+    assert rel_l2(from_nhwc(dx), want) < TOL
+    assert rel_l2(dg.cpu(), gw.grad) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,C,od", [(2, 8, 24, 64, 2), (1, 5, 7, 128, 3)])
+def test_final_conv_backward(L, B, H, W, C, od):
+    torch.manual_seed(3)
+    x = q(torch.randn(B, C, H, W)).requires_grad_(True)
+    w = (torch.randn(od, C, 1, 1) / 8).requires_grad_(True)
+    b = torch.zeros(od, requires_grad=True)
+    dy = torch.randn(B, od, H, W)
+    F.conv2d(x, w, b).backward(dy)
+    xd, wd, dyd = to_nhwc(x.detach()), w.detach().view(od, C).contiguous().cuda(), dy.contiguous().cuda()
+    dx = torch.empty_like(xd)
+    dw, db = torch.zeros(od, C, device="cuda"), torch.zeros(od, device="cuda")
+    L.check(L.lib().ofd_final_conv_backward(L.ptr(xd), L.ptr(wd), L.ptr(dyd), L.ptr(dx), L.ptr(dw), L.ptr(db), B, H, W, C, od, L.stream()))
+    torch.cuda.synchronize()
+    assert rel_l2(from_nhwc(dx), x.grad) < TOL
+    assert rel_l2(dw.cpu(), w.grad.view(od, C)) < 1e-3 and rel_l2(db.cpu(), b.grad) < 1e-3
+
+
+def _qkv_split(qkv):                      # (B, 384, n) -> q, k, v as (B, 4, 32, n)   (DD:229-231 / 256-258)
+    B, _, n = qkv.shape
+    return [t.reshape(B, 4, 32, n) for t in qkv.chunk(3, dim=1)]
+
+
+@pytest.mark.parametrize("B,n", [(1, 64), (2, 1000), (1, 9000)])
+def test_linear_attention_core_backward(L, B, n):
+    torch.manual_seed(4)
+    qkv = q(torch.randn(B, 384, n) * 1.5).requires_grad_(True)
+    dout = q(torch.randn(B, 128, n))
+    qq, kk, vv = _qkv_split(qkv)
+    qs = qq.softmax(dim=-2) * (32 ** -0.5)
+    ks = kk.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", ks, vv / n)
+    out = torch.einsum("bhde,bhdn->bhen", ctx, qs).reshape(B, 128, n)
+    out.backward(dout)
+    nhwc = lambda t: q(t.detach()).permute(0, 2, 1).contiguous().to(torch.bfloat16).cuda()
+    qd, dd = nhwc(qkv), nhwc(dout)
+    od = torch.empty(B, n, 128, dtype=torch.bfloat16, device="cuda")
+    cx, ml = torch.empty(B * 4 * 1024, device="cuda"), torch.empty(B * 4 * 64, device="cuda")
+    ws = torch.empty(max(L.lib().ofd_la_workspace_floats(B, n), L.lib().ofd_la_bwd_workspace_floats(B, n)), device="cuda")
+    L.check(L.lib().ofd_linear_attention_core(L.ptr(qd), L.ptr(od), L.ptr(cx), L.ptr(ml), L.ptr(ws), B, n, L.stream()))
+    assert rel_l2(od.float().cpu().permute(0, 2, 1), out.detach()) < TOL
+    dq = torch.empty_like(qd)
+    L.check(L.lib().ofd_linear_attention_core_backward(L.ptr(qd), L.ptr(dd), L.ptr(cx), L.ptr(ml), L.ptr(dq), L.ptr(ws), B, n, L.stream()))
+    torch.cuda.synchronize()
+    got = dq.float().cpu().permute(0, 2, 1)
+    for i, nm in enumerate("qkv"):
+        e = rel_l2(got[:, 128 * i:128 * (i + 1)], qkv.grad[:, 128 * i:128 * (i + 1)])
+        assert e < TOL, f"d{nm}: {e:.3e}"
+
+
+@pytest.mark.parametrize("B,n", [(1, 64), (2, 200), (1, 1000)])
+def test_flash_attention_backward(L, B, n):
+    torch.manual_seed(5)
+    qkv = q(torch.randn(B, 384, n) * 1.5).requires_grad_(True)
+    dout = q(torch.randn(B, 128, n))
+    qq, kk, vv = _qkv_split(qkv)
+    sim = torch.einsum("bhdi,bhdj->bhij", qq * (32 ** -0.5), kk)
+    out = torch.einsum("bhij,bhdj->bhdi", sim.softmax(dim=-1), vv).reshape(B, 128, n)
+    out.backward(dout)
+    nhwc = lambda t: q(t.detach()).permute(0, 2, 1).contiguous().to(torch.bfloat16).cuda()
+    qd, dd = nhwc(qkv), nhwc(dout)
+    od = torch.empty(B, n, 128, dtype=torch.bfloat16, device="cuda")
+    lse, delta = torch.empty(B * 4 * n, device="cuda"), torch.empty(B * 4 * n, device="cuda")
+    L.check(L.lib().ofd_flash_attention(L.ptr(qd), L.ptr(od), L.ptr(lse), B, n, L.stream()))
+    assert rel_l2(od.float().cpu().permute(0, 2, 1), out.detach()) < TOL
+    dq = torch.empty_like(qd)
+    L.check(L.lib().ofd_flash_attention_backward(L.ptr(qd), L.ptr(od), L.ptr(dd), L.ptr(lse), L.ptr(dq), L.ptr(delta), B, n, L.stream()))
+    torch.cuda.synchronize()
+    got = dq.float().cpu().permute(0, 2, 1)
+    for i, nm in enumerate("qkv"):
+        e = rel_l2(got[:, 128 * i:128 * (i + 1)], qkv.grad[:, 128 * i:128 * (i + 1)])
+        assert e < 2e-2, f"d{nm}: {e:.3e}"
