@@ -96,6 +96,10 @@ int ofd_ddim_update(const float* x_t, const float* model_out, const float* noise
 /* sum and count over positions where neither pred nor target is NaN of (pred-target)^2.
  * result: 2 doubles {sum, count} (device), zeroed by the call. */
 int ofd_nan_mse_sum(const float* pred, const float* target, size_t n, double* result, void* stream);
+/* backward of result[0] / result[1] (the nanmean): dpred = 2 (pred - target) * gout[0] / result[1] on finite pairs, else 0;
+ * result is what ofd_nan_mse_sum left, gout a device scalar */
+int ofd_nan_mse_grad(const float* pred, const float* target, size_t n, const double* result, const float* gout,
+                     float* dpred, void* stream);
 
 /* ---------------------------------------------------------------- optimiser (FD:131-134) ---
  * torch.optim.Adam(lr, weight_decay) semantics (L2 in the gradient) preceded by
@@ -243,6 +247,26 @@ int ofd_linear_attention_core_backward(const void* qkv, const void* dout, const 
 int ofd_flash_attention(const void* qkv, void* out, float* lse, int B, int n, void* stream);
 int ofd_flash_attention_backward(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                                  float* delta, int B, int n, void* stream);
+
+/* --------------------------------------------------- UNet training step -----------------------
+ * What autograd does for the reference's training_step (flow_diffuser.py:218-235 ->
+ * denoising_diffusion.py:823-891 -> Unet.forward DD:363-417), as two calls:
+ *   ofd_unet_train_forward: the forward with every intermediate kept in `workspace`
+ *       (ofd_unet_train_workspace_bytes; the workspace must stay untouched until the backward);
+ *   ofd_unet_backward: dout = dL/d(out) [B][out_dim][H][W] fp32 -> gradients of all parameters, written
+ *       (not accumulated) into the flat fp32 buffer bound with ofd_unet_bind_grad_buffer.  Parameter i
+ *       lives at floats [ofd_unet_param_offset(i), +numel) of that buffer (ofd_unet_param_floats in all).
+ *       on_ready (may be NULL) is called on the host, in backward order, with each [begin, end) float
+ *       range of the buffer as soon as the launches that produce it are enqueued on `stream` -- the
+ *       hook for overlapping the data-parallel all-reduce with the rest of the backward. */
+typedef void (*ofd_grad_ready_fn)(size_t begin, size_t end, void* user);
+size_t ofd_unet_train_workspace_bytes(ofd_unet* u, int B, int H, int W);
+size_t ofd_unet_param_floats(const ofd_unet* u);
+size_t ofd_unet_param_offset(const ofd_unet* u, int i);
+int ofd_unet_bind_grad_buffer(ofd_unet* u, float* dev_grads, size_t floats);
+int ofd_unet_train_forward(ofd_unet* u, const float* x, int Cx, const float* cond, int Cc, const int64_t* t,
+                           float* out, int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+int ofd_unet_backward(ofd_unet* u, const float* dout, ofd_grad_ready_fn on_ready, void* user, void* stream);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,9 @@ class ConvArgs(ctypes.Structure):
 
 
 # name -> (restype, argtypes); every symbol declared in include/ofd.h
+# host callback of ofd_unet_backward: (begin, end, user) float range of the flat gradient buffer
+GRAD_READY = ctypes.CFUNCTYPE(None, c_size_t, c_size_t, c_void_p)
+
 SIGNATURES = {
     "ofd_version": (c_int, []),
     "ofd_last_error": (c_char_p, []),
@@ -92,6 +95,13 @@ SIGNATURES = {
     "ofd_linear_attention_core_backward": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
     "ofd_flash_attention": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),
     "ofd_flash_attention_backward": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
+    "ofd_unet_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "ofd_unet_param_floats": (c_size_t, [c_void_p]),
+    "ofd_unet_param_offset": (c_size_t, [c_void_p, c_int]),
+    "ofd_unet_bind_grad_buffer": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "ofd_unet_train_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ofd_unet_backward": (c_int, [c_void_p, c_void_p, GRAD_READY, c_void_p, c_void_p]),
+    "ofd_nan_mse_grad": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ofd_conv_weight_prep": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_float, c_int, c_void_p]),
 }
 
@@ -117,6 +127,10 @@ def lib():
 def check(rc):
     if rc != 0:
         raise OfdError(f"libofd_hip error {rc}: {lib().ofd_last_error().decode()}")
+
+
+def last_error():
+    return lib().ofd_last_error().decode()
 
 
 def stream():

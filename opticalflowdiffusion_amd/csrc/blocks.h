@@ -51,6 +51,10 @@ int k_layernorm_c_bwd(const bf16_t* x, const float* gw, const bf16_t* dy, bf16_t
                       hipStream_t st);
 int k_final_conv_bwd(const bf16_t* x, const float* w, const float* dy, bf16_t* dx, float* dw, float* db, int B, int H, int W, int C, int out_dim,
                      hipStream_t st);
+int k_block_mlp_bwd(const float* dss, const float* temb_silu, const float* weight, int n_out, int offset, float* dweight, float* dbias, float* dts,
+                    int B, int tdim, int ss_stride, hipStream_t st);
+int k_time_mlp_bwd(const int64_t* t, const float* temb, const float* dts, const float* w1, const float* b1, const float* w2, float* dw1, float* db1,
+                   float* dw2, float* db2, float* scratch, int B, int dim, hipStream_t st);
 int k_grad_add(bf16_t* dst, const bf16_t* src, size_t elems, int accumulate, hipStream_t st);
 
 // attention backward (attn_bwd.hip)

@@ -98,6 +98,17 @@ __global__ void __launch_bounds__(256) nan_mse_kernel(const float* __restrict__ 
     }
 }
 
+// backward of mean over the non-NaN entries: dpred = 2 (pred - target) * gout / count where both are finite
+__global__ void __launch_bounds__(256) nan_mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target, size_t n,
+                                                           const double* __restrict__ result, const float* __restrict__ gout,
+                                                           float* __restrict__ dpred) {
+    const float k = (float)(2.0 * (double)gout[0] / result[1]);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float p = pred[i], t = target[i];
+        dpred[i] = (isnan(p) || isnan(t)) ? 0.0f : k * (p - t);
+    }
+}
+
 static inline dim3 ew_grid(int B, size_t nv) {
     size_t b = (nv + 255) / 256;
     if (b < 1) b = 1;
@@ -154,6 +165,16 @@ extern "C" int ofd_nan_mse_sum(const float* pred, const float* target, size_t n,
     size_t b = (n + 255) / 256;
     if (b > 2048) b = 2048;
     nan_mse_kernel<<<(unsigned)b, 256, 0, s>>>(pred, target, n, result);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" int ofd_nan_mse_grad(const float* pred, const float* target, size_t n, const double* result, const float* gout, float* dpred,
+                                void* stream) {
+    OFD_CHECK_ARG(pred && target && result && gout && dpred && n > 0, "nan_mse_grad: bad argument");
+    size_t b = (n + 255) / 256;
+    if (b > 2048) b = 2048;
+    nan_mse_grad_kernel<<<(unsigned)b, 256, 0, (hipStream_t)stream>>>(pred, target, n, result, gout, dpred);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

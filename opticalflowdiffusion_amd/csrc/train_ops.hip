@@ -277,6 +277,93 @@ __global__ void __launch_bounds__(256) grad_add_kernel(bf16_t* __restrict__ dst,
     }
 }
 
+// ---- time-embedding path backward (DD:319-324 time_mlp, DD:193-196 per-block mlp) ------------------
+// dss: [B][ss_stride] gradient of every block's scale|shift row.  One ResnetBlock's Linear, 16 rows per
+// workgroup:  dW[j][k] += sum_b dss[b][off+j] * ts[b][k] ; db[j] += sum_b dss[b][off+j] ;
+//             dts[b][k] += sum_j W[j][k] dss[b][off+j]   (atomics: every block adds into dts)
+__global__ void __launch_bounds__(256) block_mlp_bwd_kernel(const float* __restrict__ dss, const float* __restrict__ ts, const float* __restrict__ weight,
+                                                            int n_out, int offset, float* __restrict__ dweight, float* __restrict__ dbias,
+                                                            float* __restrict__ dts, int B, int tdim, int ss_stride) {
+    const int tid = threadIdx.x, j0 = blockIdx.x * 16, j1 = min(n_out, j0 + 16);
+    for (int k = tid; k < tdim; k += 256) {
+        for (int j = j0; j < j1; ++j) {
+            float a = 0.0f;
+            for (int b = 0; b < B; ++b) a += dss[(size_t)b * ss_stride + offset + j] * ts[(size_t)b * tdim + k];
+            dweight[(size_t)j * tdim + k] += a;
+        }
+        for (int b = 0; b < B; ++b) {
+            float a = 0.0f;
+            for (int j = j0; j < j1; ++j) a += weight[(size_t)j * tdim + k] * dss[(size_t)b * ss_stride + offset + j];
+            atomicAdd(dts + (size_t)b * tdim + k, a);
+        }
+    }
+    if (tid < j1 - j0) {
+        float a = 0.0f;
+        for (int b = 0; b < B; ++b) a += dss[(size_t)b * ss_stride + offset + j0 + tid];
+        dbias[j0 + tid] += a;
+    }
+}
+
+// per sample: recompute emb, z1, g1 = GELU(z1), temb; dtemb = dts * silu'(temb); dz1 = (W3^T dtemb) * gelu'(z1)
+// scratch[b] = { emb[dim] | g1[tdim] | dtemb[tdim] | dz1[tdim] }
+__global__ void __launch_bounds__(256) time_mlp_bwd_sample_kernel(const int64_t* __restrict__ t, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                                  const float* __restrict__ w2, const float* __restrict__ temb, const float* __restrict__ dts,
+                                                                  float* __restrict__ scratch, int dim) {
+    __shared__ float emb[256], z1[1024], dt[1024];
+    const int b = blockIdx.x, tid = threadIdx.x, tdim = dim * 4, half_dim = dim / 2;
+    float* out = scratch + (size_t)b * (dim + 3 * tdim);
+    const float tv = (float)t[b];
+    for (int i = tid; i < half_dim; i += 256) {
+        const float k = (float)(9.210340371976184 / (double)(half_dim - 1));
+        const float f = expf((float)i * -k);
+        emb[i] = sinf(tv * f);
+        emb[half_dim + i] = cosf(tv * f);
+    }
+    __syncthreads();
+    for (int i = tid; i < dim; i += 256) out[i] = emb[i];
+    for (int j = tid; j < tdim; j += 256) {
+        float a = b1[j];
+        for (int k = 0; k < dim; ++k) a += w1[(size_t)j * dim + k] * emb[k];
+        z1[j] = a;
+        out[dim + j] = 0.5f * a * (1.0f + erff(a * 0.70710678118654752f));
+        const float te = temb[(size_t)b * tdim + j];
+        const float sg = 1.0f / (1.0f + expf(-te));
+        const float g = dts[(size_t)b * tdim + j] * sg * (1.0f + te * (1.0f - sg));
+        dt[j] = g;
+        out[dim + tdim + j] = g;
+    }
+    __syncthreads();
+    for (int k = tid; k < tdim; k += 256) {
+        float a = 0.0f;
+        for (int j = 0; j < tdim; ++j) a += w2[(size_t)j * tdim + k] * dt[j];
+        const float z = z1[k];
+        const float dgelu = 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
+        out[dim + 2 * tdim + k] = a * dgelu;
+    }
+}
+
+// weight gradients: grid (tdim rows j): dW2[j][k] += sum_b dtemb[b][j] g1[b][k]; dW1[j][k] += sum_b dz1[b][j] emb[b][k]
+__global__ void __launch_bounds__(256) time_mlp_bwd_weight_kernel(const float* __restrict__ scratch, float* __restrict__ dw1, float* __restrict__ db1,
+                                                                  float* __restrict__ dw2, float* __restrict__ db2, int B, int dim) {
+    const int j = blockIdx.x, tid = threadIdx.x, tdim = dim * 4, rec = dim + 3 * tdim;
+    for (int k = tid; k < tdim; k += 256) {
+        float a = 0.0f;
+        for (int b = 0; b < B; ++b) a += scratch[(size_t)b * rec + dim + tdim + j] * scratch[(size_t)b * rec + dim + k];
+        dw2[(size_t)j * tdim + k] += a;
+    }
+    for (int k = tid; k < dim; k += 256) {
+        float a = 0.0f;
+        for (int b = 0; b < B; ++b) a += scratch[(size_t)b * rec + dim + 2 * tdim + j] * scratch[(size_t)b * rec + k];
+        dw1[(size_t)j * dim + k] += a;
+    }
+    if (tid == 0) {
+        float a2 = 0.0f, a1 = 0.0f;
+        for (int b = 0; b < B; ++b) { a2 += scratch[(size_t)b * rec + dim + tdim + j]; a1 += scratch[(size_t)b * rec + dim + 2 * tdim + j]; }
+        db2[j] += a2;
+        db1[j] += a1;
+    }
+}
+
 static inline int tgrid(size_t total, int cap = 4096) {
     size_t b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
@@ -334,6 +421,23 @@ int k_final_conv_bwd(const bf16_t* x, const float* w, const float* dy, bf16_t* d
 
 int k_grad_add(bf16_t* dst, const bf16_t* src, size_t elems, int accumulate, hipStream_t st) {
     grad_add_kernel<<<tgrid(elems / 8), 256, 0, st>>>(dst, src, elems / 8, accumulate);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+// dts is an accumulator across ResnetBlocks: zero it before the first block's backward
+int k_block_mlp_bwd(const float* dss, const float* temb_silu, const float* weight, int n_out, int offset, float* dweight, float* dbias, float* dts,
+                    int B, int tdim, int ss_stride, hipStream_t st) {
+    block_mlp_bwd_kernel<<<cdiv(n_out, 16), 256, 0, st>>>(dss, temb_silu, weight, n_out, offset, dweight, dbias, dts, B, tdim, ss_stride);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+// scratch: B * (dim + 3*4*dim) floats
+int k_time_mlp_bwd(const int64_t* t, const float* temb, const float* dts, const float* w1, const float* b1, const float* w2, float* dw1, float* db1,
+                   float* dw2, float* db2, float* scratch, int B, int dim, hipStream_t st) {
+    OFD_CHECK_ARG(dim * 4 <= 1024 && dim <= 256, "time_mlp_bwd: dim %d too large", dim);
+    time_mlp_bwd_sample_kernel<<<B, 256, 0, st>>>(t, w1, b1, w2, temb, dts, scratch, dim);
+    time_mlp_bwd_weight_kernel<<<dim * 4, 256, 0, st>>>(scratch, dw1, db1, dw2, db2, B, dim);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

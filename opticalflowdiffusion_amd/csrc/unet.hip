@@ -2,91 +2,13 @@
 // sequence of HIP launches on the caller's stream.  Parameters keep the reference's state-dict
 // names and order (denoising_diffusion.py:272-361; registration order downs, ups, mid).
 // Host code only: every kernel lives in conv_igemm.hip / blocks.hip.
-#include <map>
-#include <string>
-#include <vector>
-#include "blocks.h"
-
-namespace ofd {
-
-struct Param {
-    std::string name;
-    int ndim;
-    int shape[4];
-    size_t numel;
-    size_t offset;   // floats into d_params (16-byte aligned)
-    bool set;
-};
-
-struct ConvDesc {
-    std::string wname;   // "<prefix>.weight"
-    int Cout, Cin, Cin_pad, ksize;
-    float ws_eps;        // < 0: plain conv
-    int unshuffle;
-    size_t w_off;        // bf16 elements into d_wbuf
-};
-
-struct Tensor {
-    bf16_t* p = nullptr;
-    int C = 0, H = 0, W = 0;
-};
-
-enum ProfClass { PC_CONV3 = 0, PC_CONV3_64, PC_CONV3_PP, PC_CONV1, PC_CONV7, PC_GN, PC_RESOUT, PC_LN, PC_LINATTN, PC_FLASH, PC_MISC, PC_COUNT };
-static const char* kProfNames[PC_COUNT] = {"conv_igemm_kernel<3,128>", "conv_igemm_kernel<3,64>", "conv3x3_c64_pingpong_kernel", "conv1x1_igemm", "conv7x7_igemm", "gn_finalize", "resblock_out",
-                                           "layernorm_c", "linear_attention_core", "flash_attention_d32", "misc"};
-
-struct ProfRec {
-    int cls;
-    hipEvent_t e0, e1;
-    double flops, bytes;
-    std::string label;
-};
-
-}  // namespace ofd
+#include "unet_exec.h"
 
 using namespace ofd;
 
-struct ofd_unet {
-    ofd_unet_config cfg;
-    std::vector<int> dims;        // [dim, dim*1, dim*2, dim*4, dim*8]
-    std::vector<Param> params;
-    std::map<std::string, int> pindex;
-    std::vector<ConvDesc> convs;
-    std::map<std::string, int> cindex;
-    std::vector<std::string> resblocks;       // names in forward order
-    std::map<std::string, int> ss_offset;     // resblock -> offset in the scale/shift row
-    int ss_stride = 0;
-    float* d_params = nullptr;
-    size_t n_param_floats = 0;
-    bf16_t* d_wbuf = nullptr;
-    size_t n_wbuf = 0;
-    MlpDesc* d_mlp = nullptr;
-    bf16_t* d_labuf = nullptr;                // fused LinearAttention weights (C <= 128): wq | wkv | wout per block
-    size_t n_labuf = 0;
-    std::map<std::string, std::pair<size_t, int>> la_fused;   // block name -> (offset, C)
-    bool prepared = false;
-    // last forward: taps
-    std::map<std::string, Tensor> taps;
-    int last_B = 0;
-    // profiling
-    bool profiling = false;
-    std::string dump_path;                    // per-launch CSV (class,label,ms,flops,bytes) appended on resolve
-    std::vector<ProfRec> recs;
-    std::vector<hipEvent_t> pool;
-    size_t pool_used = 0;
-    double acc_ms[PC_COUNT] = {0}, acc_flops[PC_COUNT] = {0}, acc_bytes[PC_COUNT] = {0};
-    long long acc_launch[PC_COUNT] = {0};
-
-    const float* P(const std::string& n) const {
-        auto it = pindex.find(n);
-        return it == pindex.end() ? nullptr : d_params + params[it->second].offset;
-    }
-    const bf16_t* CW(const std::string& prefix) const { return d_wbuf + convs[cindex.at(prefix)].w_off; }
-};
-
 namespace ofd {
 
-static float site_eps(const ofd_unet* u, const std::string& site) {
+float site_eps(const ofd_unet* u, const std::string& site) {
     // eps the reference uses at this site (DD:107, DD:122).  eps_mode 0 = fp32 activations
     // everywhere; eps_mode 1 = dtype flow of bf16 autocast: 1e-3 only where the site's input is
     // a bare conv output (see DESIGN.md "Numerics contract").
@@ -183,77 +105,7 @@ static void build_registry(ofd_unet* u) {
     for (auto& kv : u->ss_offset) u->resblocks.push_back(kv.first);
 }
 
-// ------------------------------------------------------------------------------- forward context
-struct Ctx {
-    ofd_unet* u;
-    hipStream_t s;
-    int B;
-    char* persist;
-    size_t persist_cap, persist_used = 0;
-    char* scratch;
-    size_t scratch_cap, scratch_used = 0;
-    float* ss;
-    int rc = OFD_OK;
-
-    void* alloc(char* base, size_t& used, size_t cap, size_t bytes) {
-        bytes = (bytes + 255) / 256 * 256;
-        if (used + bytes > cap) {
-            if (rc == OFD_OK) { set_error("unet_forward: workspace too small"); rc = OFD_ERR_WORKSPACE; }
-            return nullptr;
-        }
-        void* p = base + used;
-        used += bytes;
-        return p;
-    }
-    Tensor keep(int C, int H, int W) {
-        Tensor t;
-        t.p = (bf16_t*)alloc(persist, persist_used, persist_cap, (size_t)B * H * W * C * 2);
-        t.C = C; t.H = H; t.W = W;
-        return t;
-    }
-    Tensor tmp(int C, int H, int W) {
-        Tensor t;
-        t.p = (bf16_t*)alloc(scratch, scratch_used, scratch_cap, (size_t)B * H * W * C * 2);
-        t.C = C; t.H = H; t.W = W;
-        return t;
-    }
-    float* tmpf(size_t n) { return (float*)alloc(scratch, scratch_used, scratch_cap, n * 4); }
-    void reset_scratch() { scratch_used = 0; }
-
-    // profiling bracket
-    void begin(int cls, double flops, double bytes, const std::string& label = std::string()) {
-        if (!u->profiling) return;
-        while (u->pool.size() < u->pool_used + 2) {
-            hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) return;
-            u->pool.push_back(e);
-        }
-        ProfRec r{cls, u->pool[u->pool_used], u->pool[u->pool_used + 1], flops, bytes, label};
-        u->pool_used += 2;
-        hipEventRecord(r.e0, s);
-        u->recs.push_back(r);
-    }
-    void end() {
-        if (!u->profiling || u->recs.empty()) return;
-        hipEventRecord(u->recs.back().e1, s);
-    }
-};
-
-#define RUN(expr)                         \
-    do {                                  \
-        if (c.rc == OFD_OK) {             \
-            int rc__ = (expr);            \
-            if (rc__ != OFD_OK) c.rc = rc__; \
-        }                                 \
-    } while (0)
-
-struct SrcSpec {
-    Tensor t;
-    int upsample = 0;
-    int unshuffle = 0, p1 = 0, p2 = 0;
-};
-
-static void conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& srcs, Tensor out, const float* in_scale,
+void conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& srcs, Tensor out, const float* in_scale,
                  const float* in_shift, const bf16_t* residual, const bf16_t* res_act, const float* res_scale,
                  const float* res_shift, float* gn_partial) {
     if (c.rc != OFD_OK) return;
@@ -298,21 +150,24 @@ static Tensor resblock(Ctx& c, const std::string& name, const std::vector<Tensor
     const size_t np = ofd_conv_gn_partial_count(B, H, W, Cout);
     float* p1 = c.tmpf(np);
     float* p2 = c.tmpf(np);
-    float* a1 = c.tmpf((size_t)B * Cout);
-    float* s1 = c.tmpf((size_t)B * Cout);
-    float* a2 = c.tmpf((size_t)B * Cout);
-    float* s2 = c.tmpf((size_t)B * Cout);
+    // training keeps the folded affines and the statistics for the GroupNorm backward
+    float* a1 = c.train ? c.keepf((size_t)B * Cout) : c.tmpf((size_t)B * Cout);
+    float* s1 = c.train ? c.keepf((size_t)B * Cout) : c.tmpf((size_t)B * Cout);
+    float* a2 = c.train ? c.keepf((size_t)B * Cout) : c.tmpf((size_t)B * Cout);
+    float* s2 = c.train ? c.keepf((size_t)B * Cout) : c.tmpf((size_t)B * Cout);
+    float* st1 = c.train ? c.keepf((size_t)B * 16) : nullptr;
+    float* st2 = c.train ? c.keepf((size_t)B * 16) : nullptr;
     Tensor out = keep_out ? c.keep(Cout, H, W) : c.tmp(Cout, H, W);
     if (c.rc != OFD_OK) return out;
     conv(c, name + ".block1.proj", srcs, h1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, p1);
     c.begin(PC_GN, 0, (double)np * 4);
     RUN(k_gn_finalize(p1, B, H, W, Cout, u->P(name + ".block1.norm.weight"), u->P(name + ".block1.norm.bias"), c.ss, u->ss_stride,
-                      u->ss_offset.at(name), a1, s1, c.s));
+                      u->ss_offset.at(name), a1, s1, c.s, st1));
     c.end();
     SrcSpec hs; hs.t = h1;
     conv(c, name + ".block2.proj", {hs}, h2, a1, s1, nullptr, nullptr, nullptr, nullptr, p2);
     c.begin(PC_GN, 0, (double)np * 4);
-    RUN(k_gn_finalize(p2, B, H, W, Cout, u->P(name + ".block2.norm.weight"), u->P(name + ".block2.norm.bias"), nullptr, 0, 0, a2, s2, c.s));
+    RUN(k_gn_finalize(p2, B, H, W, Cout, u->P(name + ".block2.norm.weight"), u->P(name + ".block2.norm.bias"), nullptr, 0, 0, a2, s2, c.s, st2));
     c.end();
     if (cin != Cout) {
         conv(c, name + ".res_conv", srcs, out, nullptr, nullptr, nullptr, h2.p, a2, s2, nullptr);   // DD:214 fused into the 1x1
@@ -320,6 +175,12 @@ static Tensor resblock(Ctx& c, const std::string& name, const std::vector<Tensor
         c.begin(PC_RESOUT, 0, (double)B * H * W * Cout * 6.0);
         RUN(k_resblock_out(h2.p, a2, s2, in[0].p, out.p, B, H, W, Cout, c.s));
         c.end();
+    }
+    if (c.train) {
+        TapeRec r;
+        r.kind = TK_RES; r.name = name; r.srcs = srcs; r.out = out; r.h1 = h1; r.h2 = h2;
+        r.a1 = a1; r.s1 = s1; r.a2 = a2; r.s2 = s2; r.st1 = st1; r.st2 = st2;
+        u->tape.push_back(r);
     }
     return out;
 }
@@ -329,7 +190,7 @@ static Tensor linattn(Ctx& c, const std::string& name, Tensor x) {
     const int H = x.H, W = x.W, B = c.B, C = x.C, n = H * W;
     const size_t npix = (size_t)B * n;
     auto fit = u->la_fused.find(name);
-    if (fit != u->la_fused.end()) {
+    if (fit != u->la_fused.end() && !c.train) {
         // fused two-pass block (la_fused.hip): no LayerNorm / qkv / head-output tensors in HBM
         const int nparts = la_fused_blocks(n) * 4;
         float* partial = c.tmpf((size_t)B * 4 * nparts * 1088);
@@ -348,7 +209,8 @@ static Tensor linattn(Ctx& c, const std::string& name, Tensor x) {
     Tensor xn = c.tmp(C, H, W), qkv = c.tmp(384, H, W), ao = c.tmp(128, H, W), o2 = c.tmp(C, H, W);
     const int nparts = la_parts(n);
     float* partial = c.tmpf((size_t)B * 4 * nparts * 1088);
-    float* ctx = c.tmpf((size_t)B * 4 * 1024);
+    float* ctx = c.train ? c.keepf((size_t)B * 4 * 1024) : c.tmpf((size_t)B * 4 * 1024);
+    float* ml = c.train ? c.keepf((size_t)B * 4 * 64) : nullptr;
     Tensor y = c.keep(C, H, W);
     if (c.rc != OFD_OK) return y;
     c.begin(PC_LN, 0, (double)npix * C * 4);
@@ -357,13 +219,18 @@ static Tensor linattn(Ctx& c, const std::string& name, Tensor x) {
     SrcSpec s; s.t = xn;
     conv(c, name + ".fn.fn.to_qkv", {s}, qkv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     c.begin(PC_LINATTN, 4.0 * npix * 4 * 32 * 32, (double)npix * (384 + 128 + 128) * 2);
-    RUN(k_linear_attention_core(qkv.p, partial, ctx, ao.p, B, n, c.s));
+    RUN(k_linear_attention_core(qkv.p, partial, ctx, ao.p, B, n, c.s, ml));
     c.end();
     SrcSpec s2; s2.t = ao;
     conv(c, name + ".fn.fn.to_out.0", {s2}, o2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     c.begin(PC_LN, 0, (double)npix * C * 6);
     RUN(k_layernorm_c(o2.p, u->P(name + ".fn.fn.to_out.1.g"), x.p, y.p, npix, C, site_eps(u, name + ".fn.fn.to_out.1"), c.s));
     c.end();
+    if (c.train) {
+        TapeRec r;
+        r.kind = TK_LINATTN; r.name = name; r.x = x; r.xn = xn; r.qkv = qkv; r.ao = ao; r.o2 = o2; r.out = y; r.ctx = ctx; r.ml = ml;
+        u->tape.push_back(r);
+    }
     return y;
 }
 
@@ -371,6 +238,7 @@ static Tensor midattn(Ctx& c, Tensor x) {
     ofd_unet* u = c.u;
     const int H = x.H, W = x.W, B = c.B, C = x.C, n = H * W;
     Tensor xn = c.tmp(C, H, W), qkv = c.tmp(384, H, W), ao = c.tmp(128, H, W);
+    float* lse = c.train ? c.keepf((size_t)B * 4 * n) : nullptr;
     Tensor y = c.keep(C, H, W);
     if (c.rc != OFD_OK) return y;
     const size_t npix = (size_t)B * n;
@@ -380,14 +248,124 @@ static Tensor midattn(Ctx& c, Tensor x) {
     SrcSpec s; s.t = xn;
     conv(c, "mid_attn.fn.fn.to_qkv", {s}, qkv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     c.begin(PC_FLASH, 4.0 * B * 4.0 * (double)n * n * 32, (double)npix * (384 + 128) * 2);
-    RUN(k_flash_attention(qkv.p, ao.p, B, n, c.s));
+    RUN(k_flash_attention(qkv.p, ao.p, B, n, c.s, lse));
     c.end();
     SrcSpec s2; s2.t = ao;
     conv(c, "mid_attn.fn.fn.to_out", {s2}, y, nullptr, nullptr, x.p, nullptr, nullptr, nullptr, nullptr);   // + x (DD:87)
+    if (c.train) {
+        TapeRec r;
+        r.kind = TK_MIDATTN; r.name = "mid_attn"; r.x = x; r.xn = xn; r.qkv = qkv; r.ao = ao; r.out = y; r.lse = lse;
+        u->tape.push_back(r);
+    }
     return y;
 }
 
-static size_t persist_bytes(const ofd_unet* u, int B, int H, int W) {
+// a bare convolution between blocks (init, down / up sampling): recorded for the backward
+static void plain_conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& srcs, Tensor out) {
+    conv(c, prefix, srcs, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (c.train) {
+        TapeRec r;
+        r.kind = TK_CONV; r.name = prefix; r.srcs = srcs; r.out = out;
+        c.u->tape.push_back(r);
+    }
+}
+
+int run_forward(Ctx& c, const float* x, int Cx, const float* cond, int Cc, const int64_t* t, float* out, int H, int W, float* temb,
+                float* temb_silu) {
+    ofd_unet* u = c.u;
+    const int B = c.B, dim = u->cfg.dim;
+    u->taps.clear();
+    u->last_B = B;
+    if (c.train) u->tape.clear();
+    Tensor xin = c.keep(16, H, W);
+    c.begin(PC_MISC, 0, 0);
+    RUN(k_pack_input(x, Cx, cond, cond ? Cc : 0, xin.p, B, H, W, c.s));
+    RUN(k_time_mlp(t, u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"), u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), temb, temb_silu, B, dim, c.s));
+    RUN(k_block_mlp(temb_silu, u->d_mlp, (int)u->resblocks.size(), c.ss, B, dim * 4, u->ss_stride, c.s));
+    c.end();
+    Tensor r = c.keep(dim, H, W);
+    { SrcSpec s; s.t = xin; plain_conv(c, "init_conv", {s}, r); }
+    u->taps["init_conv"] = r;
+
+    Tensor xcur = r;
+    std::vector<Tensor> hs;
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "downs." + std::to_string(i);
+        c.reset_scratch();
+        xcur = resblock(c, p + ".0", {xcur}, u->dims[i]);
+        hs.push_back(xcur);
+        u->taps[p + ".0"] = xcur;
+        c.reset_scratch();
+        Tensor x1 = resblock(c, p + ".1", {xcur}, u->dims[i]);
+        u->taps[p + ".1"] = x1;
+        c.reset_scratch();
+        xcur = linattn(c, p + ".2", x1);
+        hs.push_back(xcur);
+        u->taps[p + ".2"] = xcur;
+        if (i < 3) {
+            Tensor d = c.keep(u->dims[i + 1], xcur.H / 2, xcur.W / 2);
+            std::vector<SrcSpec> srcs;
+            for (int sub = 0; sub < 4; ++sub) { SrcSpec s; s.t = xcur; s.unshuffle = 1; s.p1 = sub >> 1; s.p2 = sub & 1; srcs.push_back(s); }
+            plain_conv(c, p + ".3.1", srcs, d);
+            xcur = d;
+        } else {
+            Tensor d = c.keep(u->dims[i + 1], xcur.H, xcur.W);
+            SrcSpec s; s.t = xcur;
+            plain_conv(c, p + ".3", {s}, d);
+            xcur = d;
+        }
+        u->taps[p + ".3"] = xcur;
+    }
+    c.reset_scratch();
+    xcur = resblock(c, "mid_block1", {xcur}, u->dims[4]);
+    u->taps["mid_block1"] = xcur;
+    c.reset_scratch();
+    xcur = midattn(c, xcur);
+    u->taps["mid_attn"] = xcur;
+    c.reset_scratch();
+    xcur = resblock(c, "mid_block2", {xcur}, u->dims[4]);
+    u->taps["mid_block2"] = xcur;
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "ups." + std::to_string(i);
+        const int co = u->dims[4 - i], ci = u->dims[3 - i];
+        c.reset_scratch();
+        Tensor h = hs.back(); hs.pop_back();
+        xcur = resblock(c, p + ".0", {xcur, h}, co);
+        u->taps[p + ".0"] = xcur;
+        c.reset_scratch();
+        h = hs.back(); hs.pop_back();
+        xcur = resblock(c, p + ".1", {xcur, h}, co);
+        u->taps[p + ".1"] = xcur;
+        c.reset_scratch();
+        xcur = linattn(c, p + ".2", xcur);
+        u->taps[p + ".2"] = xcur;
+        if (i < 3) {
+            Tensor d = c.keep(ci, xcur.H * 2, xcur.W * 2);
+            SrcSpec s; s.t = xcur; s.upsample = 1;
+            plain_conv(c, p + ".3.1", {s}, d);
+            xcur = d;
+        } else {
+            Tensor d = c.keep(ci, xcur.H, xcur.W);
+            SrcSpec s; s.t = xcur;
+            plain_conv(c, p + ".3", {s}, d);
+            xcur = d;
+        }
+        u->taps[p + ".3"] = xcur;
+    }
+    c.reset_scratch();
+    xcur = resblock(c, "final_res_block", {xcur, r}, dim);
+    u->taps["final_res_block"] = xcur;
+    c.begin(PC_MISC, 2.0 * B * H * W * dim * u->cfg.out_dim, (double)B * H * W * (dim * 2 + u->cfg.out_dim * 4));
+    RUN(k_final_conv(xcur.p, u->P("final_conv.weight"), u->P("final_conv.bias"), out, B, H, W, dim, u->cfg.out_dim, c.s));
+    c.end();
+    if (c.train) {
+        u->ts.B = B; u->ts.H = H; u->ts.W = W; u->ts.t = t; u->ts.ss = c.ss; u->ts.temb = temb; u->ts.temb_silu = temb_silu;
+        u->ts.xin = xin; u->ts.r = r; u->ts.xf = xcur; u->ts.persist_used = c.persist_used;
+    }
+    return c.rc;
+}
+
+size_t persist_bytes(const ofd_unet* u, int B, int H, int W) {
     // every kept tensor of the forward: r, 3 per down level, 1 resample per level, mid (3), 3+1 per up level, final
     auto T = [&](int C, int h, int w) { return ((size_t)B * h * w * C * 2 + 255) / 256 * 256; };
     size_t n = T(16, H, W) + T(u->dims[0], H, W);
@@ -408,7 +386,7 @@ static size_t persist_bytes(const ofd_unet* u, int B, int H, int W) {
     return n + 4096;
 }
 
-static size_t scratch_bytes(const ofd_unet* u, int B, int H, int W) {
+size_t scratch_bytes(const ofd_unet* u, int B, int H, int W) {
     // largest per-block need, taken at full resolution with C = dim (the 1/2, 1/4, 1/8 levels
     // have 2x channels on 1/4 of the pixels): h1 + h2 + out(tmp) + xn + qkv + ao + o2 + small
     const size_t px = (size_t)B * H * W;
@@ -420,7 +398,7 @@ static size_t scratch_bytes(const ofd_unet* u, int B, int H, int W) {
     return act + small + 64 * 256;
 }
 
-static size_t small_bytes(const ofd_unet* u, int B) {
+size_t small_bytes(const ofd_unet* u, int B) {
     return ((size_t)B * u->ss_stride + 2 * (size_t)B * u->cfg.dim * 4) * 4 + 4096;
 }
 
@@ -464,6 +442,7 @@ extern "C" void ofd_unet_destroy(ofd_unet* u) {
     if (u->d_wbuf) hipFree(u->d_wbuf);
     if (u->d_mlp) hipFree(u->d_mlp);
     if (u->d_labuf) hipFree(u->d_labuf);
+    if (u->d_wtbuf) hipFree(u->d_wtbuf);
     for (auto e : u->pool) hipEventDestroy(e);
     delete u;
 }
@@ -489,6 +468,7 @@ extern "C" int ofd_unet_set_param(ofd_unet* u, int i, const float* dev_src, size
     OFD_HIP(hipMemcpyAsync(u->d_params + p.offset, dev_src, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     p.set = true;
     u->prepared = false;
+    u->wt_prepared = false;
     return OFD_OK;
 }
 
@@ -512,6 +492,7 @@ extern "C" int ofd_unet_prepare(ofd_unet* u, void* stream) {
         if (rc != OFD_OK) return rc;
     }
     u->prepared = true;
+    u->wt_prepared = false;
     return OFD_OK;
 }
 
@@ -543,92 +524,7 @@ extern "C" int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float
     c.persist_cap = persist_bytes(u, B, H, W);
     c.scratch = c.persist + (c.persist_cap + 255) / 256 * 256;
     c.scratch_cap = workspace_bytes - (size_t)(c.scratch - w);
-    u->taps.clear();
-    u->last_B = B;
-    const int dim = u->cfg.dim;
-
-    Tensor xin = c.keep(16, H, W);
-    c.begin(PC_MISC, 0, 0);
-    RUN(k_pack_input(x, Cx, cond, cond ? Cc : 0, xin.p, B, H, W, c.s));
-    RUN(k_time_mlp(t, u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"), u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), temb, temb_silu, B, dim, c.s));
-    RUN(k_block_mlp(temb_silu, u->d_mlp, (int)u->resblocks.size(), c.ss, B, dim * 4, u->ss_stride, c.s));
-    c.end();
-    Tensor r = c.keep(dim, H, W);
-    { SrcSpec s; s.t = xin; conv(c, "init_conv", {s}, r, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr); }
-    u->taps["init_conv"] = r;
-
-    Tensor xcur = r;
-    std::vector<Tensor> hs;
-    for (int i = 0; i < 4; ++i) {
-        const std::string p = "downs." + std::to_string(i);
-        c.reset_scratch();
-        xcur = resblock(c, p + ".0", {xcur}, u->dims[i]);
-        hs.push_back(xcur);
-        u->taps[p + ".0"] = xcur;
-        c.reset_scratch();
-        Tensor x1 = resblock(c, p + ".1", {xcur}, u->dims[i]);
-        u->taps[p + ".1"] = x1;
-        c.reset_scratch();
-        xcur = linattn(c, p + ".2", x1);
-        hs.push_back(xcur);
-        u->taps[p + ".2"] = xcur;
-        if (i < 3) {
-            Tensor d = c.keep(u->dims[i + 1], xcur.H / 2, xcur.W / 2);
-            std::vector<SrcSpec> srcs;
-            for (int sub = 0; sub < 4; ++sub) { SrcSpec s; s.t = xcur; s.unshuffle = 1; s.p1 = sub >> 1; s.p2 = sub & 1; srcs.push_back(s); }
-            conv(c, p + ".3.1", srcs, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-            xcur = d;
-        } else {
-            Tensor d = c.keep(u->dims[i + 1], xcur.H, xcur.W);
-            SrcSpec s; s.t = xcur;
-            conv(c, p + ".3", {s}, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-            xcur = d;
-        }
-        u->taps[p + ".3"] = xcur;
-    }
-    c.reset_scratch();
-    xcur = resblock(c, "mid_block1", {xcur}, u->dims[4]);
-    u->taps["mid_block1"] = xcur;
-    c.reset_scratch();
-    xcur = midattn(c, xcur);
-    u->taps["mid_attn"] = xcur;
-    c.reset_scratch();
-    xcur = resblock(c, "mid_block2", {xcur}, u->dims[4]);
-    u->taps["mid_block2"] = xcur;
-    for (int i = 0; i < 4; ++i) {
-        const std::string p = "ups." + std::to_string(i);
-        const int co = u->dims[4 - i], ci = u->dims[3 - i];
-        c.reset_scratch();
-        Tensor h = hs.back(); hs.pop_back();
-        xcur = resblock(c, p + ".0", {xcur, h}, co);
-        u->taps[p + ".0"] = xcur;
-        c.reset_scratch();
-        h = hs.back(); hs.pop_back();
-        xcur = resblock(c, p + ".1", {xcur, h}, co);
-        u->taps[p + ".1"] = xcur;
-        c.reset_scratch();
-        xcur = linattn(c, p + ".2", xcur);
-        u->taps[p + ".2"] = xcur;
-        if (i < 3) {
-            Tensor d = c.keep(ci, xcur.H * 2, xcur.W * 2);
-            SrcSpec s; s.t = xcur; s.upsample = 1;
-            conv(c, p + ".3.1", {s}, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-            xcur = d;
-        } else {
-            Tensor d = c.keep(ci, xcur.H, xcur.W);
-            SrcSpec s; s.t = xcur;
-            conv(c, p + ".3", {s}, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-            xcur = d;
-        }
-        u->taps[p + ".3"] = xcur;
-    }
-    c.reset_scratch();
-    xcur = resblock(c, "final_res_block", {xcur, r}, dim);
-    u->taps["final_res_block"] = xcur;
-    c.begin(PC_MISC, 2.0 * B * H * W * dim * u->cfg.out_dim, (double)B * H * W * (dim * 2 + u->cfg.out_dim * 4));
-    RUN(k_final_conv(xcur.p, u->P("final_conv.weight"), u->P("final_conv.bias"), out, B, H, W, dim, u->cfg.out_dim, c.s));
-    c.end();
-    return c.rc;
+    return run_forward(c, x, Cx, cond, Cc, t, out, H, W, temb, temb_silu);
 }
 
 extern "C" int ofd_unet_read_tap(ofd_unet* u, const char* name, float* dst, size_t numel, void* stream) {

@@ -1,0 +1,216 @@
+// Shared declarations of the UNet executor (unet.hip: registry + inference forward; unet_train.hip:
+// training forward tape + backward).  Host code only.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include "blocks.h"
+
+namespace ofd {
+
+struct Param {
+    std::string name;
+    int ndim;
+    int shape[4];
+    size_t numel;
+    size_t offset;   // floats into d_params (16-byte aligned)
+    bool set;
+};
+
+struct ConvDesc {
+    std::string wname;   // "<prefix>.weight"
+    int Cout, Cin, Cin_pad, ksize;
+    float ws_eps;        // < 0: plain conv
+    int unshuffle;
+    size_t w_off;        // bf16 elements into d_wbuf
+};
+
+struct Tensor {
+    bf16_t* p = nullptr;
+    int C = 0, H = 0, W = 0;
+    bf16_t* g = nullptr;     // gradient buffer (training forward only)
+};
+
+enum ProfClass { PC_CONV3 = 0, PC_CONV3_64, PC_CONV3_PP, PC_CONV1, PC_CONV7, PC_GN, PC_RESOUT, PC_LN, PC_LINATTN, PC_FLASH, PC_MISC, PC_WGRAD3, PC_WGRAD1, PC_DGRAD3, PC_DGRAD1, PC_GNBWD, PC_LABWD, PC_FLASHBWD, PC_COUNT };
+static const char* const kProfNames[PC_COUNT] = {"conv_igemm_kernel<3,128>", "conv_igemm_kernel<3,64>", "conv3x3_c64_pingpong_kernel", "conv1x1_igemm", "conv7x7_igemm", "gn_finalize", "resblock_out",
+                                           "layernorm_c", "linear_attention_core", "flash_attention_d32", "misc", "conv_wgrad_kernel<3>", "conv_wgrad_kernel<1>",
+                                           "conv3x3_dgrad", "conv1x1_dgrad", "gn_silu_backward", "linear_attention_backward", "flash_attention_backward"};
+
+struct ProfRec {
+    int cls;
+    hipEvent_t e0, e1;
+    double flops, bytes;
+    std::string label;
+};
+
+
+struct SrcSpec {
+    Tensor t;
+    int upsample = 0;
+    int unshuffle = 0, p1 = 0, p2 = 0;
+};
+
+// one record per composite op of the training forward, replayed in reverse by the backward
+enum TapeKind { TK_CONV = 0, TK_RES, TK_LINATTN, TK_MIDATTN };
+struct TapeRec {
+    int kind = TK_CONV;
+    std::string name;
+    std::vector<SrcSpec> srcs;       // conv / resblock inputs
+    Tensor out, h1, h2, xn, qkv, ao, o2, x;
+    float *a1 = nullptr, *s1 = nullptr, *a2 = nullptr, *s2 = nullptr, *st1 = nullptr, *st2 = nullptr;
+    float *ctx = nullptr, *ml = nullptr, *lse = nullptr;
+};
+
+struct TrainState {                  // what the backward needs from the last training forward
+    bool valid = false;
+    int B = 0, H = 0, W = 0;
+    char* workspace = nullptr;
+    size_t workspace_bytes = 0;
+    const int64_t* t = nullptr;
+    float *ss = nullptr, *temb = nullptr, *temb_silu = nullptr;
+    Tensor xin, r, xf;
+    size_t persist_used = 0;
+};
+
+}  // namespace ofd
+
+using namespace ofd;
+
+struct ofd_unet {
+    ofd_unet_config cfg;
+    std::vector<int> dims;        // [dim, dim*1, dim*2, dim*4, dim*8]
+    std::vector<Param> params;
+    std::map<std::string, int> pindex;
+    std::vector<ConvDesc> convs;
+    std::map<std::string, int> cindex;
+    std::vector<std::string> resblocks;       // names in forward order
+    std::map<std::string, int> ss_offset;     // resblock -> offset in the scale/shift row
+    int ss_stride = 0;
+    float* d_params = nullptr;
+    size_t n_param_floats = 0;
+    bf16_t* d_wbuf = nullptr;
+    size_t n_wbuf = 0;
+    MlpDesc* d_mlp = nullptr;
+    bf16_t* d_labuf = nullptr;                // fused LinearAttention weights (C <= 128): wq | wkv | wout per block
+    size_t n_labuf = 0;
+    std::map<std::string, std::pair<size_t, int>> la_fused;   // block name -> (offset, C)
+    bool prepared = false;
+    // training (unet_train.hip): fp32 gradients laid out like d_params, tap-flipped transposed conv
+    // weights for the data gradients, the tape of the last training forward
+    float* d_grads = nullptr;            // bound by the caller (ofd_unet_bind_grad_buffer), not owned
+    std::map<std::string, std::pair<size_t, size_t>> prange;   // op prefix -> [begin, end) floats of its parameters
+    bf16_t* d_wtbuf = nullptr;
+    bool wt_prepared = false;
+    std::vector<TapeRec> tape;
+    TrainState ts;
+    // last forward: taps
+    std::map<std::string, Tensor> taps;
+    int last_B = 0;
+    // profiling
+    bool profiling = false;
+    std::string dump_path;                    // per-launch CSV (class,label,ms,flops,bytes) appended on resolve
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;
+    double acc_ms[PC_COUNT] = {0}, acc_flops[PC_COUNT] = {0}, acc_bytes[PC_COUNT] = {0};
+    long long acc_launch[PC_COUNT] = {0};
+
+    const float* P(const std::string& n) const {
+        auto it = pindex.find(n);
+        return it == pindex.end() ? nullptr : d_params + params[it->second].offset;
+    }
+    const bf16_t* CW(const std::string& prefix) const { return d_wbuf + convs[cindex.at(prefix)].w_off; }
+    float* G(const std::string& n) const {
+        auto it = pindex.find(n);
+        return (it == pindex.end() || !d_grads) ? nullptr : d_grads + params[it->second].offset;
+    }
+};
+
+
+namespace ofd {
+
+// ------------------------------------------------------------------------------- forward context
+struct Ctx {
+    ofd_unet* u;
+    hipStream_t s;
+    int B;
+    char* persist;
+    size_t persist_cap, persist_used = 0;
+    char* scratch;
+    size_t scratch_cap, scratch_used = 0;
+    float* ss;
+    int rc = OFD_OK;
+    bool train = false;              // keep every intermediate and record the tape
+    bool dry = false;                // size planning: allocate and count, launch nothing
+    size_t grad_offset = 0;          // bytes from an activation to its gradient buffer (training)
+    size_t scratch_high = 0;
+
+    void* alloc(char* base, size_t& used, size_t cap, size_t bytes) {
+        bytes = (bytes + 255) / 256 * 256;
+        if (used + bytes > cap) {
+            if (rc == OFD_OK) { set_error("unet_forward: workspace too small"); rc = OFD_ERR_WORKSPACE; }
+            return nullptr;
+        }
+        void* p = base + used;
+        used += bytes;
+        if (base == scratch && used > scratch_high) scratch_high = used;
+        return p;
+    }
+    Tensor keep(int C, int H, int W) {
+        Tensor t;
+        t.p = (bf16_t*)alloc(persist, persist_used, persist_cap, (size_t)B * H * W * C * 2);
+        t.C = C; t.H = H; t.W = W;
+        if (train && t.p) t.g = (bf16_t*)((char*)t.p + grad_offset);
+        return t;
+    }
+    float* keepf(size_t n) { return (float*)alloc(persist, persist_used, persist_cap, n * 4); }
+    Tensor tmp(int C, int H, int W) {
+        if (train) return keep(C, H, W);
+        Tensor t;
+        t.p = (bf16_t*)alloc(scratch, scratch_used, scratch_cap, (size_t)B * H * W * C * 2);
+        t.C = C; t.H = H; t.W = W;
+        return t;
+    }
+    float* tmpf(size_t n) { return (float*)alloc(scratch, scratch_used, scratch_cap, n * 4); }
+    void reset_scratch() { scratch_used = 0; }
+
+    // profiling bracket
+    void begin(int cls, double flops, double bytes, const std::string& label = std::string()) {
+        if (!u->profiling || dry) return;
+        while (u->pool.size() < u->pool_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            u->pool.push_back(e);
+        }
+        ProfRec r{cls, u->pool[u->pool_used], u->pool[u->pool_used + 1], flops, bytes, label};
+        u->pool_used += 2;
+        hipEventRecord(r.e0, s);
+        u->recs.push_back(r);
+    }
+    void end() {
+        if (!u->profiling || dry || u->recs.empty()) return;
+        hipEventRecord(u->recs.back().e1, s);
+    }
+};
+
+#define RUN(expr)                         \
+    do {                                  \
+        if (c.rc == OFD_OK && !c.dry) {   \
+            int rc__ = (expr);            \
+            if (rc__ != OFD_OK) c.rc = rc__; \
+        }                                 \
+    } while (0)
+
+
+
+float site_eps(const ofd_unet* u, const std::string& site);
+void conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& srcs, Tensor out, const float* in_scale, const float* in_shift,
+          const bf16_t* residual, const bf16_t* res_act, const float* res_scale, const float* res_shift, float* gn_partial);
+size_t persist_bytes(const ofd_unet* u, int B, int H, int W);
+size_t scratch_bytes(const ofd_unet* u, int B, int H, int W);
+size_t small_bytes(const ofd_unet* u, int B);
+// the whole forward (DD:363-417) on an initialised context; fills u->taps (and u->tape / u->ts when c.train)
+int run_forward(Ctx& c, const float* x, int Cx, const float* cond, int Cc, const int64_t* t, float* out, int H, int W,
+                float* temb, float* temb_silu);
+
+}  // namespace ofd

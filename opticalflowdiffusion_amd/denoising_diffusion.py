@@ -53,6 +53,23 @@ def _registry(dim, channels, out_dim, eps_mode):
     return h, names
 
 
+class _UnetTrain(torch.autograd.Function):
+    """Unet.forward under autograd: the HIP training forward keeps the tape inside the executor's
+    workspace, backward() replays it and hands the parameter gradients back as views of the
+    executor's flat gradient buffer (already all-reduced when a grad_sync is attached)."""
+
+    @staticmethod
+    def forward(ctx, unet, x, cond, t, *params):
+        ctx.unet = unet
+        ctx.ticket = unet._train_forward(x, cond, t)
+        return unet._train_out
+
+    @staticmethod
+    def backward(ctx, gout):
+        grads = ctx.unet._backward(ctx.ticket, gout)
+        return (None, None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[4:]))
+
+
 class Unet(nn.Module):
     """DD:272-417.  Supported: dim=64, dim_mults=(1,2,4,8), time_in=True, no self-conditioning --
     the UNet FlowDiffuser instantiates (FD:106-111)."""
@@ -84,6 +101,10 @@ class Unet(nn.Module):
             self._add(name, nn.Parameter(self._init(name, shape, gen, fan_in)))
         self._synced = {}
         self._ws = None
+        self._train_ws = None
+        self._gflat = None
+        self._ticket = 0
+        self.grad_sync = None          # parallel.BucketedAllReduce for data-parallel training (or None)
 
     # -- parameter tree ----------------------------------------------------------------------
     def _add(self, name, param):
@@ -150,11 +171,12 @@ class Unet(nn.Module):
         if time is None:
             raise ValueError("when Unet takes time arg, time argument must be passed in")  # DD:378-379
         L.require_gpu(x, external_cond, time)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise L.OfdError("Unet.forward under autograd: the HIP backward pass is not part of this build; "
-                             "wrap inference/sampling in torch.no_grad()")
+        if x.requires_grad or (external_cond is not None and external_cond.requires_grad):
+            raise L.OfdError("Unet.forward: gradients w.r.t. the inputs are not produced (the training step never needs them)")
         x = L.f32c(x)
         cond = L.f32c(external_cond) if external_cond is not None else None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _UnetTrain.apply(self, x, cond, time.to(torch.int64).contiguous(), *[self._param(n) for n in self._names])
         B, Cx, H, W = x.shape
         Cc = cond.shape[1] if cond is not None else 0
         t = time.to(torch.int64).contiguous()
@@ -164,6 +186,70 @@ class Unet(nn.Module):
         L.check(L.lib().ofd_unet_forward(self._handle, L.ptr(x), Cx, L.ptr(cond), Cc, L.ptr(t), L.ptr(out), B, H, W,
                                          L.ptr(ws), ws.numel(), L.stream()))
         return out
+
+    # -- training step (ofd_unet_train_forward / ofd_unet_backward) -------------------------------
+    def flat_grads(self, device=None):
+        """the flat fp32 gradient buffer the executor writes (parameter i at [offset_i, offset_i + numel_i))."""
+        lib = L.lib()
+        if self._gflat is None or (device is not None and self._gflat.device != device):
+            if device is None:
+                raise L.OfdError("no gradient buffer yet: run a training forward first")
+            self._gflat = torch.zeros(lib.ofd_unet_param_floats(self._handle), dtype=torch.float32, device=device)
+            L.check(lib.ofd_unet_bind_grad_buffer(self._handle, L.ptr(self._gflat), self._gflat.numel()))
+            self._goffsets = [lib.ofd_unet_param_offset(self._handle, i) for i in range(len(self._names))]
+        return self._gflat
+
+    def _train_forward(self, x, cond, t):
+        lib = L.lib()
+        B, Cx, H, W = x.shape
+        Cc = cond.shape[1] if cond is not None else 0
+        self._sync_params(x.device)
+        self.flat_grads(x.device)
+        need = lib.ofd_unet_train_workspace_bytes(self._handle, B, H, W)
+        if need == 0:
+            raise L.OfdError(f"training workspace planning failed for B={B} H={H} W={W}: {L.last_error()}")
+        if self._train_ws is None or self._train_ws.numel() < need or self._train_ws.device != x.device:
+            self._train_ws = None
+            self._train_ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        out = torch.empty(B, self.out_dim, H, W, dtype=torch.float32, device=x.device)
+        L.check(lib.ofd_unet_train_forward(self._handle, L.ptr(x), Cx, L.ptr(cond), Cc, L.ptr(t), L.ptr(out), B, H, W,
+                                           L.ptr(self._train_ws), self._train_ws.numel(), L.stream()))
+        self._train_t = t                  # the backward re-reads the timesteps
+        self._train_out = out
+        self._ticket += 1
+        return self._ticket
+
+    def _backward(self, ticket, gout):
+        if ticket != self._ticket:
+            raise L.OfdError("Unet backward: the tape belongs to an older forward (one training forward per backward; "
+                             "retain_graph / double backward are not supported)")
+        lib = L.lib()
+        flat = self.flat_grads()
+        gout = L.f32c(gout)
+        sync, err = self.grad_sync, []
+
+        def ready(begin, end, _user):
+            try:
+                if sync is not None:
+                    sync.on_range(flat, begin, end)
+            except BaseException as e:      # must not propagate through the C frame
+                err.append(e)
+
+        cb = L.GRAD_READY(ready)
+        if sync is not None:
+            sync.begin(flat)
+        L.check(lib.ofd_unet_backward(self._handle, L.ptr(gout), cb, None, L.stream()))
+        if err:
+            raise err[0]
+        if sync is not None:
+            sync.finish(flat)
+        self._ticket += 1                   # tape consumed
+        grads = []
+        for i, name in enumerate(self._names):
+            p = self._param(name)
+            off = self._goffsets[i]
+            grads.append(flat[off:off + p.numel()].view(p.shape))
+        return grads
 
     def read_tap(self, name, shape):
         """named intermediate of the last forward as NCHW fp32 (parity tests)."""

@@ -112,15 +112,34 @@ def warp(first, second, flow, rep="flow", mode="backward", **kwargs):
     raise ValueError(f"unknown warp mode {mode!r}")
 
 
-def nan_mse(pred, target, reduction="mean"):
-    """WP:260-271.  reduction='mean' runs the fused HIP reduction; 'none' returns the compacted
-    squared errors (dynamic shape, as the reference)."""
-    if reduction == "mean" and not (pred.requires_grad or target.requires_grad):
-        L.require_gpu(pred, target)
-        p, t = L.f32c(pred).flatten(), L.f32c(target).flatten()
+class _NanMseMean(torch.autograd.Function):
+    """nanmean of the masked squared error and its gradient w.r.t. the prediction (the training loss,
+    DD:908,973)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        p, t = L.f32c(pred).reshape(-1), L.f32c(target).reshape(-1)
         res = torch.empty(2, dtype=torch.float64, device=p.device)
         L.check(L.lib().ofd_nan_mse_sum(L.ptr(p), L.ptr(t), p.numel(), L.ptr(res), L.stream()))
+        ctx.save_for_backward(p, t, res)
+        ctx.shape = pred.shape
         return (res[0] / res[1]).float()
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, t, res = ctx.saved_tensors
+        g = L.f32c(gout).reshape(1)
+        dp = torch.empty_like(p)
+        L.check(L.lib().ofd_nan_mse_grad(L.ptr(p), L.ptr(t), p.numel(), L.ptr(res), L.ptr(g), L.ptr(dp), L.stream()))
+        return dp.view(ctx.shape), None
+
+
+def nan_mse(pred, target, reduction="mean"):
+    """WP:260-271.  reduction='mean' runs the fused HIP reduction (differentiable w.r.t. pred);
+    'none' returns the compacted squared errors (dynamic shape, as the reference)."""
+    if reduction == "mean" and not target.requires_grad:
+        L.require_gpu(pred, target)
+        return _NanMseMean.apply(pred, target)
     pred, target = pred.flatten(), target.flatten()
     ok = torch.logical_not(torch.logical_or(torch.isnan(target), torch.isnan(pred)))
     sq = torch.square(pred[ok] - target[ok])

@@ -280,3 +280,48 @@ def test_flash_attention_backward(L, B, n):
     for i, nm in enumerate("qkv"):
         e = rel_l2(got[:, 128 * i:128 * (i + 1)], qkv.grad[:, 128 * i:128 * (i + 1)])
         assert e < 2e-2, f"d{nm}: {e:.3e}"
+
+
+def test_unet_training_step_gradients(L):
+    """End to end: loss.backward() through the HIP training executor vs autograd on the oracle UNet
+    (bf16c contract) with the same parameters -- every one of the 276 parameter gradients."""
+    from opticalflowdiffusion_amd import Unet
+    from opticalflowdiffusion_amd.warp import nan_mse
+    torch.manual_seed(7)
+    B, H, W = 2, 32, 48
+    net = Unet(64, channels=5, out_dim=2).cuda()
+    x = torch.randn(B, 2, H, W)
+    cond = torch.rand(B, 3, H, W) * 2 - 1
+    t = torch.tensor([17, 803])
+    target = torch.randn(B, 2, H, W)
+    target[0, :, 3:5, 7:9] = float("nan")
+    out = net(x.cuda(), external_cond=cond.cuda(), time=t.cuda())
+    loss = nan_mse(out, target.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    # inference forward is the same function
+    with torch.no_grad():
+        out_inf = net(x.cuda(), external_cond=cond.cuda(), time=t.cuda())
+    assert rel_l2(out.detach().cpu(), out_inf.cpu()) < 2e-2      # (inference fuses LinearAttention: other roundings)
+    # oracle autograd
+    P = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in net.named_parameters()}
+    ref = R.unet_forward(P, x, cond, t, mode="bf16c")
+    assert rel_l2(out.detach().cpu(), ref.detach()) < 2e-2
+    ok = ~torch.isnan(target)
+    ref_loss = ((ref - torch.nan_to_num(target)) ** 2)[ok].mean()
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item())
+    worst = []
+    for n, p in net.named_parameters():
+        assert p.grad is not None, n
+        e = rel_l2(p.grad.cpu(), P[n].grad)
+        worst.append((e, n))
+    worst.sort(reverse=True)
+    print("worst parameter-gradient errors:", [(f"{e:.3e}", n) for e, n in worst[:8]])
+    bad = [(e, n) for e, n in worst if e > 5e-2]
+    assert not bad, bad
+    # global direction: cosine of the flattened gradients
+    g1 = torch.cat([p.grad.flatten().cpu() for _, p in net.named_parameters()])
+    g2 = torch.cat([P[n].grad.flatten() for n, _ in net.named_parameters()])
+    cos = torch.dot(g1, g2) / (g1.norm() * g2.norm())
+    assert cos > 0.999, cos
