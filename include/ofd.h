@@ -136,6 +136,10 @@ int ofd_unet_param_shape(const ofd_unet* u, int i, int* dims4);   /* returns ndi
 /* copy fp32 parameter i from a device buffer (reference layout, e.g. OIHW) into the engine */
 int ofd_unet_set_param(ofd_unet* u, int i, const float* dev_src, size_t numel, void* stream);
 /* weight standardisation + bf16 re-layout of everything set so far; call after set_param */
+/* Zero-copy alternative to ofd_unet_set_param: the executor reads its parameters from the caller's flat fp32
+ * device buffer (parameter i at floats [ofd_unet_param_offset(i), +numel), ofd_unet_param_floats in all; 16-byte
+ * aligned, must outlive the handle or the next bind).  Call ofd_unet_prepare again whenever its contents change. */
+int ofd_unet_bind_param_buffer(ofd_unet* u, float* dev_params, size_t floats);
 int ofd_unet_prepare(ofd_unet* u, void* stream);
 size_t ofd_unet_workspace_bytes(const ofd_unet* u, int B, int H, int W);
 /* x: (B,Cx,H,W) fp32, cond: (B,Cc,H,W) fp32 or NULL (Cx+Cc == channels), t: (B,) int64,

@@ -63,6 +63,7 @@ SIGNATURES = {
     "ofd_unet_param_numel": (c_size_t, [c_void_p, c_int]),
     "ofd_unet_param_shape": (c_int, [c_void_p, c_int, ctypes.POINTER(c_int)]),
     "ofd_unet_set_param": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "ofd_unet_bind_param_buffer": (c_int, [c_void_p, c_void_p, c_size_t]),
     "ofd_unet_prepare": (c_int, [c_void_p, c_void_p]),
     "ofd_unet_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "ofd_unet_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,

@@ -404,6 +404,33 @@ size_t small_bytes(const ofd_unet* u, int B) {
 
 }  // namespace ofd
 
+static void upload_mlp_descs(ofd_unet* u) {
+    std::vector<MlpDesc> descs;
+    for (auto& name : u->resblocks) {
+        MlpDesc d;
+        d.weight = u->P(name + ".mlp.1.weight");
+        d.bias = u->P(name + ".mlp.1.bias");
+        d.n_out = (int)u->params[u->pindex.at(name + ".mlp.1.bias")].numel;
+        d.offset = u->ss_offset.at(name);
+        descs.push_back(d);
+    }
+    hipMemcpy(u->d_mlp, descs.data(), descs.size() * sizeof(MlpDesc), hipMemcpyHostToDevice);
+}
+
+extern "C" int ofd_unet_bind_param_buffer(ofd_unet* u, float* dev_params, size_t floats) {
+    OFD_CHECK_ARG(u && dev_params, "unet_bind_param_buffer: null argument");
+    OFD_CHECK_ARG(floats >= u->n_param_floats, "unet_bind_param_buffer: %zu floats, need %zu", floats, u->n_param_floats);
+    OFD_CHECK_ARG(((uintptr_t)dev_params & 15) == 0, "unet_bind_param_buffer: buffer must be 16-byte aligned");
+    if (u->owns_params && u->d_params) hipFree(u->d_params);
+    u->d_params = dev_params;
+    u->owns_params = false;
+    for (auto& p : u->params) p.set = true;          // the caller's buffer holds every parameter
+    upload_mlp_descs(u);
+    u->prepared = false;
+    u->wt_prepared = false;
+    return OFD_OK;
+}
+
 extern "C" int ofd_unet_create(const ofd_unet_config* cfg, ofd_unet** out) {
     OFD_CHECK_ARG(cfg && out, "unet_create: null argument");
     OFD_CHECK_ARG(cfg->dim == 64, "unet_create: dim=%d unsupported (the FlowDiffuser UNet is Unet(64), flow_diffuser.py:106)", cfg->dim);
@@ -422,23 +449,14 @@ extern "C" int ofd_unet_create(const ofd_unet_config* cfg, ofd_unet** out) {
         return OFD_ERR_HIP;
     }
     hipMemset(u->d_params, 0, u->n_param_floats * sizeof(float));
-    std::vector<MlpDesc> descs;
-    for (auto& name : u->resblocks) {
-        MlpDesc d;
-        d.weight = u->P(name + ".mlp.1.weight");
-        d.bias = u->P(name + ".mlp.1.bias");
-        d.n_out = (int)u->params[u->pindex.at(name + ".mlp.1.bias")].numel;
-        d.offset = u->ss_offset.at(name);
-        descs.push_back(d);
-    }
-    hipMemcpy(u->d_mlp, descs.data(), descs.size() * sizeof(MlpDesc), hipMemcpyHostToDevice);
+    upload_mlp_descs(u);
     *out = u;
     return OFD_OK;
 }
 
 extern "C" void ofd_unet_destroy(ofd_unet* u) {
     if (!u) return;
-    if (u->d_params) hipFree(u->d_params);
+    if (u->d_params && u->owns_params) hipFree(u->d_params);
     if (u->d_wbuf) hipFree(u->d_wbuf);
     if (u->d_mlp) hipFree(u->d_mlp);
     if (u->d_labuf) hipFree(u->d_labuf);

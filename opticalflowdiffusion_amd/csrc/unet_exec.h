@@ -87,6 +87,7 @@ struct ofd_unet {
     std::map<std::string, int> ss_offset;     // resblock -> offset in the scale/shift row
     int ss_stride = 0;
     float* d_params = nullptr;
+    bool owns_params = true;                  // false once the caller bound its own flat buffer
     size_t n_param_floats = 0;
     bf16_t* d_wbuf = nullptr;
     size_t n_wbuf = 0;

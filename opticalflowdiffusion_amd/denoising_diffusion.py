@@ -99,7 +99,9 @@ class Unet(nn.Module):
                 for s_ in shape[1:]:
                     fan_in *= s_
             self._add(name, nn.Parameter(self._init(name, shape, gen, fan_in)))
-        self._synced = {}
+        self._synced = None
+        self._pflat = None
+        self._poffsets = None
         self._ws = None
         self._train_ws = None
         self._gflat = None
@@ -143,20 +145,32 @@ class Unet(nn.Module):
 
     # -- execution ---------------------------------------------------------------------------
     def _sync_params(self, device):
+        """The executor reads the parameters in place: every nn.Parameter is a view of one flat fp32 device
+        tensor laid out like the executor's registry (bound once, zero copies per step).  Whenever a
+        parameter's version changed (optimizer step, load_state_dict, manual edit) only the weight
+        preparation (standardise + bf16 pack) is re-run."""
         lib = L.lib()
-        dirty = False
-        for i, name in enumerate(self._names):
-            p = self._param(name)
-            key = (p.data_ptr(), p._version, str(p.device))
-            if self._synced.get(name) != key:
-                src = p.detach()
-                if src.device != device or src.dtype != torch.float32 or not src.is_contiguous():
-                    src = src.to(device=device, dtype=torch.float32).contiguous()
-                L.check(lib.ofd_unet_set_param(self._handle, i, L.ptr(src), src.numel(), L.stream()))
-                self._synced[name] = key      # (a temporary `src` is safe to drop: same-stream ordering)
-                dirty = True
-        if dirty:
+        params = [self._param(n) for n in self._names]
+        if self._poffsets is None:
+            self._poffsets = [lib.ofd_unet_param_offset(self._handle, i) for i in range(len(self._names))]
+        flat = self._pflat
+        intact = flat is not None and flat.device == device
+        if intact:
+            base = flat.data_ptr()
+            intact = all(p.data_ptr() == base + 4 * off and p.dtype == torch.float32 for p, off in zip(params, self._poffsets))
+        if not intact:
+            flat = torch.zeros(lib.ofd_unet_param_floats(self._handle), dtype=torch.float32, device=device)
+            for p, off in zip(params, self._poffsets):
+                view = flat[off:off + p.numel()].view(p.shape)
+                view.copy_(p.detach())
+                p.data = view
+            self._pflat = flat
+            L.check(lib.ofd_unet_bind_param_buffer(self._handle, L.ptr(flat), flat.numel()))
+            self._synced = None
+        key = tuple(p._version for p in params)
+        if self._synced != key:
             L.check(lib.ofd_unet_prepare(self._handle, L.stream()))
+            self._synced = key
 
     def _workspace(self, device, B, H, W):
         need = L.lib().ofd_unet_workspace_bytes(self._handle, B, H, W)

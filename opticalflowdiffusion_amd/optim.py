@@ -69,5 +69,6 @@ class FusedAdam(torch.optim.Optimizer):
                                           float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), step, L.stream()))
             for p in params:
                 self.state[p]["step"] = step
+            torch.autograd.graph.increment_version(params)      # written through raw pointers: tell torch (and Unet's cache)
             self.last_grad_norm = tab["norm"]
         return loss

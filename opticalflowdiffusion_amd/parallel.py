@@ -58,3 +58,94 @@ def max_over_ranks(seconds, device=None):
 def whole_job_rate(units_per_rank, world, seconds):
     """aggregate throughput: units all ranks processed / time of the slowest rank"""
     return units_per_rank * world / seconds
+
+
+class BucketedAllReduce:
+    """Gradient averaging of data-parallel training (the reference's DDPStrategy, exp_base.py:193-206)
+    for the UNet executor's FLAT gradient buffer.
+
+    `Unet._backward` reports [begin, end) float ranges of that buffer in backward order, each as soon
+    as the launches producing it are enqueued.  Ranges are coalesced (neighbouring ops are adjacent in
+    the buffer) and, once `bucket_bytes` are pending, all-reduced on a side stream that waits on an
+    event recorded on the compute stream -- the collective of one bucket overlaps the backward of the
+    layers below it.  xGMI is point-to-point: few large messages (default 32 MiB) beat many small ones.
+    `finish` flushes the tail and makes the compute stream wait for every collective.
+    """
+
+    def __init__(self, bucket_bytes=32 << 20, group=None):
+        self.bucket_bytes = int(bucket_bytes)
+        self.group = group
+        self._comm = None
+        self._pending, self._pending_floats, self._works, self._done = [], 0, [], []
+
+    def _world(self):
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def begin(self, flat):
+        self._pending, self._pending_floats, self._works, self._done = [], 0, [], []
+        if flat.is_cuda and self._comm is None:
+            self._comm = torch.cuda.Stream(device=flat.device)
+
+    def on_range(self, flat, begin, end):
+        if end <= begin:
+            return
+        p = self._pending
+        if p and end == p[-1][0]:
+            p[-1] = (begin, p[-1][1])
+        elif p and begin == p[-1][1]:
+            p[-1] = (p[-1][0], end)
+        else:
+            p.append((begin, end))
+        self._pending_floats += end - begin
+        if self._pending_floats * 4 >= self.bucket_bytes:
+            self._flush(flat)
+
+    def _flush(self, flat):
+        ranges, self._pending, self._pending_floats = self._pending, [], 0
+        if not ranges:
+            return
+        self._done.extend(ranges)
+        if self._world() == 1:
+            return
+        if flat.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(flat.device))
+            self._comm.wait_event(ev)
+            with torch.cuda.stream(self._comm):
+                for b, e in ranges:
+                    self._works.append(dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            for b, e in ranges:
+                dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM, group=self.group)
+
+    def finish(self, flat):
+        self._flush(flat)
+        world = self._world()
+        if world > 1:
+            if flat.is_cuda:
+                with torch.cuda.stream(self._comm):
+                    for w in self._works:
+                        w.wait()
+                    for b, e in self._done:
+                        flat[b:e].mul_(1.0 / world)
+                torch.cuda.current_stream(flat.device).wait_stream(self._comm)
+            else:
+                for b, e in self._done:
+                    flat[b:e].mul_(1.0 / world)
+        self._works = []
+        return self._done
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """rank `src`'s parameters and buffers to every rank (what DDP does at construction)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+def attach_grad_sync(flow_diffuser_or_unet, bucket_bytes=32 << 20, group=None):
+    """data-parallel training: average the UNet's gradients across ranks inside every backward."""
+    unet = getattr(flow_diffuser_or_unet, "unet", flow_diffuser_or_unet)
+    unet.grad_sync = BucketedAllReduce(bucket_bytes, group)
+    return unet.grad_sync

@@ -50,3 +50,70 @@ def test_two_rank_sampling_shards_and_timing():
     assert t0 == t1 == pytest.approx(0.75)            # MAX over ranks
     assert rate0 == rate1 == pytest.approx(5 * 2 / 0.75)
     assert sums0 == sums1 and sums0[0] != sums0[1]    # different chains per rank
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from opticalflowdiffusion_amd import parallel as P
+    P.init(backend="gloo")
+    n = 10_000
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(n, generator=g)
+    mine = flat.clone()
+    sync = P.BucketedAllReduce(bucket_bytes=8_000)            # 2000 floats per bucket
+    sync.begin(flat)
+    # the executor's order: top of the buffer first, neighbouring ops descending, then a far range
+    ranges = [(9000, 10000), (8500, 9000), (7000, 8500), (3000, 7000), (2500, 3000), (100, 2500), (0, 100)]
+    for b, e in ranges:
+        sync.on_range(flat, b, e)
+    done = sync.finish(flat)
+    others = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(others, mine)
+    want = sum(others) / world
+    covered = sorted(done)
+    q.put((rank, float((flat - want).abs().max()), covered))
+    # parameters follow rank 0
+    lin = torch.nn.Linear(4, 3)
+    P.broadcast_parameters(lin)
+    ws = [torch.zeros_like(lin.weight) for _ in range(world)]
+    dist.all_gather(ws, lin.weight.data)
+    q.put((rank, bool(torch.equal(ws[0], ws[1]))))
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_gradient_allreduce():
+    """the data-parallel exchange step (reference: Lightning DDPStrategy, exp_base.py:193-206): ranges
+    reported in backward order are coalesced into buckets, every float is averaged exactly once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    avg = [r for r in res if len(r) == 3]
+    same = [r for r in res if len(r) == 2]
+    for rank, err, covered in avg:
+        assert err < 1e-6
+        # coalesced: contiguous cover of [0, n) without overlap
+        pos = 0
+        for b, e in covered:
+            assert b == pos
+            pos = e
+        assert pos == 10_000
+        assert len(covered) < 7                       # neighbours were merged into fewer collectives
+    assert all(ok for _, ok in same)
+
+
+def test_bucketed_allreduce_single_process_is_identity():
+    from opticalflowdiffusion_amd import parallel as P
+    flat = torch.arange(100, dtype=torch.float32)
+    sync = P.BucketedAllReduce(bucket_bytes=64)
+    sync.begin(flat)
+    sync.on_range(flat, 50, 100)
+    sync.on_range(flat, 0, 50)
+    sync.finish(flat)
+    assert torch.equal(flat, torch.arange(100, dtype=torch.float32))

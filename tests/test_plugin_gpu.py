@@ -79,8 +79,8 @@ def test_flow_diffuser_sample_validation_and_joint_model():
         assert torch.equal(torch.isnan(samples.cpu()), ~ok) and float((samples.cpu()[ok] - ref[ok]).abs().max()) < 1e-5
         loss = fd.validation_step((img, tgt, flow), 0)
         assert torch.isfinite(loss) and "val/loss" in fd.logged
-    with pytest.raises(Exception):                       # training needs the backward kernels: fails loudly
-        fd.training_step((img, tgt, flow), 0)
+    loss_t = fd.training_step((img, tgt, flow), 0)         # FD:218-235: differentiable through the HIP executor
+    assert loss_t.requires_grad and torch.isfinite(loss_t)
 
     cfgj = dict(target="joint", image_size=[H, W], timesteps=4, flow_max=20, zero_init=False)
     fj = FlowDiffuser(cfgj).cuda()
@@ -145,3 +145,61 @@ def test_fused_adam_matches_torch_adam_with_clipping():
             assert rel_l2(b.detach().cpu(), a.detach().cpu()) < 1e-6, it
     sd = mine.state_dict()
     assert set(sd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_flow_diffuser_training_steps_reduce_the_loss():
+    """FD:218-235 + FD:131-134: training_step -> backward through the HIP executor -> FusedAdam.step, the
+    loop pl.Trainer.fit drives (exp_base.py:209-214).  Overfits one synthetic batch: the loss must fall."""
+    from opticalflowdiffusion_amd import FlowDiffuser
+    torch.manual_seed(0)
+    H, W, B = 32, 64, 4
+    fd = FlowDiffuser(dict(target="flow", image_size=[H, W], timesteps=50, flow_max=20, zero_init=False, lr=2e-3, weight_decay=0.0)).cuda()
+    fd.log_dict = lambda *a, **k: None
+    opt = fd.configure_optimizers()
+    img = torch.rand(B, 3, H, W, device="cuda")
+    flow = torch.clamp(torch.randn(B, 2, H, W, device="cuda") * 8, -20, 20)
+    flow[0, :, :2, :3] = float("nan")                      # Sintel-style invalid pixels: masked out of the loss
+    losses = []
+    for it in range(12):
+        torch.manual_seed(100)                              # same t and noise each step: a clean overfitting signal
+        loss = fd.training_step((img, img, flow), it)
+        assert loss.requires_grad and torch.isfinite(loss)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.6 * losses[0], losses
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in fd.unet.parameters())
+
+
+def test_backward_reports_every_gradient_range_once():
+    """the ranges handed to the data-parallel hook cover the flat gradient buffer exactly once, last layers first"""
+    from opticalflowdiffusion_amd import Unet
+    from opticalflowdiffusion_amd.warp import nan_mse
+    torch.manual_seed(0)
+    net = Unet(64, channels=5, out_dim=2).cuda()
+
+    class Recorder:
+        def __init__(self):
+            self.ranges = []
+        def begin(self, flat):
+            self.ranges = []
+        def on_range(self, flat, b, e):
+            self.ranges.append((b, e))
+        def finish(self, flat):
+            pass
+
+    rec = net.grad_sync = Recorder()
+    out = net(torch.randn(1, 2, 16, 16, device="cuda"), external_cond=torch.randn(1, 3, 16, 16, device="cuda"), time=torch.tensor([3], device="cuda"))
+    nan_mse(out, torch.zeros_like(out)).backward()
+    n = net.flat_grads().numel()
+    pos = 0
+    for b, e in sorted(rec.ranges):
+        assert b == pos, (b, pos)
+        pos = e
+    assert pos == n
+    offs = dict(zip(net._names, net._goffsets))
+    assert rec.ranges[0][0] == offs["final_conv.weight"]            # backward order: the head first ...
+    assert rec.ranges[-1][0] == offs["time_mlp.1.weight"]           # ... the time MLP (fed by every block) last
+    with pytest.raises(Exception, match="older forward|tape"):
+        nan_mse(out, torch.zeros_like(out)).backward()              # the tape is single-use

@@ -1,7 +1,8 @@
 import csv, collections, sys
 rows=list(csv.reader(open(sys.argv[1] if len(sys.argv)>1 else 'gpurun_out/launches.csv')))
 agg=collections.OrderedDict()
-for cls,label,ms,fl,by in rows:
+for row in rows:
+    cls, label, ms, fl, by = row[0], ",".join(row[1:-3]), row[-3], row[-2], row[-1]
     k=(cls,label)
     a=agg.setdefault(k,[0,0.0,float(fl),float(by)])
     a[0]+=1; a[1]+=float(ms)
