@@ -223,14 +223,15 @@ int ofd_channel_sum(const void* dy, float* out, size_t npix, int C, void* stream
  * ofd_gn_silu_backward: backward of out = SiLU(GroupNorm(h) * (scale+1) + shift) (DD:181-187) given
  *   g = dL/dout.  (a, s) is the folded per-(sample, channel) affine of the forward, stats = [B][8][{mean,
  *   rstd}].  Writes dh; ADDS into dgamma / dbeta (fp32 [C]); writes the scale|shift gradient rows into dss
- *   (same indexing as ss; NULL when the block has no time-embedding input).  workspace:
+ *   (same indexing as ss; NULL when the block has no time-embedding input).  dconv_bias (may be NULL):
+ *   ADDS sum_pixels dh, the bias gradient of the convolution that produced h.  workspace:
  *   ofd_gn_bwd_workspace_floats floats.
  * ofd_layernorm_c_backward: DD:116-125; dx written (or added when accumulate != 0), dg ADDED.
  * ofd_final_conv_backward: DD:361; dx written, dw / db ADDED. */
 size_t ofd_gn_bwd_workspace_floats(int B, int H, int W, int C);
 int ofd_gn_silu_backward(const void* g, const void* h, const float* a, const float* s, const float* stats,
                          const float* gamma, const float* beta, const float* ss, int ss_stride, int ss_offset,
-                         void* dh, float* dgamma, float* dbeta, float* dss, float* workspace,
+                         void* dh, float* dgamma, float* dbeta, float* dss, float* dconv_bias, float* workspace,
                          int B, int H, int W, int C, void* stream);
 int ofd_affine_silu(const void* h, const float* a, const float* s, void* out, int B, int H, int W, int C, void* stream);
 int ofd_layernorm_c_backward(const void* x, const float* g, const void* dy, void* dx, float* dg, size_t npix, int C,

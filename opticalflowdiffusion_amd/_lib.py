@@ -86,7 +86,7 @@ SIGNATURES = {
     "ofd_grad_scatter": (c_int, [c_void_p, c_int, c_int, c_void_p] + [c_int] * 8 + [c_void_p]),
     "ofd_channel_sum": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ofd_gn_bwd_workspace_floats": (c_size_t, [c_int] * 4),
-    "ofd_gn_silu_backward": (c_int, [c_void_p] * 8 + [c_int, c_int] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "ofd_gn_silu_backward": (c_int, [c_void_p] * 8 + [c_int, c_int] + [c_void_p] * 6 + [c_int] * 4 + [c_void_p]),
     "ofd_affine_silu": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "ofd_layernorm_c_backward": (c_int, [c_void_p] * 5 + [c_size_t, c_int, c_float, c_int, c_void_p]),
     "ofd_final_conv_backward": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),

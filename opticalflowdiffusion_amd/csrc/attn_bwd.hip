@@ -1,6 +1,5 @@
 // Backward of the two attention cores (training path):
-//   * LinearAttention core, DD:229-242 (softmax over d on q, softmax over pixels on k, ctx = k.v^T / n,
-//     out = ctx^T q * scale): two passes over the pixels, fp32 VALU, context-sized state in LDS.
+//   * LinearAttention core: la_core.hip (forward and backward);
 //   * mid-block softmax attention, DD:256-268: flash-style recompute with MFMA 32x32x16 bf16, one
 //     kernel that owns query blocks (dQ) and one that owns key blocks (dK, dV) -- no atomics.
 // qkv / dqkv are [B][n][384] bf16 (q | k | v, head-major 4 x 32), attention outputs [B][n][128].
@@ -29,165 +28,6 @@ __device__ __forceinline__ void load32(const bf16_t* p, float (&f)[32]) {
 __device__ __forceinline__ void store32(bf16_t* p, const float (&f)[32]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) *(uint4*)(p + u * 8) = a_pack8(&f[u * 8]);
-}
-
-// =====================================================================================================
-// LinearAttention core backward
-// pass 1: dctx[d][e] = sum_n qs[d,n] * dout[e,n]  (qs = softmax_d(q) * scale); grid (nparts, B*4)
-constexpr int LB_SUB = 128;
-__global__ void __launch_bounds__(256) la_bwd_dctx_partial_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                                  float* __restrict__ partial, int n, int span, int nparts, float scale) {
-    __shared__ __attribute__((aligned(16))) float qs[LB_SUB][33];
-    __shared__ __attribute__((aligned(16))) float ds[LB_SUB][32];
-    const int tid = threadIdx.x, part = blockIdx.x, bh = blockIdx.y, b = bh / 4, h = bh % 4;
-    const int n_begin = part * span, n_end = min(n, n_begin + span);
-    const int d = tid >> 3, e4 = (tid & 7) * 4;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c0 = n_begin; c0 < n_end; c0 += LB_SUB) {
-        const int cnt = min(LB_SUB, n_end - c0);
-        __syncthreads();
-        {
-            const int p = tid >> 1, hf = tid & 1;
-            if (p < cnt) {
-                const size_t pix = (size_t)b * n + c0 + p;
-                float f[16], g[16];
-                a_unpack8(*(const uint4*)(qkv + pix * 384 + h * 32 + hf * 16), &f[0]);
-                a_unpack8(*(const uint4*)(qkv + pix * 384 + h * 32 + hf * 16 + 8), &f[8]);
-                a_unpack8(*(const uint4*)(dout + pix * 128 + h * 32 + hf * 16), &g[0]);
-                a_unpack8(*(const uint4*)(dout + pix * 128 + h * 32 + hf * 16 + 8), &g[8]);
-                float mx = f[0];
-#pragma unroll
-                for (int j = 1; j < 16; ++j) mx = fmaxf(mx, f[j]);
-                mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-                float sum = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) { f[j] = __expf(f[j] - mx); sum += f[j]; }
-                sum += __shfl_xor(sum, 1, 64);
-                const float k = scale / sum;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) { qs[p][hf * 16 + j] = f[j] * k; ds[p][hf * 16 + j] = g[j]; }
-            }
-        }
-        __syncthreads();
-        for (int p = 0; p < cnt; ++p) {
-            const float qv = qs[p][d];
-            const float4 dv = *(const float4*)&ds[p][e4];
-            acc[0] += qv * dv.x; acc[1] += qv * dv.y; acc[2] += qv * dv.z; acc[3] += qv * dv.w;
-        }
-    }
-    *(float4*)(partial + ((size_t)bh * nparts + part) * 1024 + d * 32 + e4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-}
-
-// combine: dctx[bh] = sum of partials; S[bh][d] = sum_e dctx[d][e] * ctx[d][e]   (grid B*4, 256 threads)
-__global__ void __launch_bounds__(256) la_bwd_combine_kernel(const float* __restrict__ partial, const float* __restrict__ ctx, float* __restrict__ dctx,
-                                                             float* __restrict__ S, int nparts) {
-    __shared__ float prod[1024];
-    const int tid = threadIdx.x, bh = blockIdx.x;
-    for (int i = tid; i < 1024; i += 256) {
-        float a = 0.0f;
-        for (int c = 0; c < nparts; ++c) a += partial[((size_t)bh * nparts + c) * 1024 + i];
-        dctx[(size_t)bh * 1024 + i] = a;
-        prod[i] = a * ctx[(size_t)bh * 1024 + i];
-    }
-    __syncthreads();
-    if (tid < 32) {
-        float s = 0.0f;
-        for (int e = 0; e < 32; ++e) s += prod[tid * 32 + e];
-        S[(size_t)bh * 32 + tid] = s;
-    }
-}
-
-// pass 2: per pixel.  wave = head, lane = pixel (64 pixels per workgroup iteration); every context row
-// read from LDS is a broadcast.   grid (gx, B)
-__global__ void __launch_bounds__(256) la_bwd_apply_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ ctx,
-                                                           const float* __restrict__ dctx, const float* __restrict__ ml, const float* __restrict__ S,
-                                                           bf16_t* __restrict__ dqkv, int n, float scale) {
-    __shared__ __attribute__((aligned(16))) float cs[4][32][32], dcs[4][32][32];
-    __shared__ float Ms[4][32], Li[4][32], Ss[4][32];
-    const int tid = threadIdx.x, b = blockIdx.y, h = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < 4096; i += 256) {
-        (&cs[0][0][0])[i] = ctx[(size_t)b * 4096 + i];
-        (&dcs[0][0][0])[i] = dctx[(size_t)b * 4096 + i];
-    }
-    if (tid < 128) {
-        Ms[tid >> 5][tid & 31] = ml[((size_t)b * 4 + (tid >> 5)) * 64 + (tid & 31)];
-        Li[tid >> 5][tid & 31] = ml[((size_t)b * 4 + (tid >> 5)) * 64 + 32 + (tid & 31)];
-        Ss[tid >> 5][tid & 31] = S[((size_t)b * 4 + (tid >> 5)) * 32 + (tid & 31)];
-    }
-    __syncthreads();
-    const float inv_n = 1.0f / (float)n;
-    for (int p0 = blockIdx.x * 64; p0 < n; p0 += gridDim.x * 64) {
-        const int p = p0 + lane;
-        if (p >= n) continue;
-        const size_t pix = (size_t)b * n + p;
-        {   // d q_raw = softmax(q) * (dq - <softmax(q), dq>), dq = scale * ctx . dout
-            float q[32], g[32], dq[32];
-            load32(qkv + pix * 384 + h * 32, q);
-            load32(dout + pix * 128 + h * 32, g);
-            float mx = q[0];
-#pragma unroll
-            for (int j = 1; j < 32; ++j) mx = fmaxf(mx, q[j]);
-            float sum = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) { q[j] = __expf(q[j] - mx); sum += q[j]; }
-            const float rs = __builtin_amdgcn_rcpf(sum);
-            float t = 0.0f;
-#pragma unroll
-            for (int d = 0; d < 32; ++d) {
-                float aq = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 32; e += 4) {
-                    const float4 c4 = *(const float4*)&cs[h][d][e];
-                    aq += c4.x * g[e] + c4.y * g[e + 1] + c4.z * g[e + 2] + c4.w * g[e + 3];
-                }
-                q[d] *= rs;
-                dq[d] = aq * scale;
-                t += q[d] * dq[d];
-            }
-#pragma unroll
-            for (int j = 0; j < 32; ++j) dq[j] = q[j] * (dq[j] - t);
-            store32(dqkv + pix * 384 + h * 32, dq);
-        }
-        float k[32], v[32], dv[32];
-        load32(qkv + pix * 384 + 128 + h * 32, k);
-        load32(qkv + pix * 384 + 256 + h * 32, v);
-#pragma unroll
-        for (int j = 0; j < 32; ++j) dv[j] = 0.0f;
-#pragma unroll
-        for (int d = 0; d < 32; ++d) {
-            float ak = 0.0f;
-            const float kd = __expf(k[d] - Ms[h][d]) * Li[h][d];
-#pragma unroll
-            for (int e = 0; e < 32; e += 4) {
-                const float4 d4 = *(const float4*)&dcs[h][d][e];
-                ak += d4.x * v[e] + d4.y * v[e + 1] + d4.z * v[e + 2] + d4.w * v[e + 3];
-                dv[e] += kd * d4.x; dv[e + 1] += kd * d4.y; dv[e + 2] += kd * d4.z; dv[e + 3] += kd * d4.w;
-            }
-            k[d] = kd * (ak * inv_n - Ss[h][d]);           // d k_raw
-        }
-#pragma unroll
-        for (int j = 0; j < 32; ++j) dv[j] *= inv_n;
-        store32(dqkv + pix * 384 + 128 + h * 32, k);
-        store32(dqkv + pix * 384 + 256 + h * 32, dv);
-    }
-}
-
-size_t la_bwd_workspace_floats(int B, int n) { return (size_t)B * 4 * ((size_t)la_parts(n) * 1024 + 1024 + 32); }
-
-int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const float* ctx, const float* ml, bf16_t* dqkv, float* workspace, int B, int n,
-                                hipStream_t s) {
-    const int nparts = la_parts(n);
-    float* partial = workspace;
-    float* dctx = partial + (size_t)B * 4 * nparts * 1024;
-    float* S = dctx + (size_t)B * 4 * 1024;
-    const float scale = 0.17677669529663687f;
-    la_bwd_dctx_partial_kernel<<<dim3(nparts, B * 4), 256, 0, s>>>(qkv, dout, partial, n, 4096, nparts, scale);
-    la_bwd_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, dctx, S, nparts);
-    int gx = cdiv(n, 64);
-    if (gx > 2048) gx = 2048;
-    la_bwd_apply_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, dout, ctx, dctx, ml, S, dqkv, n, scale);
-    OFD_LAUNCH_CHECK();
-    return OFD_OK;
 }
 
 // =====================================================================================================
@@ -389,7 +229,7 @@ int k_flash_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout
 }  // namespace ofd
 using namespace ofd;
 
-extern "C" size_t ofd_la_workspace_floats(int B, int n) { return (size_t)B * 4 * (size_t)la_parts(n) * 1088; }
+extern "C" size_t ofd_la_workspace_floats(int B, int n) { return (size_t)B * 4 * (size_t)la_parts(B, n) * 1088; }
 extern "C" size_t ofd_la_bwd_workspace_floats(int B, int n) { return la_bwd_workspace_floats(B, n); }
 extern "C" int ofd_linear_attention_core(const void* qkv, void* out, float* ctx, float* ml, float* workspace, int B, int n, void* stream) {
     OFD_CHECK_ARG(qkv && out && ctx && ml && workspace && B > 0 && n > 0, "linear_attention_core: bad argument");

@@ -30,7 +30,7 @@ int k_gn_finalize(const float* partial, int B, int H, int W, int C, const float*
                   int ss_stride, int ss_offset, float* a_out, float* s_out, hipStream_t s, float* stats_out = nullptr);
 int k_resblock_out(const bf16_t* h, const float* a, const float* sft, const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t s);
 int k_layernorm_c(const bf16_t* x, const float* g, const bf16_t* res, bf16_t* out, size_t npix, int C, float eps, hipStream_t s);
-int la_parts(int n);
+int la_parts(int B, int n);
 int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s, float* ml_out = nullptr);
 int la_fused_blocks(int n);
 int k_la_weight_prep(const float* wqkv, const float* g, const float* wout, bf16_t* wq, bf16_t* wkv, bf16_t* woutp, int C, hipStream_t s);
@@ -46,7 +46,7 @@ int k_affine_silu(const bf16_t* h, const float* a, const float* s, bf16_t* out, 
 size_t gn_bwd_workspace_floats(int B, int H, int W, int C);
 int k_gn_silu_backward(const bf16_t* g, const bf16_t* h, const float* a, const float* s, const float* stats, const float* gamma,
                        const float* beta, const float* ss, int ss_stride, int ss_offset, bf16_t* dh, float* dgamma, float* dbeta, float* dss,
-                       float* workspace, int B, int H, int W, int C, hipStream_t st);
+                       float* workspace, int B, int H, int W, int C, hipStream_t st, float* dconv_bias = nullptr);
 int k_layernorm_c_bwd(const bf16_t* x, const float* gw, const bf16_t* dy, bf16_t* dx, float* dg, size_t npix, int C, float eps, int accumulate,
                       hipStream_t st);
 int k_final_conv_bwd(const bf16_t* x, const float* w, const float* dy, bf16_t* dx, float* dw, float* db, int B, int H, int W, int C, int out_dim,

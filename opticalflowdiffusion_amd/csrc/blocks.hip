@@ -193,95 +193,6 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const bf16_t* __restri
     }
 }
 
-// ---- LinearAttention, pass 1 (DD:235,238,240): per (sample, head) streaming softmax over n of k and
-// the context k_soft . v^T / n.  A workgroup walks `span` pixels in sub-chunks of 256 with an
-// online max (flash-style rescale) and emits a partial {m[32], l[32], ctx[32][32]}.
-constexpr int LA_SUB = 128;
-__global__ void __launch_bounds__(256) la_ctx_partial_kernel(const bf16_t* __restrict__ qkv, float* __restrict__ partial, int n, int span, int nparts) {
-    __shared__ __attribute__((aligned(16))) float ks[LA_SUB][33];
-    __shared__ __attribute__((aligned(16))) float vs[LA_SUB][32];
-    __shared__ float red[8][32], m_s[32], f_s[32];
-    const int tid = threadIdx.x, part = blockIdx.x, bh = blockIdx.y, b = bh / 4, h = bh % 4;
-    const int n_begin = part * span, n_end = min(n, n_begin + span);
-    const int d = tid >> 3, e4 = (tid & 7) * 4;          // thread owns ctx[d][e4..e4+3]
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (tid < 32) m_s[tid] = -3.0e38f;
-    float l_run = 0.0f;                                   // threads 0..31: running sum for d = tid
-    __syncthreads();
-    for (int c0 = n_begin; c0 < n_end; c0 += LA_SUB) {
-        const int cnt = min(LA_SUB, n_end - c0);
-        // stage k and v of this head: 128 pixels x (4 + 4) 16-byte units, 4 units per thread
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + i * 256, p = id >> 3, u = id & 7;
-            if (p < cnt) {
-                const bf16_t* row = qkv + ((size_t)b * n + c0 + p) * 384 + h * 32;
-                float f[8];
-                if (u < 4) {
-                    unpack8(*(const uint4*)(row + 128 + u * 8), f);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) ks[p][u * 8 + j] = f[j];
-                } else {
-                    unpack8(*(const uint4*)(row + 256 + (u - 4) * 8), f);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) vs[p][(u - 4) * 8 + j] = f[j];
-                }
-            }
-        }
-        __syncthreads();
-        // chunk max per d: 8 groups of 32 lanes
-        {
-            const int dd = tid & 31, grp = tid >> 5;
-            float mx = -3.0e38f;
-            for (int p = grp; p < cnt; p += 8) mx = fmaxf(mx, ks[p][dd]);
-            red[grp][dd] = mx;
-        }
-        __syncthreads();
-        if (tid < 32) {
-            float mx = red[0][tid];
-#pragma unroll
-            for (int g = 1; g < 8; ++g) mx = fmaxf(mx, red[g][tid]);
-            const float m_old = m_s[tid], m_new = fmaxf(m_old, mx);
-            f_s[tid] = __expf(m_old - m_new);
-            m_s[tid] = m_new;
-        }
-        __syncthreads();
-        // exponentiate in place + partial row sums
-        {
-            const int dd = tid & 31, grp = tid >> 5;
-            const float m = m_s[dd];
-            float sum = 0.0f;
-            for (int p = grp; p < cnt; p += 8) {
-                const float e = __expf(ks[p][dd] - m);
-                ks[p][dd] = e;
-                sum += e;
-            }
-            red[grp][dd] = sum;
-        }
-        __syncthreads();
-        if (tid < 32) {
-            float sum = red[0][tid];
-#pragma unroll
-            for (int g = 1; g < 8; ++g) sum += red[g][tid];
-            l_run = l_run * f_s[tid] + sum;
-        }
-        {
-            const float f = f_s[d];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] *= f;
-            for (int p = 0; p < cnt; ++p) {
-                const float pk = ks[p][d];
-                const float4 vv = *(const float4*)&vs[p][e4];
-                acc[0] += pk * vv.x; acc[1] += pk * vv.y; acc[2] += pk * vv.z; acc[3] += pk * vv.w;
-            }
-        }
-        __syncthreads();
-    }
-    float* o = partial + ((size_t)bh * nparts + part) * 1088;
-    if (tid < 32) { o[tid] = m_s[tid]; o[32 + tid] = l_run; }
-    *(float4*)(o + 64 + d * 32 + e4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-}
-
 // combine the partials: ctx[bh][d][e] = sum_c exp(m_c - M) ctx_c / (sum_c exp(m_c - M) l_c) / n
 __global__ void __launch_bounds__(256) la_ctx_combine_kernel(const float* __restrict__ partial, float* __restrict__ ctx, int nparts, float inv_n, float* __restrict__ ml_out) {
     __shared__ float M[32], Linv[32];
@@ -305,68 +216,6 @@ __global__ void __launch_bounds__(256) la_ctx_combine_kernel(const float* __rest
         float a = 0.0f;
         for (int c = 0; c < nparts; ++c) a += base[(size_t)c * 1088 + 64 + i] * __expf(base[(size_t)c * 1088 + d] - M[d]);
         ctx[(size_t)bh * 1024 + i] = a * Linv[d] * inv_n;
-    }
-}
-
-// ---- LinearAttention, pass 2 (DD:234,237,242): per pixel q softmax over d, * scale, out = ctx^T q ---
-// workgroup: 32 pixels per iteration; thread -> (pixel, head, 16 of the 32 outputs e)
-__global__ void __launch_bounds__(256) la_out_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ ctx, bf16_t* __restrict__ out, int n, float scale) {
-    __shared__ float cs[4][32][32], qs[32][129];
-    const int tid = threadIdx.x, b = blockIdx.y;
-    for (int i = tid; i < 4096; i += 256) (&cs[0][0][0])[i] = ctx[(size_t)b * 4096 + i];
-    const int px = tid >> 3, hh = (tid & 7) >> 1, eh = (tid & 1) * 16;
-    for (int p0 = blockIdx.x * 32; p0 < n; p0 += gridDim.x * 32) {
-        __syncthreads();
-        // stage + softmax over d: thread -> (pixel px, head hh, half eh/16 of d): 16 values each
-        {
-            const int p = p0 + px;
-            float f[16];
-            if (p < n) {
-                const bf16_t* row = qkv + ((size_t)b * n + p) * 384 + hh * 32 + eh;
-                float a[8], c[8];
-                unpack8(*(const uint4*)(row), a);
-                unpack8(*(const uint4*)(row + 8), c);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { f[j] = a[j]; f[8 + j] = c[j]; }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) f[j] = 0.0f;
-            }
-            float mx = f[0];
-#pragma unroll
-            for (int j = 1; j < 16; ++j) mx = fmaxf(mx, f[j]);
-            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-            float sum = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { f[j] = __expf(f[j] - mx); sum += f[j]; }
-            sum += __shfl_xor(sum, 1, 64);
-            const float k = scale / sum;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) qs[px][hh * 32 + eh + j] = f[j] * k;
-        }
-        __syncthreads();
-        {
-            float o[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) o[j] = 0.0f;
-            for (int d = 0; d < 32; ++d) {
-                const float qv = qs[px][hh * 32 + d];
-#pragma unroll
-                for (int j = 0; j < 16; j += 4) {
-                    const float4 c4 = *(const float4*)&cs[hh][d][eh + j];
-                    o[j] += qv * c4.x; o[j + 1] += qv * c4.y; o[j + 2] += qv * c4.z; o[j + 3] += qv * c4.w;
-                }
-            }
-            const int p = p0 + px;
-            if (p < n) {
-                bf16_t* dst = out + ((size_t)b * n + p) * 128 + hh * 32 + eh;
-                float lo[8], hi[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { lo[j] = o[j]; hi[j] = o[8 + j]; }
-                *(uint4*)dst = pack8(lo);
-                *(uint4*)(dst + 8) = pack8(hi);
-            }
-        }
     }
 }
 
@@ -574,16 +423,8 @@ int k_layernorm_c(const bf16_t* x, const float* g, const bf16_t* res, bf16_t* ou
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
-int la_parts(int n) { return cdiv(n, 4096); }
-int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s, float* ml_out) {
-    const int nparts = la_parts(n);
-    la_ctx_partial_kernel<<<dim3(nparts, B * 4), 256, 0, s>>>(qkv, partial, n, 4096, nparts);
-    la_ctx_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, nparts, 1.0f / (float)n, ml_out);
-    int gx = cdiv(n, 32);
-    if (gx > 1024) gx = 1024;
-    la_out_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, ctx, out, n, 0.17677669529663687f);
-    OFD_LAUNCH_CHECK();
-    return OFD_OK;
+void launch_la_ctx_combine(const float* partial, float* ctx, int B, int nparts, float inv_n, float* ml_out, hipStream_t s) {
+    la_ctx_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, nparts, inv_n, ml_out);
 }
 int k_flash_attention(const bf16_t* qkv, bf16_t* out, int B, int n, hipStream_t s, float* lse) {
     flash_attn_d32_kernel<<<dim3(cdiv(n, 128), B * 4), 256, 0, s>>>(qkv, out, n, 0.17677669529663687f, lse);

@@ -12,13 +12,9 @@
 //     (denoising_diffusion.py:109-112).
 #include "blocks.h"
 #include "conv_params.h"
+#include "mfma_util.h"
 
 namespace ofd {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // prepared forward weights [tap][Cin/8][Cout][8]  ->  dgrad weights [T-1-tap][Cout/8][Cin][8]
 __global__ void __launch_bounds__(256) wt_transpose_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wt, int taps, int Cin, int Cout) {
@@ -41,20 +37,6 @@ struct WgradParams {
     const bf16_t* dy;
     float* dw;           // [taps][Cin_total][Cout] fp32, accumulated with atomics (zeroed by the caller)
 };
-
-// two transposing reads = one MFMA operand fragment: 8 consecutive PIXELS (k) of this lane's channel
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base_px0, int row_stride_bytes, int lane) {
-    // lane -> (16-lane group: channel block cb, k half h), (q, p) inside the group
-    const int li = lane & 15, q = li >> 2, p = li & 3, cb = (lane >> 4) & 1, h = lane >> 5;
-    const unsigned char* a = base_px0 + (size_t)(8 * h + q) * row_stride_bytes + (cb * 16 + 4 * p) * 2;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 4 * row_stride_bytes));
-    // (whole-vector reinterpretation: per-element bit_casts of the builtin's result are miscompiled by
-    //  hipcc 7.2 into a splat of element 0 -- found with tools/probe/tr_probe2.hip)
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, both);
-}
 
 // grid: (pixel-tile groups, KS kernel rows, (Cin/64)*(Cout/64)); workgroup = 4 waves, wave -> 32 ci x 32 co
 template <int KS>
@@ -151,58 +133,94 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams P) {
     }
 }
 
-// 7x7 init conv (Cin padded to 16, Cout = 64): dW[tap][ci<16][co], VALU: one thread per (tap, co) pair
-// walks the pixels of its slice, 16 accumulators (ci); 226 GFLOP at the benchmark size.
-__global__ void __launch_bounds__(256) conv7_wgrad_kernel(const bf16_t* __restrict__ x16, const bf16_t* __restrict__ dy, float* __restrict__ dw,
-                                                          int B, int H, int W, int rows_per_block) {
-    // grid: (49 taps, row slices); block: 64 co x 4 column phases
-    const int tap = blockIdx.x, ky = tap / 7, kx = tap % 7, co = threadIdx.x & 63, ph = threadIdx.x >> 6;
-    float acc[16];
+// 7x7 init conv (Cin padded to 16, Cout = 64): dW[tap][ci<16][co] = sum_p X16[p + tap][ci] dY[p][co].
+// MFMA over pixels like conv_wgrad_kernel.  The halo tile keeps 16 channels = 32 B per pixel, so the
+// "second 16-channel block" of a transposing fragment read is simply the NEXT PIXEL: one 32-row A
+// operand carries the taps (ky, kx) and (ky, kx+1).  8 waves: wave -> (n-tile of 32 co, two ky rows),
+// 8 accumulator tiles each; workgroups walk many 8x32 pixel tiles and add their sums once.
+__global__ void __launch_bounds__(512) conv7_wgrad_kernel(const bf16_t* __restrict__ x16, const bf16_t* __restrict__ dy, float* __restrict__ dw,
+                                                          int B, int H, int W, int tiles_x, int tiles_y) {
+    constexpr int XW = 40, XPIX = 14 * XW;                // 38 columns needed (+1 for the phantom tap kx = 7)
+    __shared__ __attribute__((aligned(16))) unsigned char xs[XPIX * 32];
+    __shared__ __attribute__((aligned(16))) unsigned char ys[256 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int nt = wave & 1, kg = wave >> 1;               // ky rows of this wave: kg and kg + 4 (kg + 4 < 7)
+    const int tpi = tiles_x * tiles_y, ntiles = tpi * B;
+    f32x16 acc[2][4];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
-    const long total_rows = (long)B * H;
-    const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(total_rows, r0 + rows_per_block);
-    for (long row = r0; row < r1; ++row) {
-        const int b = (int)(row / H), y = (int)(row % H);
-        const int iy = y + ky - 3;
-        if (iy < 0 || iy >= H) continue;
-        for (int x = ph; x < W; x += 4) {
-            const int ix = x + kx - 3;
-            if (ix < 0 || ix >= W) continue;
-            const float g = bf2f(dy[(((size_t)b * H + y) * W + x) * 64 + co]);
-            const uint4* xp = (const uint4*)(x16 + (((size_t)b * H + iy) * W + ix) * 16);
-            const uint4 lo = xp[0], hi = xp[1];
-            const uint32_t w8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                acc[2 * j] += g * bf2f((bf16_t)(w8[j] & 0xffffu));
-                acc[2 * j + 1] += g * bf2f((bf16_t)(w8[j] >> 16));
-            }
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][k][r] = 0.0f;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int b = t / tpi, t_in = t - b * tpi;
+        const int oy0 = (t_in / tiles_x) * 8, ox0 = (t_in % tiles_x) * 32;
+        __syncthreads();
+        for (int i = tid; i < XPIX * 2; i += 512) {
+            const int p = i >> 1, u = i & 1, ty = p / XW, tx = p - ty * XW;
+            const int iy = oy0 + ty - 3, ix = ox0 + tx - 3;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            u32x4 v = *(const u32x4*)(x16 + (((size_t)b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * 16 + u * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
+            *(u32x4*)(xs + p * 32 + u * 16) = v;
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 512, p = id >> 3, c8 = id & 7;
+            const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
+            const bool ok = oy < H && ox < W;
+            u32x4 v = *(const u32x4*)(dy + (((size_t)b * H + min(oy, H - 1)) * W + min(ox, W - 1)) * 64 + c8 * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
+            *(u32x4*)(ys + p * 128 + c8 * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb) {
+                const bf16x8 yf = tr_frag(ys + ((r * 32 + xb * 16) * 64 + nt * 32) * 2, 128, lane);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int ky = kg + 4 * a;
+                    if (ky < 7) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bf16x8 xf = tr_frag(xs + ((r + ky) * XW + xb * 16 + 2 * k) * 32, 32, lane);
+                            acc[a][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yf, acc[a][k], 0, 0, 0);   // rows = (tap kx|kx+1, ci), cols = co
+                        }
+                    }
+                }
+            }
     }
-    __shared__ float red[4][16][64];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) red[ph][c][co] = acc[c];
-    __syncthreads();
-    if (ph == 0) {
+    for (int a = 0; a < 2; ++a) {
+        const int ky = kg + 4 * a;
+        if (ky >= 7) continue;
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
-            atomicAdd(dw + ((size_t)tap * 16 + c) * 64 + co, (red[0][c][co] + red[1][c][co]) + (red[2][c][co] + red[3][c][co]));
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * half, kx = 2 * k + (m >> 4), ci = m & 15;
+                if (kx < 7) atomicAdd(dw + ((size_t)(ky * 7 + kx) * 16 + ci) * 64 + nt * 32 + l31, acc[a][k][r]);
+            }
     }
 }
 
-// dY [npix][C] bf16 -> out[C] += column sums (bias gradients)
-__global__ void __launch_bounds__(256) channel_sum_kernel(const bf16_t* __restrict__ dy, float* __restrict__ out, size_t npix, int C, int pix_per_block) {
+// dY [npix][C] bf16 -> out[C] += column sums (bias gradients).  Workgroups stride over the pixels
+// (lanes along the channel octets, the rest of the workgroup along pixels), one atomic per channel each.
+__global__ void __launch_bounds__(256) channel_sum_kernel(const bf16_t* __restrict__ dy, float* __restrict__ out, size_t npix, int C) {
     __shared__ float red[256][9];
     const int c8n = C / 8, tid = threadIdx.x;
-    const size_t p0 = (size_t)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
     for (int cu = 0; cu < c8n; cu += 256) {       // (C <= 2048)
         const int lanes_c = min(c8n - cu, 256);    // threads covering different channel octets
         const int rows = 256 / lanes_c;            // pixel phases
         const int my_c = tid % lanes_c, my_r = tid / lanes_c;
         float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (my_r < rows)
-            for (size_t p = p0 + my_r; p < p1; p += rows) {
+            for (size_t p = (size_t)blockIdx.x * rows + my_r; p < npix; p += (size_t)gridDim.x * rows) {
                 const uint4 v = *(const uint4*)(dy + p * C + (cu + my_c) * 8);
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -371,19 +389,21 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
 }
 
 int k_conv7_wgrad(const bf16_t* x16, const bf16_t* dy, float* dw, int B, int H, int W, hipStream_t s) {
-    const long rows = (long)B * H;
-    int slices = (int)((rows + 15) / 16);
-    if (slices > 64) slices = 64;
-    const int rpb = (int)((rows + slices - 1) / slices);
-    conv7_wgrad_kernel<<<dim3(49, slices), 256, 0, s>>>(x16, dy, dw, B, H, W, rpb);
+    const int tx = cdiv(W, 32), ty = cdiv(H, 8);
+    int grid = tx * ty * B;
+    if (grid > 768) grid = 768;
+    conv7_wgrad_kernel<<<grid, 512, 0, s>>>(x16, dy, dw, B, H, W, tx, ty);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
 
 int k_channel_sum(const bf16_t* dy, float* out, size_t npix, int C, hipStream_t s) {
     OFD_CHECK_ARG(C % 8 == 0 && C <= 2048, "channel_sum: C=%d", C);
-    const int ppb = 2048;
-    channel_sum_kernel<<<(unsigned)((npix + ppb - 1) / ppb), 256, 0, s>>>(dy, out, npix, C, ppb);
+    const int rows = 256 / (C / 8 < 256 ? C / 8 : 256);
+    size_t grid = (npix + (size_t)rows * 16 - 1) / ((size_t)rows * 16);      // >= 16 pixels per thread ...
+    if (grid > 512) grid = 512;                                             // ... and at most 512 atomics per channel
+    if (grid < 1) grid = 1;
+    channel_sum_kernel<<<(unsigned)grid, 256, 0, s>>>(dy, out, npix, C);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

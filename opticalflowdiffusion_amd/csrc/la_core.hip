@@ -1,0 +1,396 @@
+// LinearAttention core on a materialised qkv tensor (training path; inference uses la_fused.hip),
+// DD:229-242: q softmax over d (* scale), k softmax over the pixels, ctx = k . v^T / n, out = ctx^T q.
+// Forward and backward, MFMA 32x32x16 bf16, two passes over the pixels each:
+//   pass 1 (reduction over pixels, K = pixel): context-shaped 32x32 sums per (sample, head); both operands
+//           are pixel-major in LDS and read with the transposing LDS read;
+//   pass 2 (per pixel): the PIXEL sits on the MFMA column (= lane), so every per-pixel softmax reduction is
+//           in-lane plus one cross-half shuffle, and the 32x32 context matrices are the A operands.
+// qkv / dqkv: [B][n][384] bf16 (q | k | v, 4 heads x 32); out / dout: [B][n][128].
+#include "blocks.h"
+#include "mfma_util.h"
+
+namespace ofd {
+
+constexpr int LC_CH = 128;            // pixels per staged chunk
+constexpr float LC_SCALE = 0.17677669529663687f;
+
+__device__ __forceinline__ void lc_unpack8(const u32x4& v, float* f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = bf2f((bf16_t)(v[j] & 0xffffu));
+        f[2 * j + 1] = bf2f((bf16_t)(v[j] >> 16));
+    }
+}
+__device__ __forceinline__ u32x4 lc_pack8(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = f2bf2(f[2 * j], f[2 * j + 1]);
+    return v;
+}
+__device__ __forceinline__ bf16x8 lc_frag(const float* f) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)f[j];
+    return r;
+}
+
+constexpr int FC_CH = 96;             // forward pass 1 chunk (two 24 KB tiles + scan scratch within the 64 KB static LDS)
+// ---- forward pass 1: partial {m[32], l[32], ctx[32][32]} per (sample*head, part); grid (nparts, B) ----
+// workgroup = 4 waves = 4 heads; online max over chunks of 96 pixels (accumulators rescaled per row d)
+__global__ void __launch_bounds__(256) lc_ctx_partial_kernel(const bf16_t* __restrict__ qkv, float* __restrict__ partial, int n, int span, int nparts) {
+    __shared__ __attribute__((aligned(16))) unsigned char ks[FC_CH * 256];     // [pixel][128 k channels] bf16 (raw, then exp(k - m))
+    __shared__ __attribute__((aligned(16))) unsigned char vs[FC_CH * 256];     // [pixel][128 v channels]
+    __shared__ float mx2[2][128], m_s[128], f_s[128], l2[2][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int part = blockIdx.x, b = blockIdx.y;
+    const int n_begin = part * span, n_end = min(n, n_begin + span);
+    const int ch = tid & 127, ph = tid >> 7;           // channel scans: thread -> (channel, pixel parity half)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float l_run = 0.0f;                                // threads < 128: running sum of channel tid
+    if (tid < 128) m_s[tid] = -3.0e38f;
+    for (int c0 = n_begin; c0 < n_end; c0 += FC_CH) {
+        const int cnt = min(FC_CH, n_end - c0);
+        __syncthreads();
+        // stage k and v: 128 px x (16 + 16) 16-byte units; pixels past the end: k = -inf-like, v = 0
+#pragma unroll
+        for (int i = 0; i < FC_CH / 8; ++i) {
+            const int id = tid + i * 256, p = id >> 5, u = id & 31;
+            const bool ok = p < cnt;
+            const bf16_t* row = qkv + ((size_t)b * n + c0 + min(p, cnt - 1)) * 384 + 128;
+            u32x4 v = *(const u32x4*)(row + u * 8);
+            if (!ok) {
+                const unsigned fill = (u < 16) ? 0xff7fff7fu : 0u;      // bf16 -3.4e38 | 0
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fill;
+            }
+            if (u < 16) *(u32x4*)(ks + p * 256 + u * 16) = v;
+            else *(u32x4*)(vs + p * 256 + (u - 16) * 16) = v;
+        }
+        __syncthreads();
+        {   // chunk max per channel
+            float mx = -3.0e38f;
+            for (int p = ph; p < FC_CH; p += 2) mx = fmaxf(mx, bf2f(*(const bf16_t*)(ks + p * 256 + ch * 2)));
+            mx2[ph][ch] = mx;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const float m_old = m_s[tid], m_new = fmaxf(m_old, fmaxf(mx2[0][tid], mx2[1][tid]));
+            f_s[tid] = __expf(m_old - m_new);
+            m_s[tid] = m_new;
+        }
+        __syncthreads();
+        {   // exponentiate in place (bf16), row sums of the values as the MFMA will see them
+            const float m = m_s[ch];
+            float sum = 0.0f;
+            for (int p = ph; p < FC_CH; p += 2) {
+                bf16_t* a = (bf16_t*)(ks + p * 256 + ch * 2);
+                const bf16_t e = f2bf(__expf(bf2f(*a) - m));
+                *a = e;
+                sum += bf2f(e);
+            }
+            l2[ph][ch] = sum;
+        }
+        __syncthreads();
+        if (tid < 128) l_run = l_run * f_s[tid] + l2[0][tid] + l2[1][tid];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] *= f_s[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+        for (int sl = 0; sl < FC_CH / 16; ++sl) {
+            const bf16x8 kf = tr_frag(ks + sl * 16 * 256 + wave * 64, 256, lane);      // rows = d
+            const bf16x8 vf = tr_frag(vs + sl * 16 * 256 + wave * 64, 256, lane);      // cols = e
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, vf, acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* o = partial + ((size_t)(b * 4 + wave) * nparts + part) * 1088;
+    if (tid < 128) {
+        float* oh = partial + ((size_t)(b * 4 + (tid >> 5)) * nparts + part) * 1088;
+        oh[tid & 31] = m_s[tid];
+        oh[32 + (tid & 31)] = l_run;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[64 + ((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[r];
+}
+
+// context-shaped matrices of one sample as bf16 A operands in LDS: [4 heads][32 rows][40] (80-byte rows)
+__device__ __forceinline__ void lc_stage_matrix(unsigned char* lds, const float* __restrict__ src, bool transpose, int tid) {
+    for (int i = tid; i < 4096; i += 256) {
+        const int h = i >> 10, r = (i >> 5) & 31, c = i & 31;
+        const float v = src[i];
+        const int rr = transpose ? c : r, cc = transpose ? r : c;
+        *(bf16_t*)(lds + ((h * 32 + rr) * 40 + cc) * 2) = f2bf(v);
+    }
+}
+__device__ __forceinline__ bf16x8 lc_afrag(const unsigned char* lds, int h, int s, int l31, int half) {
+    return *(const bf16x8*)(lds + ((h * 32 + l31) * 40 + s * 16 + half * 8) * 2);
+}
+
+// ---- forward pass 2: out[n][e] = sum_d ctx[d][e] * softmax_d(q)[n][d] * scale; grid (gx, B) -----------------
+__global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ ctx, bf16_t* __restrict__ out, int n) {
+    __shared__ __attribute__((aligned(16))) unsigned char ct[4 * 32 * 80];      // ctx^T: rows e, k = d
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5, b = blockIdx.y;
+    lc_stage_matrix(ct, ctx + (size_t)b * 4096, true, tid);
+    __syncthreads();
+    for (int p0 = (blockIdx.x * 4 + wave) * 32; p0 < n; p0 += gridDim.x * 128) {
+        const int p = min(p0 + l31, n - 1);
+        const bf16_t* row = qkv + ((size_t)b * n + p) * 384;
+        bf16_t* orow = out + ((size_t)b * n + p) * 128;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            float q[16];
+            lc_unpack8(*(const u32x4*)(row + h * 32 + half * 8), &q[0]);
+            lc_unpack8(*(const u32x4*)(row + h * 32 + 16 + half * 8), &q[8]);
+            float mx = q[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) mx = fmaxf(mx, q[j]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { q[j] = __expf(q[j] - mx); sum += q[j]; }
+            sum += __shfl_xor(sum, 32, 64);
+            const float k = LC_SCALE * __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) q[j] *= k;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(ct, h, 0, l31, half), lc_frag(&q[0]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(ct, h, 1, l31, half), lc_frag(&q[8]), acc, 0, 0, 0);
+            if (p0 + l31 < n) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(uint2*)(orow + h * 32 + 8 * g + 4 * half) = make_uint2(f2bf2(acc[4 * g], acc[4 * g + 1]), f2bf2(acc[4 * g + 2], acc[4 * g + 3]));
+            }
+        }
+    }
+}
+
+// ---- backward pass 1: dctx[d][e] = sum_n qs[n][d] * dout[n][e]; partial per (sample*head, part); grid (nparts, B)
+__global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, float* __restrict__ partial,
+                                                              int n, int span, int nparts) {
+    __shared__ __attribute__((aligned(16))) unsigned char qs[LC_CH * 256];     // softmax_d(q) * scale, bf16, pixel-major
+    __shared__ __attribute__((aligned(16))) unsigned char gs[LC_CH * 256];     // dout
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int part = blockIdx.x, b = blockIdx.y;
+    const int n_begin = part * span, n_end = min(n, n_begin + span);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int c0 = n_begin; c0 < n_end; c0 += LC_CH) {
+        const int cnt = min(LC_CH, n_end - c0);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // item -> (pixel, head, half of d): 16 q values, softmax completed with the neighbouring lane
+            const int id = tid + i * 256, p = id >> 3, hh = (id >> 1) & 3, hf = id & 1;
+            const bool ok = p < cnt;
+            const size_t pix = (size_t)b * n + c0 + min(p, cnt - 1);
+            float q[16];
+            lc_unpack8(*(const u32x4*)(qkv + pix * 384 + hh * 32 + hf * 16), &q[0]);
+            lc_unpack8(*(const u32x4*)(qkv + pix * 384 + hh * 32 + hf * 16 + 8), &q[8]);
+            u32x4 g0 = *(const u32x4*)(dout + pix * 128 + hh * 32 + hf * 16);
+            u32x4 g1 = *(const u32x4*)(dout + pix * 128 + hh * 32 + hf * 16 + 8);
+            float mx = q[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) mx = fmaxf(mx, q[j]);
+            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { q[j] = __expf(q[j] - mx); sum += q[j]; }
+            sum += __shfl_xor(sum, 1, 64);
+            const float k = ok ? LC_SCALE * __builtin_amdgcn_rcpf(sum) : 0.0f;      // pixels past the end contribute nothing
+#pragma unroll
+            for (int j = 0; j < 16; ++j) q[j] *= k;
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { g0[j] = 0u; g1[j] = 0u; }
+            }
+            *(u32x4*)(qs + p * 256 + hh * 64 + hf * 32) = lc_pack8(&q[0]);
+            *(u32x4*)(qs + p * 256 + hh * 64 + hf * 32 + 16) = lc_pack8(&q[8]);
+            *(u32x4*)(gs + p * 256 + hh * 64 + hf * 32) = g0;
+            *(u32x4*)(gs + p * 256 + hh * 64 + hf * 32 + 16) = g1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < LC_CH / 16; ++sl) {
+            const bf16x8 qf = tr_frag(qs + sl * 16 * 256 + wave * 64, 256, lane);      // rows = d
+            const bf16x8 gf = tr_frag(gs + sl * 16 * 256 + wave * 64, 256, lane);      // cols = e
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, gf, acc, 0, 0, 0);
+        }
+    }
+    float* o = partial + ((size_t)(b * 4 + wave) * nparts + part) * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[r];
+}
+
+// ---- backward pass 2: per pixel; grid (gx, B) -----------------------------------------------------------
+//   dq_raw = sm(q) * (dq - <sm(q), dq>), dq = scale * ctx . dout          (MFMA rows d, A = ctx)
+//   dk_raw = k * (dctx . v / n - S),    k = exp(k_raw - M) / L            (MFMA rows d, A = dctx)
+//   dv     = dctx^T . k / n                                               (MFMA rows e, A = dctx^T)
+__global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ ctx,
+                                                           const float* __restrict__ dctx, const float* __restrict__ ml, const float* __restrict__ S,
+                                                           bf16_t* __restrict__ dqkv, int n) {
+    __shared__ __attribute__((aligned(16))) unsigned char cA[4 * 32 * 80], dA[4 * 32 * 80], dT[4 * 32 * 80];
+    __shared__ __attribute__((aligned(16))) float Ms[128], Li[128], Ss[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5, b = blockIdx.y;
+    lc_stage_matrix(cA, ctx + (size_t)b * 4096, false, tid);
+    lc_stage_matrix(dA, dctx + (size_t)b * 4096, false, tid);
+    lc_stage_matrix(dT, dctx + (size_t)b * 4096, true, tid);
+    if (tid < 128) {
+        Ms[tid] = ml[((size_t)b * 4 + (tid >> 5)) * 64 + (tid & 31)];
+        Li[tid] = ml[((size_t)b * 4 + (tid >> 5)) * 64 + 32 + (tid & 31)];
+        Ss[tid] = S[((size_t)b * 4 + (tid >> 5)) * 32 + (tid & 31)];
+    }
+    __syncthreads();
+    const float inv_n = 1.0f / (float)n;
+    for (int p0 = (blockIdx.x * 4 + wave) * 32; p0 < n; p0 += gridDim.x * 128) {
+        const int p = min(p0 + l31, n - 1);
+        const bool ok = p0 + l31 < n;
+        const bf16_t* row = qkv + ((size_t)b * n + p) * 384;
+        const bf16_t* grow = dout + ((size_t)b * n + p) * 128;
+        bf16_t* drow = dqkv + ((size_t)b * n + p) * 384;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            f32x16 acc;
+            // ---- dq
+            const bf16x8 g0 = *(const bf16x8*)(grow + h * 32 + half * 8), g1 = *(const bf16x8*)(grow + h * 32 + 16 + half * 8);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(cA, h, 0, l31, half), g0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(cA, h, 1, l31, half), g1, acc, 0, 0, 0);
+            {
+                float q[16];      // accumulator layout: register 4g+j <-> d = 8g + 4*half + j
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint2 v = *(const uint2*)(row + h * 32 + 8 * g + 4 * half);
+                    q[4 * g] = bf2f((bf16_t)(v.x & 0xffffu)); q[4 * g + 1] = bf2f((bf16_t)(v.x >> 16));
+                    q[4 * g + 2] = bf2f((bf16_t)(v.y & 0xffffu)); q[4 * g + 3] = bf2f((bf16_t)(v.y >> 16));
+                }
+                float mx = q[0];
+#pragma unroll
+                for (int j = 1; j < 16; ++j) mx = fmaxf(mx, q[j]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { q[j] = __expf(q[j] - mx); sum += q[j]; }
+                sum += __shfl_xor(sum, 32, 64);
+                const float rs = __builtin_amdgcn_rcpf(sum);
+                float t = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { q[j] *= rs; acc[j] *= LC_SCALE; t += q[j] * acc[j]; }
+                t += __shfl_xor(t, 32, 64);
+                if (ok) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *(uint2*)(drow + h * 32 + 8 * g + 4 * half) =
+                            make_uint2(f2bf2(q[4 * g] * (acc[4 * g] - t), q[4 * g + 1] * (acc[4 * g + 1] - t)),
+                                       f2bf2(q[4 * g + 2] * (acc[4 * g + 2] - t), q[4 * g + 3] * (acc[4 * g + 3] - t)));
+                }
+            }
+            // ---- dk
+            const bf16x8 v0 = *(const bf16x8*)(row + 256 + h * 32 + half * 8), v1 = *(const bf16x8*)(row + 256 + h * 32 + 16 + half * 8);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dA, h, 0, l31, half), v0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dA, h, 1, l31, half), v1, acc, 0, 0, 0);
+            if (ok) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = h * 32 + 8 * g + 4 * half;
+                    const uint2 kv = *(const uint2*)(row + 128 + d0);
+                    const float4 m4 = *(const float4*)&Ms[d0], l4 = *(const float4*)&Li[d0], s4 = *(const float4*)&Ss[d0];
+                    const float k0 = __expf(bf2f((bf16_t)(kv.x & 0xffffu)) - m4.x) * l4.x, k1 = __expf(bf2f((bf16_t)(kv.x >> 16)) - m4.y) * l4.y;
+                    const float k2 = __expf(bf2f((bf16_t)(kv.y & 0xffffu)) - m4.z) * l4.z, k3 = __expf(bf2f((bf16_t)(kv.y >> 16)) - m4.w) * l4.w;
+                    *(uint2*)(drow + 128 + d0) = make_uint2(f2bf2(k0 * (acc[4 * g] * inv_n - s4.x), k1 * (acc[4 * g + 1] * inv_n - s4.y)),
+                                                            f2bf2(k2 * (acc[4 * g + 2] * inv_n - s4.z), k3 * (acc[4 * g + 3] * inv_n - s4.w)));
+                }
+            }
+            // ---- dv
+            float kk[16];
+            lc_unpack8(*(const u32x4*)(row + 128 + h * 32 + half * 8), &kk[0]);
+            lc_unpack8(*(const u32x4*)(row + 128 + h * 32 + 16 + half * 8), &kk[8]);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int d0 = h * 32 + 16 * s + 8 * half;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) kk[8 * s + j] = __expf(kk[8 * s + j] - Ms[d0 + j]) * Li[d0 + j];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dT, h, 0, l31, half), lc_frag(&kk[0]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dT, h, 1, l31, half), lc_frag(&kk[8]), acc, 0, 0, 0);
+            if (ok) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(uint2*)(drow + 256 + h * 32 + 8 * g + 4 * half) =
+                        make_uint2(f2bf2(acc[4 * g] * inv_n, acc[4 * g + 1] * inv_n), f2bf2(acc[4 * g + 2] * inv_n, acc[4 * g + 3] * inv_n));
+            }
+        }
+    }
+}
+
+// combine of backward pass 1 (also used by the forward's la_ctx_combine in blocks.hip for the ctx partials)
+__global__ void __launch_bounds__(256) lc_bwd_combine_kernel(const float* __restrict__ partial, const float* __restrict__ ctx, float* __restrict__ dctx,
+                                                             float* __restrict__ S, int nparts) {
+    __shared__ float prod[1024];
+    const int tid = threadIdx.x, bh = blockIdx.x;
+    for (int i = tid; i < 1024; i += 256) {
+        float a = 0.0f;
+        for (int c = 0; c < nparts; ++c) a += partial[((size_t)bh * nparts + c) * 1024 + i];
+        dctx[(size_t)bh * 1024 + i] = a;
+        prod[i] = a * ctx[(size_t)bh * 1024 + i];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float s = 0.0f;
+        for (int e = 0; e < 32; ++e) s += prod[tid * 32 + e];
+        S[(size_t)bh * 32 + tid] = s;
+    }
+}
+
+static inline void lc_parts(int B, int n, int& nparts, int& span) {
+    // enough workgroups to fill the chip in the reduction passes; spans are multiples of the 128-pixel chunk
+    nparts = cdiv(768, B);
+    const int maxp = cdiv(n, 512);
+    if (nparts > maxp) nparts = maxp;
+    if (nparts < 1) nparts = 1;
+    span = cdiv(cdiv(n, nparts), LC_CH) * LC_CH;
+    nparts = cdiv(n, span);
+}
+int la_parts(int B, int n) { int np, sp; lc_parts(B, n, np, sp); return np; }
+
+void launch_la_ctx_combine(const float* partial, float* ctx, int B, int nparts, float inv_n, float* ml_out, hipStream_t s);   // blocks.hip
+
+int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s, float* ml_out) {
+    int nparts, span;
+    lc_parts(B, n, nparts, span);
+    lc_ctx_partial_kernel<<<dim3(nparts, B), 256, 0, s>>>(qkv, partial, n, span, nparts);
+    launch_la_ctx_combine(partial, ctx, B, nparts, 1.0f / (float)n, ml_out, s);
+    int gx = cdiv(n, 128);
+    if (gx > 1024) gx = 1024;
+    lc_out_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, ctx, out, n);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+size_t la_bwd_workspace_floats(int B, int n) { return (size_t)B * 4 * ((size_t)la_parts(B, n) * 1024 + 1024 + 32); }
+
+int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const float* ctx, const float* ml, bf16_t* dqkv, float* workspace, int B, int n,
+                                hipStream_t s) {
+    int nparts, span;
+    lc_parts(B, n, nparts, span);
+    float* partial = workspace;
+    float* dctx = partial + (size_t)B * 4 * nparts * 1024;
+    float* S = dctx + (size_t)B * 4 * 1024;
+    lc_dctx_partial_kernel<<<dim3(nparts, B), 256, 0, s>>>(qkv, dout, partial, n, span, nparts);
+    lc_bwd_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, dctx, S, nparts);
+    int gx = cdiv(n, 128);
+    if (gx > 1024) gx = 1024;
+    lc_bwd_apply_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, dout, ctx, dctx, ml, S, dqkv, n);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+}  // namespace ofd

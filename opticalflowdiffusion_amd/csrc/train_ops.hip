@@ -50,18 +50,18 @@ __global__ void __launch_bounds__(256) affine_silu_kernel(const bf16_t* __restri
 }
 
 // ---- backward of out = SiLU(GN-affine(h)), pass 1: per (sample, channel) sums of du and du*h --------
-// du = g * silu'(a h + s).  grid (chunks, B); partial[b][chunk][C][2]
+// du = g * silu'(a h + s); also sum h (for the bias gradient of the conv that made h).  grid (chunks, B); partial[b][chunk][C][3]
 __global__ void __launch_bounds__(256) gnbwd_reduce_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ h, const float* __restrict__ a,
                                                            const float* __restrict__ s, float* __restrict__ partial, int C, size_t pix_per_sample,
                                                            int pix_per_chunk) {
-    __shared__ float red[256][17];
+    __shared__ float red[256][25];
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, c8n = C / 8;
     const size_t p0 = (size_t)chunk * pix_per_chunk, p1 = min(pix_per_sample, p0 + pix_per_chunk);
     for (int cu0 = 0; cu0 < c8n; cu0 += 256) {
         const int lanes_c = min(c8n - cu0, 256), rows = 256 / lanes_c, my_c = tid % lanes_c, my_r = tid / lanes_c;
-        float a1[8], a2[8];
+        float a1[8], a2[8], a3[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { a1[j] = 0.0f; a2[j] = 0.0f; }
+        for (int j = 0; j < 8; ++j) { a1[j] = 0.0f; a2[j] = 0.0f; a3[j] = 0.0f; }
         if (my_r < rows) {
             float av[8], sv[8];
             load8f(a + (size_t)b * C + (cu0 + my_c) * 8, av);
@@ -76,20 +76,22 @@ __global__ void __launch_bounds__(256) gnbwd_reduce_kernel(const bf16_t* __restr
                     const float du = gv[j] * t_dsilu(hv[j] * av[j] + sv[j]);
                     a1[j] += du;
                     a2[j] += du * hv[j];
+                    a3[j] += hv[j];
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { red[tid][j] = a1[j]; red[tid][8 + j] = a2[j]; }
+        for (int j = 0; j < 8; ++j) { red[tid][j] = a1[j]; red[tid][8 + j] = a2[j]; red[tid][16 + j] = a3[j]; }
         __syncthreads();
         if (tid < lanes_c) {
-            float* o = partial + (((size_t)b * gridDim.x + chunk) * C + (cu0 + tid) * 8) * 2;
+            float* o = partial + (((size_t)b * gridDim.x + chunk) * C + (cu0 + tid) * 8) * 3;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float s1 = 0.0f, s2 = 0.0f;
-                for (int r = 0; r < rows; ++r) { s1 += red[r * lanes_c + tid][j]; s2 += red[r * lanes_c + tid][8 + j]; }
-                o[2 * j] = s1;
-                o[2 * j + 1] = s2;
+                float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+                for (int r = 0; r < rows; ++r) { s1 += red[r * lanes_c + tid][j]; s2 += red[r * lanes_c + tid][8 + j]; s3 += red[r * lanes_c + tid][16 + j]; }
+                o[3 * j] = s1;
+                o[3 * j + 1] = s2;
+                o[3 * j + 2] = s3;
             }
         }
         __syncthreads();
@@ -99,21 +101,24 @@ __global__ void __launch_bounds__(256) gnbwd_reduce_kernel(const bf16_t* __restr
 // pass 2 (tiny): grid (B, 8 groups).  stats[b][g] = {mean, rstd} saved by the forward.
 //   dh = a*du + c2*h + c3 ; c2 = -r^2 G2/N ; c3 = -r G1/N + r^2 mu G2/N
 //   dgamma += scp*S ; dbeta += scp*A1 ; dscale[b,c] = gamma*S + beta*A1 ; dshift[b,c] = A1     (S = r (A2 - mu A1))
-__global__ void __launch_bounds__(256) gnbwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, double count,
+//   dconv_bias[c] += sum_pixels dh = a*A1 + c2*sum(h) + c3*HW      (bias of the conv that produced h; optional)
+__global__ void __launch_bounds__(256) gnbwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, double count, double hw,
                                                              const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             const float* __restrict__ ss, int ss_stride, int ss_offset, float* __restrict__ c2c3,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dss) {
+                                                             const float* __restrict__ a_aff, const float* __restrict__ ss, int ss_stride, int ss_offset,
+                                                             float* __restrict__ c2c3, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ dss, float* __restrict__ dconv_bias) {
     __shared__ double g1s[256], g2s[256];
-    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, gs = C / 8;
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, gs = C / 8;     // gs <= 64: at most one channel per thread
     const float mu = stats[((size_t)b * 8 + g) * 2], r = stats[((size_t)b * 8 + g) * 2 + 1];
-    double G1 = 0.0, G2 = 0.0;
-    for (int cc = tid; cc < gs; cc += 256) {
-        const int c = g * gs + cc;
-        double A1 = 0.0, A2 = 0.0;
+    double G1 = 0.0, G2 = 0.0, A1 = 0.0, A3 = 0.0;
+    const int c = g * gs + tid;
+    if (tid < gs) {
+        double A2 = 0.0;
         for (int k = 0; k < chunks; ++k) {
-            const float* p = partial + (((size_t)b * chunks + k) * C + c) * 2;
+            const float* p = partial + (((size_t)b * chunks + k) * C + c) * 3;
             A1 += (double)p[0];
             A2 += (double)p[1];
+            A3 += (double)p[2];
         }
         const float scp = ss ? ss[(size_t)b * ss_stride + ss_offset + c] + 1.0f : 1.0f;
         const double S = (double)r * (A2 - (double)mu * A1);
@@ -123,8 +128,8 @@ __global__ void __launch_bounds__(256) gnbwd_finalize_kernel(const float* __rest
             dss[(size_t)b * ss_stride + ss_offset + c] = (float)(gamma[c] * S + beta[c] * A1);
             dss[(size_t)b * ss_stride + ss_offset + C + c] = (float)A1;
         }
-        G1 += (double)gamma[c] * scp * A1;
-        G2 += (double)gamma[c] * scp * S;
+        G1 = (double)gamma[c] * scp * A1;
+        G2 = (double)gamma[c] * scp * S;
     }
     g1s[tid] = G1;
     g2s[tid] = G2;
@@ -133,11 +138,13 @@ __global__ void __launch_bounds__(256) gnbwd_finalize_kernel(const float* __rest
         if (tid < k) { g1s[tid] += g1s[tid + k]; g2s[tid] += g2s[tid + k]; }
         __syncthreads();
     }
+    const double rr = (double)r, N = count;
+    const double c2 = -rr * rr * g2s[0] / N, c3 = -rr * g1s[0] / N + rr * rr * (double)mu * g2s[0] / N;
     if (tid == 0) {
-        const double rr = (double)r, N = count;
-        c2c3[((size_t)b * 8 + g) * 2] = (float)(-rr * rr * g2s[0] / N);
-        c2c3[((size_t)b * 8 + g) * 2 + 1] = (float)(-rr * g1s[0] / N + rr * rr * (double)mu * g2s[0] / N);
+        c2c3[((size_t)b * 8 + g) * 2] = (float)c2;
+        c2c3[((size_t)b * 8 + g) * 2 + 1] = (float)c3;
     }
+    if (dconv_bias && tid < gs) atomicAdd(dconv_bias + c, (float)((double)a_aff[(size_t)b * C + c] * A1 + c2 * A3 + c3 * hw));
 }
 
 // pass 3: dh = a * g * silu'(a h + s) + c2[b,grp] * h + c3[b,grp]
@@ -376,24 +383,37 @@ int k_affine_silu(const bf16_t* h, const float* a, const float* s, bf16_t* out, 
     return OFD_OK;
 }
 
+static inline void gn_bwd_chunks(int B, size_t pps, int& chunks, int& ppc) {
+    // ~1024 workgroups in the reduction pass whatever the resolution, at least 64 pixels each
+    chunks = cdiv(1024, B);
+    const int maxc = cdiv((long)pps, 64);
+    if (chunks > maxc) chunks = maxc;
+    if (chunks < 1) chunks = 1;
+    ppc = cdiv((long)pps, chunks);
+    chunks = cdiv((long)pps, ppc);
+}
+
 size_t gn_bwd_workspace_floats(int B, int H, int W, int C) {
-    const int chunks = cdiv((long)H * W, 2048);
-    return (size_t)B * chunks * C * 2 + (size_t)B * 16;
+    int chunks, ppc;
+    gn_bwd_chunks(B, (size_t)H * W, chunks, ppc);
+    return (size_t)B * chunks * C * 3 + (size_t)B * 16;
 }
 
 // g: gradient w.r.t. SiLU output; h: the conv output GroupNorm normalised; (a, s): the folded affine;
-// stats: [B][8][{mean, rstd}]; ss/dss: per-sample scale|shift rows of this block (NULL for block2)
+// stats: [B][8][{mean, rstd}]; ss/dss: per-sample scale|shift rows of this block (NULL for block2);
+// dconv_bias (optional): += bias gradient of the convolution that produced h
 int k_gn_silu_backward(const bf16_t* g, const bf16_t* h, const float* a, const float* s, const float* stats, const float* gamma,
                        const float* beta, const float* ss, int ss_stride, int ss_offset, bf16_t* dh, float* dgamma, float* dbeta, float* dss,
-                       float* workspace, int B, int H, int W, int C, hipStream_t st) {
-    OFD_CHECK_ARG(C % 64 == 0, "gn_silu_backward: C=%d", C);
+                       float* workspace, int B, int H, int W, int C, hipStream_t st, float* dconv_bias) {
+    OFD_CHECK_ARG(C % 64 == 0 && C <= 512, "gn_silu_backward: C=%d", C);
     const size_t pps = (size_t)H * W;
-    const int ppc = 2048, chunks = cdiv((long)pps, ppc);
+    int chunks, ppc;
+    gn_bwd_chunks(B, pps, chunks, ppc);
     float* partial = workspace;
-    float* c2c3 = workspace + (size_t)B * chunks * C * 2;
+    float* c2c3 = workspace + (size_t)B * chunks * C * 3;
     gnbwd_reduce_kernel<<<dim3(chunks, B), 256, 0, st>>>(g, h, a, s, partial, C, pps, ppc);
-    gnbwd_finalize_kernel<<<dim3(B, 8), 256, 0, st>>>(partial, chunks, C, (double)pps * (C / 8), stats, gamma, beta, ss, ss_stride, ss_offset, c2c3,
-                                                    dgamma, dbeta, dss);
+    gnbwd_finalize_kernel<<<dim3(B, 8), 256, 0, st>>>(partial, chunks, C, (double)pps * (C / 8), (double)pps, stats, gamma, beta, a, ss, ss_stride,
+                                                    ss_offset, c2c3, dgamma, dbeta, dss, dconv_bias);
     const size_t units = (size_t)B * pps * (C / 8);
     gnbwd_apply_kernel<<<tgrid(units), 256, 0, st>>>(g, h, a, s, c2c3, dh, C, pps, units);
     OFD_LAUNCH_CHECK();
@@ -448,10 +468,10 @@ using namespace ofd;
 extern "C" size_t ofd_gn_bwd_workspace_floats(int B, int H, int W, int C) { return gn_bwd_workspace_floats(B, H, W, C); }
 extern "C" int ofd_gn_silu_backward(const void* g, const void* h, const float* a, const float* s, const float* stats, const float* gamma,
                                     const float* beta, const float* ss, int ss_stride, int ss_offset, void* dh, float* dgamma, float* dbeta,
-                                    float* dss, float* workspace, int B, int H, int W, int C, void* stream) {
+                                    float* dss, float* dconv_bias, float* workspace, int B, int H, int W, int C, void* stream) {
     OFD_CHECK_ARG(g && h && a && s && stats && gamma && beta && dh && dgamma && dbeta && workspace, "gn_silu_backward: null argument");
     return k_gn_silu_backward((const bf16_t*)g, (const bf16_t*)h, a, s, stats, gamma, beta, ss, ss_stride, ss_offset, (bf16_t*)dh, dgamma, dbeta, dss,
-                              workspace, B, H, W, C, (hipStream_t)stream);
+                              workspace, B, H, W, C, (hipStream_t)stream, dconv_bias);
 }
 extern "C" int ofd_affine_silu(const void* h, const float* a, const float* s, void* out, int B, int H, int W, int C, void* stream) {
     OFD_CHECK_ARG(h && a && s && out && C % 8 == 0, "affine_silu: bad argument");

@@ -207,7 +207,7 @@ static Tensor linattn(Ctx& c, const std::string& name, Tensor x) {
         return y;
     }
     Tensor xn = c.tmp(C, H, W), qkv = c.tmp(384, H, W), ao = c.tmp(128, H, W), o2 = c.tmp(C, H, W);
-    const int nparts = la_parts(n);
+    const int nparts = la_parts(B, n);
     float* partial = c.tmpf((size_t)B * 4 * nparts * 1088);
     float* ctx = c.train ? c.keepf((size_t)B * 4 * 1024) : c.tmpf((size_t)B * 4 * 1024);
     float* ml = c.train ? c.keepf((size_t)B * 4 * 64) : nullptr;
@@ -393,7 +393,7 @@ size_t scratch_bytes(const ofd_unet* u, int B, int H, int W) {
     const int C = u->dims[0];
     size_t act = px * 2 * (size_t)(3 * C + C + 384 + 128 + C);
     // mid level widest: 512 ch at 1/64 of the pixels is far smaller; small buffers:
-    size_t small = 4 * ofd_conv_gn_partial_count(B, H, W, u->dims[4]) * 4 + (size_t)B * 4 * ((size_t)(la_parts(H * W) > 256 ? la_parts(H * W) : 256) * 1088 + 1024) * 4 +
+    size_t small = 4 * ofd_conv_gn_partial_count(B, H, W, u->dims[4]) * 4 + (size_t)B * 4 * ((size_t)(la_parts(B, H * W) > 256 ? la_parts(B, H * W) : 256) * 1088 + 1024) * 4 +
                    16 * (size_t)B * u->dims[4] * 4 + 64 * 1024;
     return act + small + 64 * 256;
 }

@@ -43,8 +43,11 @@ static void fill_args(ofd_conv_args& a, int B, int H, int W, int ksize, int Cout
 
 // backward of one convolution: bias and weight gradients into the flat gradient buffer; returns the
 // gradient w.r.t. the concatenated (virtual) input [B][H][W][cin] in scratch (+ `add` when given)
+// gradient w.r.t. a single same-resolution source goes straight into that source's gradient buffer
+static bool direct_target(const std::vector<SrcSpec>& srcs) { return srcs.size() == 1 && !srcs[0].upsample && !srcs[0].unshuffle && srcs[0].t.g; }
+
 static Tensor conv_backward(Bwd& b, const std::string& prefix, const std::vector<SrcSpec>& srcs, const bf16_t* dy, int H, int W, bool need_dx,
-                            const bf16_t* add) {
+                            const bf16_t* add, bool bias_done = false, bool to_source = false) {
     Ctx& c = b.c;
     ofd_unet* u = c.u;
     Tensor D;
@@ -54,7 +57,8 @@ static Tensor conv_backward(Bwd& b, const std::string& prefix, const std::vector
     int cin = 0;
     for (auto& s : srcs) cin += s.t.C;
     const double px = (double)B * H * W;
-    if (float* gb = u->G(prefix + ".bias")) {
+    float* gb = bias_done ? nullptr : u->G(prefix + ".bias");     // (block convs: the GroupNorm backward already summed dh)
+    if (gb) {
         c.begin(PC_MISC, 0, px * d.Cout * 2, prefix + " dbias");
         RUN(k_channel_sum(dy, gb, (size_t)B * H * W, d.Cout, c.s));
         c.end();
@@ -74,7 +78,21 @@ static Tensor conv_backward(Bwd& b, const std::string& prefix, const std::vector
     RUN(k_wgrad_finish(acc, u->P(d.wname), u->G(d.wname), d.Cout, d.Cin, d.Cin_pad, d.ksize, d.ws_eps, d.unshuffle, 0, c.s));
     c.end();
     if (!need_dx) return D;
-    D = b.stmp(cin, H, W);
+    const bool direct = to_source && direct_target(srcs);
+    if (direct) {
+        // (+)= into the source's gradient: the conv epilogue adds `residual`, which may alias the output
+        const Tensor& t = srcs[0].t;
+        if (b.has(t) && add) {
+            RUN(k_grad_add(t.g, add, (size_t)B * H * W * cin, 1, c.s));
+            add = t.g;
+        } else if (b.has(t)) {
+            add = t.g;
+        }
+        D = t; D.p = t.g;
+        b.mark(t);
+    } else {
+        D = b.stmp(cin, H, W);
+    }
     if (c.rc != OFD_OK) return D;
     ofd_conv_args a{};
     a.B = B; a.H = H; a.W = W; a.ksize = d.ksize; a.n_src = 1; a.Cout = cin;
@@ -120,26 +138,29 @@ static void resblock_backward(Bwd& b, const TapeRec& r, float* dss, float* dts) 
     // out = SiLU(GN2(h2)) + res
     c.begin(PC_GNBWD, 0, ew * 5, name + ".block2 gn-silu bwd");
     RUN(k_gn_silu_backward(dout, r.h2.p, r.a2, r.s2, r.st2, u->P(name + ".block2.norm.weight"), u->P(name + ".block2.norm.bias"), nullptr, 0, 0,
-                           r.h2.g, u->G(name + ".block2.norm.weight"), u->G(name + ".block2.norm.bias"), nullptr, ws, B, H, W, Cout, c.s));
+                           r.h2.g, u->G(name + ".block2.norm.weight"), u->G(name + ".block2.norm.bias"), nullptr, ws, B, H, W, Cout, c.s,
+                           u->G(name + ".block2.proj.bias")));
     c.end();
     // h2 = conv2(act1), act1 = SiLU(GN1(h1) * (scale + 1) + shift): recomputed, the forward fused it into conv2's loader
     c.begin(PC_GNBWD, 0, ew * 2, name + " act1 recompute");
     RUN(k_affine_silu(r.h1.p, r.a1, r.s1, act1.p, B, H, W, Cout, c.s));
     c.end();
     SrcSpec sa; sa.t = act1;
-    Tensor dact1 = conv_backward(b, name + ".block2.proj", {sa}, r.h2.g, H, W, true, nullptr);
+    Tensor dact1 = conv_backward(b, name + ".block2.proj", {sa}, r.h2.g, H, W, true, nullptr, true);
     c.begin(PC_GNBWD, 0, ew * 5, name + ".block1 gn-silu bwd");
     RUN(k_gn_silu_backward(dact1.p, r.h1.p, r.a1, r.s1, r.st1, u->P(name + ".block1.norm.weight"), u->P(name + ".block1.norm.bias"), c.ss,
                            u->ss_stride, u->ss_offset.at(name), r.h1.g, u->G(name + ".block1.norm.weight"), u->G(name + ".block1.norm.bias"), dss,
-                           ws, B, H, W, Cout, c.s));
+                           ws, B, H, W, Cout, c.s, u->G(name + ".block1.proj.bias")));
     RUN(k_block_mlp_bwd(dss, u->ts.temb_silu, u->P(name + ".mlp.1.weight"), 2 * Cout, u->ss_offset.at(name), u->G(name + ".mlp.1.weight"),
                         u->G(name + ".mlp.1.bias"), dts, B, u->cfg.dim * 4, u->ss_stride, c.s));
     c.end();
     Tensor D;
     if (cin == Cout) {
-        D = conv_backward(b, name + ".block1.proj", r.srcs, r.h1.g, H, W, true, dout);           // + identity residual
+        const bool direct = direct_target(r.srcs);
+        D = conv_backward(b, name + ".block1.proj", r.srcs, r.h1.g, H, W, true, dout, true, direct);     // + identity residual
+        if (direct) return;
     } else {
-        Tensor D1 = conv_backward(b, name + ".block1.proj", r.srcs, r.h1.g, H, W, true, nullptr);
+        Tensor D1 = conv_backward(b, name + ".block1.proj", r.srcs, r.h1.g, H, W, true, nullptr, true);
         D = conv_backward(b, name + ".res_conv", r.srcs, dout, H, W, true, D1.p);
     }
     if (c.rc != OFD_OK) return;
@@ -251,8 +272,9 @@ static int run_backward(Ctx& c, const float* dout, const TrainLayout& L, float* 
             case TK_MIDATTN: midattn_backward(b, r); break;
             default: {
                 const bool first = r.name == "init_conv";
-                Tensor D = conv_backward(b, r.name, r.srcs, r.out.g, r.out.H, r.out.W, !first, nullptr);
-                if (!first && c.rc == OFD_OK) scatter_to_sources(b, D, r.srcs);
+                const bool direct = direct_target(r.srcs);
+                Tensor D = conv_backward(b, r.name, r.srcs, r.out.g, r.out.H, r.out.W, !first, nullptr, false, direct);
+                if (!first && !direct && c.rc == OFD_OK) scatter_to_sources(b, D, r.srcs);
             }
         }
         notify(r.name);

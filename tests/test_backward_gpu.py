@@ -172,12 +172,14 @@ def test_gn_silu_backward(L, B, H, W, C, with_ss):
     dh = torch.empty_like(hd_)
     dgam, dbet = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
     dss = torch.zeros_like(ssd)
+    dcb = torch.zeros(C, device="cuda")
     wsp = torch.empty(L.lib().ofd_gn_bwd_workspace_floats(B, H, W, C), device="cuda")
     L.check(L.lib().ofd_gn_silu_backward(L.ptr(gd), L.ptr(hd_), L.ptr(ad), L.ptr(sd), L.ptr(std), L.ptr(gam), L.ptr(bet),
                                          L.ptr(ssd) if with_ss else None, ssd.shape[1], off, L.ptr(dh), L.ptr(dgam), L.ptr(dbet),
-                                         L.ptr(dss) if with_ss else None, L.ptr(wsp), B, H, W, C, L.stream()))
+                                         L.ptr(dss) if with_ss else None, L.ptr(dcb), L.ptr(wsp), B, H, W, C, L.stream()))
     torch.cuda.synchronize()
     assert rel_l2(from_nhwc(dh), h.grad) < TOL
+    assert rel_l2(dcb.cpu(), h.grad.sum(dim=(0, 2, 3))) < TOL          # bias gradient of the conv in front
     assert rel_l2(dgam.cpu(), gamma.grad) < TOL and rel_l2(dbet.cpu(), beta.grad) < TOL
     if with_ss:
         assert rel_l2(dss.cpu(), ss.grad) < TOL
