@@ -133,6 +133,119 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams P) {
     }
 }
 
+// 3x3: all nine taps in one workgroup.  grid (pixel-tile groups, (Cin/64)*(Cout/64)); 4 waves, wave -> 32 ci x 32 co x 9 taps
+// (144 accumulator registers).  The 10 x 34 halo tile and the 8 x 32 dY tile are read from HBM once per
+// (ci block, co block): 248 flop per byte, against 83 for one kernel row per workgroup.  The halo rows are
+// walked once; a halo row rr feeds output rows rr, rr-1, rr-2 (ky = 0, 1, 2), whose dY fragments stay in a
+// three-row register window: 8 fragment reads per 18 MFMAs.
+__global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P) {
+    constexpr int IWK = 34, XROWS = 10, XPIX = XROWS * IWK, YPIX = 256;
+    constexpr int XPT = (XPIX * 8 + 255) / 256, YPT = YPIX * 8 / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xs = smem;                  // [XPIX][64 ch] bf16, pixel-major
+    unsigned char* ys = smem + XPIX * 128;     // [YPIX][64 co]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int ncob = P.Cout / 64, kc = blockIdx.y / ncob, cob = blockIdx.y % ncob;
+    const int cit = wave & 1, cot = wave >> 1;
+    const int tpi = P.tiles_x * P.tiles_y, ntiles = tpi * P.B;
+    int si = 0, first = 0;
+    while (si + 1 < P.n_src && kc >= first + P.src[si].chunks) { first += P.src[si].chunks; ++si; }
+    const int kcl = kc - first;
+    const ConvSrcDev S = P.src[si];
+    const int c8 = tid & 7;
+
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][k][r] = 0.0f;
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int b = t / tpi, t_in = t - b * tpi;
+        const int oy0 = (t_in / P.tiles_x) * 8, ox0 = (t_in % P.tiles_x) * 32;
+        u32x4 xr[XPT];
+        unsigned xok = 0;
+        const bf16_t* xbase = S.ptr + (size_t)b * S.SH * S.SW * S.src_channels + S.ch_offset + kcl * 64 + c8 * 8;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int p = min((tid >> 3) + i * 32, XPIX - 1);
+            const int ty = p / IWK, tx = p - ty * IWK;
+            const int iy = oy0 + ty - 1, ix = ox0 + tx - 1;
+            const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+            xok |= (ok ? 1u : 0u) << i;
+            const int cy = min(max(iy, 0), P.H - 1), cx = min(max(ix, 0), P.W - 1);
+            int sy = cy, sx = cx;
+            if (S.mode == 1) { sy = cy >> 1; sx = cx >> 1; }
+            else if (S.mode == 2) { sy = 2 * cy + S.p1; sx = 2 * cx + S.p2; }
+            xr[i] = *(const u32x4*)(xbase + ((size_t)sy * S.SW + sx) * S.src_channels);
+        }
+        __syncthreads();     // previous tile's operand reads are complete
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int p = (tid >> 3) + i * 32;
+            u32x4 v = xr[i];
+            const bool ok = (xok >> i) & 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
+            if (p < XPIX) *(u32x4*)(xs + p * 128 + c8 * 16) = v;
+        }
+        // (dY tile fetched after the halo tile left its registers: both at once do not fit two workgroups per CU)
+        u32x4 yr[YPT];
+        unsigned yok = 0;
+#pragma unroll
+        for (int i = 0; i < YPT; ++i) {
+            const int p = (tid >> 3) + i * 32;
+            const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
+            const bool ok = oy < P.H && ox < P.W;
+            yok |= (ok ? 1u : 0u) << i;
+            yr[i] = *(const u32x4*)(P.dy + (((size_t)b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1)) * P.Cout + cob * 64 + c8 * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < YPT; ++i) {
+            const int p = (tid >> 3) + i * 32;
+            u32x4 v = yr[i];
+            const bool ok = (yok >> i) & 1u;      // pixels of the tile overhang contribute nothing
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
+            *(u32x4*)(ys + p * 128 + c8 * 16) = v;
+        }
+        __syncthreads();
+        bf16x8 yw[3][2];     // dY fragments of output rows rr, rr-1, rr-2
+#pragma unroll
+        for (int rr = 0; rr < XROWS; ++rr) {
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb) {
+                yw[2][xb] = yw[1][xb];
+                yw[1][xb] = yw[0][xb];
+                if (rr < 8) yw[0][xb] = tr_frag(ys + ((rr * 32 + xb * 16) * 64 + cot * 32) * 2, 128, lane);
+            }
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bf16x8 xf = tr_frag(xs + ((rr * IWK + xb * 16 + kx) * 64 + cit * 32) * 2, 128, lane);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+                        if (rr - ky >= 0 && rr - ky < 8)
+                            acc[ky][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yw[ky][xb], acc[ky][kx], 0, 0, 0);   // rows = ci, cols = co
+                }
+        }
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            float* d = P.dw + ((size_t)(ky * 3 + kx) * P.Cin_total + kc * 64 + cit * 32) * P.Cout + cob * 64 + cot * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
+                atomicAdd(d + (size_t)ci * P.Cout, acc[ky][kx][r]);
+            }
+        }
+}
+
 // 7x7 init conv (Cin padded to 16, Cout = 64): dW[tap][ci<16][co] = sum_p X16[p + tap][ci] dY[p][co].
 // MFMA over pixels like conv_wgrad_kernel.  The halo tile keeps 16 channels = 32 B per pixel, so the
 // "second 16-channel block" of a transposing fragment read is simply the NEXT PIXEL: one 32-row A
@@ -374,10 +487,13 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
     if (gx > ntiles) gx = ntiles;
     OFD_CHECK_ARG(combos <= 65535, "conv_wgrad: too many channel blocks");
     if (a->ksize == 3) {
-        constexpr int LDS = 8 * 34 * 128 + 256 * 128;
+        constexpr int LDS = 10 * 34 * 128 + 256 * 128;
         static bool attr = false;
-        if (!attr) { OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
-        conv_wgrad_kernel<3><<<dim3(gx, 3, combos), 256, LDS, s>>>(P);
+        if (!attr) { OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+        gx = cdiv(512, combos);                  // two workgroups per CU fit (75.5 KB LDS each)
+        if (gx < 1) gx = 1;
+        if (gx > ntiles) gx = ntiles;
+        conv_wgrad3_kernel<<<dim3(gx, combos), 256, LDS, s>>>(P);
     } else {
         constexpr int LDS = 8 * 32 * 128 + 256 * 128;
         static bool attr = false;
