@@ -48,6 +48,50 @@ def cpu_baseline(H, W, batch):
             "sample": f"1 of {batch} samples: one fp32 UNet forward at 1x5x{H}x{W} in {dt:.1f} s, scaled x{batch}"}
 
 
+TRAIN_TFLOP_PER_SAMPLE = 4.8917       # fwd + bwd = 2.99 x fwd (ch=5 @ 440x1024)
+
+
+def train_leg(args, dev, rank, world, H, W):
+    """SURVEY 8d 'report also train steps/sec' (configs C2 / C4): FlowDiffuser.training_step (HIP training
+    forward + backward) + fused Adam with clipping, per-GPU batch as the denoise leg; for world > 1 the
+    gradients are averaged with the bucketed RCCL all-reduce overlapped with the backward."""
+    from opticalflowdiffusion_amd import FlowDiffuser, parallel
+    B = args.batch
+    torch.manual_seed(0)
+    fd = FlowDiffuser(dict(target="flow", image_size=[H, W], timesteps=1000, flow_max=20, zero_init=False, lr=1e-4,
+                           weight_decay=0.0, clip=100.0)).to(dev)
+    fd.log_dict = lambda *a, **k: None
+    if world > 1:
+        parallel.broadcast_parameters(fd)
+        parallel.attach_grad_sync(fd)
+    opt = fd.configure_optimizers()
+    g = torch.Generator(device=dev).manual_seed(parallel.rank_seed(7, rank))
+    img = torch.rand(B, 3, H, W, device=dev, generator=g)
+    flow = torch.nn.functional.avg_pool2d(torch.clamp(torch.randn(B, 2, H, W, device=dev, generator=g) * 8, -20, 20), 9, 1, 4)
+
+    def step(i):
+        loss = fd.training_step((img, img, flow), i)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(args.train_warmup):
+        step(i)
+    parallel.barrier(dev)
+    t0 = time.perf_counter()
+    for i in range(args.train_steps):
+        loss = step(i)
+    parallel.barrier(dev)
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    sps = args.train_steps / dt
+    return {"metric": "flow_diffuser train steps/sec (fwd + bwd + Adam)", "value": sps, "unit": "train_steps/s", "ms_per_step": 1e3 / sps,
+            "samples_per_s": sps * B * world, "batch_per_gpu": B, "global_batch": B * world, "steps": args.train_steps,
+            "warmup": args.train_warmup, "scaling": "weak", "grad_sync": "bucketed RCCL all-reduce, 32 MiB" if world > 1 else "none",
+            "mfma_frac_of_peak": sps * B * TRAIN_TFLOP_PER_SAMPLE * (H * W) / (440 * 1024) / PEAK_BF16_TFLOPS,
+            "loss": float(loss.detach()), "max_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +103,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel HIP events in the timed region")
     ap.add_argument("--dump-launches", default=None, help="CSV path: one row per kernel launch of the timed region")
+    ap.add_argument("--train-steps", type=int, default=3, help="timed training steps of the extra `train` object (0: skip)")
+    ap.add_argument("--train-warmup", type=int, default=1)
+    ap.add_argument("--with-train", action="store_true", help="run the training leg for N > 1 too (default: N = 1 only)")
     args = ap.parse_args()
 
     from opticalflowdiffusion_amd import parallel
@@ -113,6 +160,18 @@ def main():
 
     elapsed = parallel.max_over_ranks(elapsed, dev)
 
+    train = None
+    if args.train_steps > 0 and (world == 1 or args.with_train):
+        del img, noises
+        unet._ws = None                      # hand the inference workspace back before the training one is sized
+        torch.cuda.empty_cache()
+        try:
+            train = train_leg(args, dev, rank, world, H, W)
+        except Exception as e:               # the headline metric must survive a failure of the extra leg
+            if world > 1:
+                raise
+            train = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         steps_per_s = parallel.whole_job_rate(args.steps, world, elapsed)
         line = {
@@ -143,6 +202,8 @@ def main():
             c3 = [prof[n] for n in ("conv_igemm_kernel<3,128>", "conv_igemm_kernel<3,64>", "conv3x3_c64_pingpong_kernel")]
             line["conv3x3_all_tflops"] = sum(v["flops"] for v in c3) / (sum(v["ms"] for v in c3) * 1e-3) / 1e12
             line["kernel_ms_per_step"] = {n: v["ms"] / args.steps for n, v in prof.items()}
+        if train is not None:
+            line["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(H, W, B)
         print(json.dumps(line), flush=True)

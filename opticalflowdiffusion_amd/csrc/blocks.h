@@ -14,8 +14,8 @@ struct MlpDesc {            // one ResnetBlock's time-embedding Linear (DD:193-1
 int conv_forward_impl(const ofd_conv_args* a, hipStream_t s);
 // conv backward (conv_bwd.hip)
 int k_wt_transpose(const bf16_t* w, bf16_t* wt, int taps, int Cin, int Cout, hipStream_t s);
-int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_t s);
-int k_conv7_wgrad(const bf16_t* x16, const bf16_t* dy, float* dw, int B, int H, int W, hipStream_t s);
+int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_t s, float* dbias = nullptr);
+int k_conv7_wgrad(const bf16_t* x16, const bf16_t* dy, float* dw, int B, int H, int W, hipStream_t s, float* dbias = nullptr);
 int k_channel_sum(const bf16_t* dy, float* out, size_t npix, int C, hipStream_t s);
 int k_wgrad_finish(const float* acc, const float* w_raw, float* dst, int Cout, int Cin, int Cin_pad, int ksize, float ws_eps, int unshuffle,
                    int accumulate, hipStream_t s);
@@ -48,7 +48,7 @@ int k_gn_silu_backward(const bf16_t* g, const bf16_t* h, const float* a, const f
                        const float* beta, const float* ss, int ss_stride, int ss_offset, bf16_t* dh, float* dgamma, float* dbeta, float* dss,
                        float* workspace, int B, int H, int W, int C, hipStream_t st, float* dconv_bias = nullptr);
 int k_layernorm_c_bwd(const bf16_t* x, const float* gw, const bf16_t* dy, bf16_t* dx, float* dg, size_t npix, int C, float eps, int accumulate,
-                      hipStream_t st);
+                      hipStream_t st, const bf16_t* extra = nullptr);
 int k_final_conv_bwd(const bf16_t* x, const float* w, const float* dy, bf16_t* dx, float* dw, float* db, int B, int H, int W, int C, int out_dim,
                      hipStream_t st);
 int k_block_mlp_bwd(const float* dss, const float* temb_silu, const float* weight, int n_out, int offset, float* dweight, float* dbias, float* dts,

@@ -36,7 +36,17 @@ struct WgradParams {
     ConvSrcDev src[4];
     const bf16_t* dy;
     float* dw;           // [taps][Cin_total][Cout] fp32, accumulated with atomics (zeroed by the caller)
+    float* dbias;        // optional [Cout]: += column sums of dY (workgroups of the first ci block add them)
 };
+
+// column sums of a staged dY tile [256 pixels][64 co] (128-byte rows): thread -> (co, quarter of the pixels)
+__device__ __forceinline__ float ytile_colsum(const unsigned char* ys, int tid) {
+    const int co = tid & 63, part = tid >> 6;
+    float s = 0.0f;
+#pragma unroll 8
+    for (int p = part * 64; p < part * 64 + 64; ++p) s += bf2f(*(const bf16_t*)(ys + p * 128 + co * 2));
+    return s;
+}
 
 // grid: (pixel-tile groups, KS kernel rows, (Cin/64)*(Cout/64)); workgroup = 4 waves, wave -> 32 ci x 32 co
 template <int KS>
@@ -61,6 +71,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams P) {
     for (int k = 0; k < KS; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+    const bool do_bias = P.dbias && kc == 0 && ky == 0;
+    float bsum = 0.0f;
 
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int b = t / tpi, t_in = t - b * tpi;
@@ -109,6 +121,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams P) {
             *(u32x4*)(ys + p * 128 + c8 * 16) = v;
         }
         __syncthreads();
+        if (do_bias) bsum += ytile_colsum(ys, tid);
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
@@ -121,6 +134,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams P) {
                 }
             }
     }
+    if (do_bias) atomicAdd(P.dbias + cob * 64 + (tid & 63), bsum);
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) {
         const int tap = ky * KS + kx;
@@ -154,6 +168,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
     const ConvSrcDev S = P.src[si];
     const int c8 = tid & 7;
 
+    const bool do_bias = P.dbias && kc == 0;
+    float bsum = 0.0f;
     f32x16 acc[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -212,6 +228,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
             *(u32x4*)(ys + p * 128 + c8 * 16) = v;
         }
         __syncthreads();
+        if (do_bias) bsum += ytile_colsum(ys, tid);
         bf16x8 yw[3][2];     // dY fragments of output rows rr, rr-1, rr-2
 #pragma unroll
         for (int rr = 0; rr < XROWS; ++rr) {
@@ -233,6 +250,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
                 }
         }
     }
+    if (do_bias) atomicAdd(P.dbias + cob * 64 + (tid & 63), bsum);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -252,13 +270,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
 // operand carries the taps (ky, kx) and (ky, kx+1).  8 waves: wave -> (n-tile of 32 co, two ky rows),
 // 8 accumulator tiles each; workgroups walk many 8x32 pixel tiles and add their sums once.
 __global__ void __launch_bounds__(512) conv7_wgrad_kernel(const bf16_t* __restrict__ x16, const bf16_t* __restrict__ dy, float* __restrict__ dw,
-                                                          int B, int H, int W, int tiles_x, int tiles_y) {
+                                                          int B, int H, int W, int tiles_x, int tiles_y, float* __restrict__ dbias) {
     constexpr int XW = 40, XPIX = 14 * XW;                // 38 columns needed (+1 for the phantom tap kx = 7)
     __shared__ __attribute__((aligned(16))) unsigned char xs[XPIX * 32];
     __shared__ __attribute__((aligned(16))) unsigned char ys[256 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int nt = wave & 1, kg = wave >> 1;               // ky rows of this wave: kg and kg + 4 (kg + 4 < 7)
     const int tpi = tiles_x * tiles_y, ntiles = tpi * B;
+    float bsum = 0.0f;
     f32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -290,6 +309,10 @@ __global__ void __launch_bounds__(512) conv7_wgrad_kernel(const bf16_t* __restri
             *(u32x4*)(ys + p * 128 + c8 * 16) = v;
         }
         __syncthreads();
+        if (dbias) {
+            const int co = tid & 63, part = tid >> 6;
+            for (int p = part * 32; p < part * 32 + 32; ++p) bsum += bf2f(*(const bf16_t*)(ys + p * 128 + co * 2));
+        }
 #pragma unroll 2
         for (int r = 0; r < 8; ++r)
 #pragma unroll
@@ -308,6 +331,7 @@ __global__ void __launch_bounds__(512) conv7_wgrad_kernel(const bf16_t* __restri
                 }
             }
     }
+    if (dbias) atomicAdd(dbias + (tid & 63), bsum);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int ky = kg + 4 * a;
@@ -461,7 +485,7 @@ int k_wt_transpose(const bf16_t* w, bf16_t* wt, int taps, int Cin, int Cout, hip
 }
 
 // dw (fp32 [taps][Cin_total][Cout]) must be zeroed by the caller; x sources as in the forward conv
-int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_t s) {
+int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_t s, float* dbias) {
     OFD_CHECK_ARG(a && dy && dw, "conv_wgrad: null argument");
     OFD_CHECK_ARG(a->ksize == 1 || a->ksize == 3, "conv_wgrad: ksize %d (7x7 has its own kernel)", a->ksize);
     OFD_CHECK_ARG(a->Cout % 64 == 0 && a->n_src >= 1 && a->n_src <= 4, "conv_wgrad: bad configuration");
@@ -480,7 +504,7 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
         d.p1 = s_.p1; d.p2 = s_.p2;
         cin += s_.channels;
     }
-    P.Cin_total = cin; P.dy = dy; P.dw = dw;
+    P.Cin_total = cin; P.dy = dy; P.dw = dw; P.dbias = dbias;
     const int ntiles = P.tiles_x * P.tiles_y * P.B, combos = (cin / 64) * (a->Cout / 64);
     int gx = cdiv(1024, combos * a->ksize);     // ~4 workgroups per CU in total; each walks ntiles / gx pixel tiles
     if (gx < 1) gx = 1;
@@ -504,11 +528,11 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
     return OFD_OK;
 }
 
-int k_conv7_wgrad(const bf16_t* x16, const bf16_t* dy, float* dw, int B, int H, int W, hipStream_t s) {
+int k_conv7_wgrad(const bf16_t* x16, const bf16_t* dy, float* dw, int B, int H, int W, hipStream_t s, float* dbias) {
     const int tx = cdiv(W, 32), ty = cdiv(H, 8);
     int grid = tx * ty * B;
     if (grid > 768) grid = 768;
-    conv7_wgrad_kernel<<<grid, 512, 0, s>>>(x16, dy, dw, B, H, W, tx, ty);
+    conv7_wgrad_kernel<<<grid, 512, 0, s>>>(x16, dy, dw, B, H, W, tx, ty, dbias);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -549,11 +573,11 @@ extern "C" int ofd_conv_dgrad_weight_prep(const void* w_fwd, void* w_t, int Cout
     return k_wt_transpose((const bf16_t*)w_fwd, (bf16_t*)w_t, ksize * ksize, Cin, Cout, (hipStream_t)stream);
 }
 extern "C" int ofd_conv_wgrad(const ofd_conv_args* fwd, const void* dy, float* dw_acc, void* stream) {
-    return k_conv_wgrad(fwd, (const bf16_t*)dy, dw_acc, (hipStream_t)stream);
+    return k_conv_wgrad(fwd, (const bf16_t*)dy, dw_acc, (hipStream_t)stream, nullptr);
 }
 extern "C" int ofd_conv7_wgrad(const void* x16, const void* dy, float* dw_acc, int B, int H, int W, void* stream) {
     OFD_CHECK_ARG(x16 && dy && dw_acc, "conv7_wgrad: null argument");
-    return k_conv7_wgrad((const bf16_t*)x16, (const bf16_t*)dy, dw_acc, B, H, W, (hipStream_t)stream);
+    return k_conv7_wgrad((const bf16_t*)x16, (const bf16_t*)dy, dw_acc, B, H, W, (hipStream_t)stream, nullptr);
 }
 extern "C" int ofd_conv_wgrad_finish(const float* dw_acc, const float* w_oihw, float* dst_oihw, int Cout, int Cin, int Cin_pad, int ksize,
                                      float ws_eps, int unshuffle, int accumulate, void* stream) {

@@ -172,7 +172,8 @@ __global__ void __launch_bounds__(256) gnbwd_apply_kernel(const bf16_t* __restri
 // ---- LayerNorm over channels backward (DD:116-125): y = x^ * g (+ residual); lpp lanes per pixel ----
 // dx = r (t - mean(t) - x^ mean(t x^)), t = dy*g ; dg[c] += sum_pixels dy * x^   (per-workgroup partial -> atomics)
 __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gw, const bf16_t* __restrict__ dy,
-                                                              bf16_t* __restrict__ dx, float* __restrict__ dg, int C, float eps, size_t npix, int accumulate) {
+                                                              bf16_t* __restrict__ dx, float* __restrict__ dg, int C, float eps, size_t npix, int accumulate,
+                                                              const bf16_t* __restrict__ extra) {
     extern __shared__ float dg_s[];       // [C]
     for (int i = threadIdx.x; i < C; i += 256) dg_s[i] = 0.0f;
     __syncthreads();
@@ -210,10 +211,11 @@ __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const bf16_t* __re
         m1 *= inv_c;
         m2 *= inv_c;
         if (ok) {
-            float r8[8];
+            float r8[8], e8[8];
             if (accumulate) t_unpack8(*(const uint4*)(dx + p * C + sub * 8), r8);
+            if (extra) t_unpack8(*(const uint4*)(extra + p * C + sub * 8), e8);      // e.g. the residual branch's gradient
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[j] = rstd * (d[j] - m1 - v[j] * m2) + (accumulate ? r8[j] : 0.0f);
+            for (int j = 0; j < 8; ++j) d[j] = rstd * (d[j] - m1 - v[j] * m2) + (accumulate ? r8[j] : 0.0f) + (extra ? e8[j] : 0.0f);
             *(uint4*)(dx + p * C + sub * 8) = t_pack8(d);
         }
     }
@@ -421,10 +423,10 @@ int k_gn_silu_backward(const bf16_t* g, const bf16_t* h, const float* a, const f
 }
 
 int k_layernorm_c_bwd(const bf16_t* x, const float* gw, const bf16_t* dy, bf16_t* dx, float* dg, size_t npix, int C, float eps, int accumulate,
-                      hipStream_t st) {
+                      hipStream_t st, const bf16_t* extra) {
     OFD_CHECK_ARG(C == 64 || C == 128 || C == 256 || C == 512, "layernorm_c_bwd: C=%d", C);
     const size_t waves = (npix + (512 / C) - 1) / (512 / C);
-    layernorm_c_bwd_kernel<<<tgrid(waves * 64, 1024), 256, C * sizeof(float), st>>>(x, gw, dy, dx, dg, C, eps, npix, accumulate);
+    layernorm_c_bwd_kernel<<<tgrid(waves * 64, 1024), 256, C * sizeof(float), st>>>(x, gw, dy, dx, dg, C, eps, npix, accumulate, extra);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -480,7 +482,7 @@ extern "C" int ofd_affine_silu(const void* h, const float* a, const float* s, vo
 extern "C" int ofd_layernorm_c_backward(const void* x, const float* g, const void* dy, void* dx, float* dg, size_t npix, int C, float eps,
                                         int accumulate, void* stream) {
     OFD_CHECK_ARG(x && g && dy && dx && dg, "layernorm_c_backward: null argument");
-    return k_layernorm_c_bwd((const bf16_t*)x, g, (const bf16_t*)dy, (bf16_t*)dx, dg, npix, C, eps, accumulate, (hipStream_t)stream);
+    return k_layernorm_c_bwd((const bf16_t*)x, g, (const bf16_t*)dy, (bf16_t*)dx, dg, npix, C, eps, accumulate, (hipStream_t)stream, nullptr);
 }
 extern "C" int ofd_final_conv_backward(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db, int B, int H, int W, int C,
                                        int out_dim, void* stream) {

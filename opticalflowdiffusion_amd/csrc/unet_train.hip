@@ -57,23 +57,20 @@ static Tensor conv_backward(Bwd& b, const std::string& prefix, const std::vector
     int cin = 0;
     for (auto& s : srcs) cin += s.t.C;
     const double px = (double)B * H * W;
-    float* gb = bias_done ? nullptr : u->G(prefix + ".bias");     // (block convs: the GroupNorm backward already summed dh)
-    if (gb) {
-        c.begin(PC_MISC, 0, px * d.Cout * 2, prefix + " dbias");
-        RUN(k_channel_sum(dy, gb, (size_t)B * H * W, d.Cout, c.s));
-        c.end();
-    }
+    // bias gradient = column sums of dY: taken from the dY tiles the weight-gradient kernel stages anyway
+    // (block convs: the GroupNorm backward already summed dh)
+    float* gb = bias_done ? nullptr : u->G(prefix + ".bias");
     const size_t nacc = (size_t)taps * d.Cin_pad * d.Cout;
     float* acc = b.stmpf(nacc);
     if (c.rc != OFD_OK) return D;
     if (!c.dry && hipMemsetAsync(acc, 0, nacc * 4, c.s) != hipSuccess) { set_error("conv_backward: memset failed"); c.rc = OFD_ERR_HIP; return D; }
     c.begin(d.ksize == 3 ? PC_WGRAD3 : PC_WGRAD1, 2.0 * px * d.Cout * (double)d.Cin * taps, px * 2.0 * (d.Cout + cin), prefix + " wgrad");
     if (d.ksize == 7) {
-        RUN(k_conv7_wgrad(srcs[0].t.p, dy, acc, B, H, W, c.s));
+        RUN(k_conv7_wgrad(srcs[0].t.p, dy, acc, B, H, W, c.s, gb));
     } else {
         ofd_conv_args a{};
         fill_args(a, B, H, W, d.ksize, d.Cout, srcs);
-        RUN(k_conv_wgrad(&a, dy, acc, c.s));
+        RUN(k_conv_wgrad(&a, dy, acc, c.s, gb));
     }
     RUN(k_wgrad_finish(acc, u->P(d.wname), u->G(d.wname), d.Cout, d.Cin, d.Cin_pad, d.ksize, d.ws_eps, d.unshuffle, 0, c.s));
     c.end();
@@ -177,9 +174,8 @@ static void attn_tail_backward(Bwd& b, const TapeRec& r, const std::string& qkv_
     Tensor Dx = conv_backward(b, qkv_prefix, {sx}, r.qkv.g, H, W, true, nullptr);
     if (c.rc != OFD_OK) return;
     c.begin(PC_LN, 0, (double)npix * C * 10, r.name + " prenorm bwd");
-    RUN(k_grad_add(r.x.g, dy, npix * C, b.has(r.x) ? 1 : 0, c.s));
+    RUN(k_layernorm_c_bwd(r.x.p, u->P(norm_g), Dx.p, r.x.g, u->G(norm_g), npix, C, site_eps(u, r.name + ".fn.norm"), b.has(r.x) ? 1 : 0, c.s, dy));
     b.mark(r.x);
-    RUN(k_layernorm_c_bwd(r.x.p, u->P(norm_g), Dx.p, r.x.g, u->G(norm_g), npix, C, site_eps(u, r.name + ".fn.norm"), 1, c.s));
     c.end();
 }
 
