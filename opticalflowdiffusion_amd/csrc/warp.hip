@@ -4,9 +4,17 @@
 //
 // Forward splat design (instead of the reference's one global atomicAdd per corner):
 //   * an output tile of 64x64 pixels x 4 channels is owned by one workgroup and accumulated in
-//     LDS (ds_add_f32); the workgroup scans the source window = tile footprint +- radius, so
-//     flow is read once per pixel (not once per channel) and the output is written once,
-//     coalesced, with no zero-fill pass and no global atomics;
+//     LDS; the workgroup scans the source window = tile footprint +- radius, so flow is read
+//     once per pixel (not once per channel) and the output is written once, coalesced, with no
+//     zero-fill pass and no global atomics;
+//   * the LDS accumulators are 64-bit FIXED POINT, not float: ds_add_f32 retires 0.37 lane-atomics
+//     per clock and CU on gfx950 whatever the access pattern, ds_add_u64 5-10 (tools/probe/
+//     lds_atomic_probe.hip).  Every product in*w is computed in fp32 exactly as the reference does,
+//     scaled by 2^(44 - E_c) (E_c = exponent of the largest finite |in| of channel c in the window,
+//     found by a first pass over the window) and added as an integer: the sum is exact and
+//     order-independent (bit-reproducible, unlike float atomics), one rounding back to fp32 at the
+//     end, resolution 2^-44 of the channel maximum.  Non-finite products set NaN / +inf / -inf flag
+//     bits per output pixel and follow IEEE addition rules at write-out;
 //   * samples whose corner lands in a tile whose window does not contain them ("far" corners,
 //     |displacement| > radius) are appended to a list by the workgroup that owns the SOURCE
 //     pixel and added with global atomics by a second, normally empty, kernel.
@@ -20,7 +28,7 @@ struct SplatGeom {
     int B, C, H, W, Ho, Wo, scale, ox, oy, radius, ntx, nty, dbg;
 };
 
-constexpr int S_TH = 64, S_TW = 64, S_CG = 4, S_NT = 512;
+constexpr int S_TH = 64, S_TW = 64, S_CG = 4, S_NT = 1024;
 constexpr int SKIPPED = -(1 << 30);
 
 // variant 0: forward (SS:374-390), 1: ingrad (SS:515-533), 2: flowgrad (SS:628-647).
@@ -84,17 +92,52 @@ __device__ __forceinline__ void footprint(int t, int nt, int tile, int scale, in
     hi = (t == nt - 1) ? full : (t + 1) * tile * scale;
 }
 
+// largest finite |in| of every (sample, channel) plane, as float bits (non-negative floats order like unsigned ints)
+__global__ void __launch_bounds__(256) splat_absmax_kernel(const float* __restrict__ in, unsigned int* __restrict__ absmax, size_t plane) {
+    const float* p = in + (size_t)blockIdx.y * plane;
+    float m = 0.0f;
+    const size_t n4 = plane / 4;
+#pragma unroll 4
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = ((const float4*)p)[i];
+        const float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
+        if (a0 < 3.0e38f) m = fmaxf(m, a0);
+        if (a1 < 3.0e38f) m = fmaxf(m, a1);
+        if (a2 < 3.0e38f) m = fmaxf(m, a2);
+        if (a3 < 3.0e38f) m = fmaxf(m, a3);
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < plane; i += (size_t)gridDim.x * 256) {
+        const float a = fabsf(p[i]);
+        if (a < 3.0e38f) m = fmaxf(m, a);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {       // one atomic per workgroup: same-address atomics serialise in L2
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (m > 0.0f) atomicMax(absmax + blockIdx.y, __float_as_uint(m));
+    }
+}
+
+constexpr int S_FIX = 44;                                  // fixed-point fraction bits relative to the channel maximum
+constexpr int S_LDS_BYTES = S_CG * S_TH * S_TW * 8 + S_TH * S_TW * 4;
+
 __global__ void __launch_bounds__(S_NT) splat_tile_kernel(const float* __restrict__ in, const float* __restrict__ flow,
                                                           float* __restrict__ out, unsigned long long* __restrict__ far_list,
                                                           unsigned int* __restrict__ far_count, unsigned int far_cap,
-                                                          SplatGeom g, int c0, int cg) {
-    __shared__ float acc[S_CG][S_TH][S_TW];
+                                                          const unsigned int* __restrict__ absmax, SplatGeom g, int c0, int cg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_lds[];
+    unsigned long long(*acc)[S_TH][S_TW] = (unsigned long long(*)[S_TH][S_TW])s_lds;          // [S_CG][S_TH][S_TW]
+    unsigned int(*flags)[S_TW] = (unsigned int(*)[S_TW])(s_lds + S_CG * S_TH * S_TW * 8);     // 3 bits per channel: nan, +inf, -inf
+    __shared__ float k_s[S_CG];
+    __shared__ double kinv_s[S_CG];
     const int tid = threadIdx.x;
     const int tx = blockIdx.x, ty = blockIdx.y, n = blockIdx.z;
     const int X0 = tx * S_TW, Y0 = ty * S_TH;
 
-    for (int i = tid; i < S_CG * S_TH * S_TW; i += S_NT) (&acc[0][0][0])[i] = 0.0f;
-    __syncthreads();
+    for (int i = tid; i < S_CG * S_TH * S_TW; i += S_NT) (&acc[0][0][0])[i] = 0ull;
+    for (int i = tid; i < S_TH * S_TW; i += S_NT) (&flags[0][0])[i] = 0u;
 
     int fx0, fx1, fy0, fy1;
     footprint(tx, g.ntx, S_TW, g.scale, g.W, fx0, fx1);
@@ -106,55 +149,102 @@ __global__ void __launch_bounds__(S_NT) splat_tile_kernel(const float* __restric
     const float* flow_n = flow + (size_t)n * 2 * plane;
     const float* in_n = in + ((size_t)n * g.C + c0) * plane;
 
-    for (int p = tid; p < ww * wh; p += S_NT) {
-        const int y = wy0 + p / ww, x = wx0 + p % ww;
-        const size_t pix = (size_t)y * g.W + x;
-        float fx, fy, d0, d1;
-        if (!splat_remap<0>(flow_n[pix], flow_n[plane + pix], x, y, g, fx, fy, d0, d1)) continue;
-        const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
-        const bool own = (x >= fx0) && (x < fx1) && (y >= fy0) && (y < fy1);
-        const int lx0 = x0 - X0, ly0 = y0 - Y0;
-        const bool touches = (lx0 >= -1) && (lx0 < S_TW) && (ly0 >= -1) && (ly0 < S_TH);
-        if (!touches && !own) continue;
-        float w[4];
-        corner_weights(fx, fy, x0, y0, w);
-        if (touches) {
-            float v[S_CG];
+    if (tid < S_CG) {   // fixed-point scale 2^(S_FIX - E_c) from the largest finite |in| of this (sample, channel) plane
+        const float v = (tid < cg) ? __uint_as_float(absmax[(size_t)n * g.C + c0 + tid]) : 0.0f;
+        int e = 0;
+        if (v > 0.0f) frexpf(v, &e);                                  // v < 2^e
+        int sh = S_FIX - e;
+        sh = min(max(sh, -100), 126);
+        k_s[tid] = ldexpf(1.0f, sh);
+        kinv_s[tid] = ldexp(1.0, -sh);
+    }
+    __syncthreads();
+    double kd[S_CG];
 #pragma unroll
-            for (int c = 0; c < S_CG; ++c) v[c] = (c < cg) ? in_n[(size_t)c * plane + pix] : 0.0f;
+    for (int c = 0; c < S_CG; ++c) kd[c] = (double)k_s[c];
+
+    // the scan is latency-bound if one pixel is walked at a time (flow -> remap -> image loads -> atomics):
+    // S_U pixels per thread are in flight together, all loads issued before the first use
+    // thread -> window column tid % 128 (the window is at most 64 + 2*radius <= 128 wide when radius <= 32,
+    // wider windows loop over column blocks), rows tid / 128 + 8 i: no integer divisions in the scan
+    constexpr int S_U = 4, S_COLS = 128, S_ROWS = S_NT / S_COLS;
+    for (int xb = 0; xb < ww; xb += S_COLS)
+    for (int r0 = tid / S_COLS; r0 < wh; r0 += S_ROWS * S_U) {
+        int xs[S_U], ys[S_U];
+        size_t pixs[S_U];
+        float f0[S_U], f1[S_U], v[S_U][S_CG];
+        bool live[S_U];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int lx = lx0 + (k & 1), ly = ly0 + (k >> 1);
-                const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
-                if (lx >= 0 && lx < S_TW && ly >= 0 && ly < S_TH && cx < g.Wo && cy < g.Ho) {
+        for (int u = 0; u < S_U; ++u) {
+            const int r = r0 + u * S_ROWS, col = xb + (tid % S_COLS);
+            live[u] = r < wh && col < ww;
+            ys[u] = wy0 + min(r, wh - 1);
+            xs[u] = wx0 + min(col, ww - 1);
+            pixs[u] = (size_t)ys[u] * g.W + xs[u];
+            f0[u] = flow_n[pixs[u]];
+            f1[u] = flow_n[plane + pixs[u]];
 #pragma unroll
-                    for (int c = 0; c < S_CG; ++c)
-                        if (c < cg) {
-                            // LDS float atomics are the bottleneck (~0.55 lane-atomics/clk/CU measured): skip
-                            // products that are exactly zero (x + 0 == x; NaN/inf inputs are never zero)
-                            const float val = v[c] * w[k];
-                            if (val != 0.0f) atomicAdd(&acc[c][ly][lx], val);
-                        }
+            for (int c = 0; c < S_CG; ++c) v[u][c] = (c < cg) ? in_n[(size_t)c * plane + pixs[u]] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < S_U; ++u) {
+            const int x = xs[u], y = ys[u];
+            const size_t pix = pixs[u];
+            float fx, fy, d0, d1;
+            if (!live[u] || !splat_remap<0>(f0[u], f1[u], x, y, g, fx, fy, d0, d1)) continue;
+            const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
+            const bool own = (x >= fx0) && (x < fx1) && (y >= fy0) && (y < fy1);
+            const int lx0 = x0 - X0, ly0 = y0 - Y0;
+            const bool touches = (lx0 >= -1) && (lx0 < S_TW) && (ly0 >= -1) && (ly0 < S_TH);
+            if (!touches && !own) continue;
+            float w[4];
+            corner_weights(fx, fy, x0, y0, w);
+            if (touches) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int lx = lx0 + (k & 1), ly = ly0 + (k >> 1);
+                    const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+                    if (lx >= 0 && lx < S_TW && ly >= 0 && ly < S_TH && cx < g.Wo && cy < g.Ho) {
+#pragma unroll
+                        for (int c = 0; c < S_CG; ++c)
+                            if (c < cg) {
+                                const float val = v[u][c] * w[k];            // the reference's fp32 product (SS:406-418)
+                                if (fabsf(val) < 3.0e38f) {
+                                    if (val != 0.0f) {
+                                        // round(val * 2^sh) as a 64-bit integer without a float->int64 conversion (a ~20
+                                        // instruction expansion on gfx950): the 1.5*2^52 trick, exact for |x| < 2^51
+                                        const double d = __builtin_fma((double)val, kd[c], 6755399441055744.0);
+                                        atomicAdd(&acc[c][ly][lx], (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll));
+                                    }
+                                } else {
+                                    const unsigned bit = (val != val) ? 1u : (val > 0.0f ? 2u : 4u);
+                                    atomicOr(&flags[ly][lx], bit << (3 * c));
+                                }
+                            }
+                    }
                 }
             }
-        }
-        if (own && c0 == 0) {
-            // far corners: in-bounds corners whose owner tile does not scan this source pixel
-            unsigned mask = 0;
+            // far corners: in-bounds corners whose owner tile does not scan this source pixel.  A target within
+            // `radius` (in source pixels) of its source cannot have one: skip the per-corner analysis then.
+            const bool maybe_far = fabsf(fx * (float)g.scale - (float)x) >= (float)(g.radius - g.scale - 1) ||
+                                   fabsf(fy * (float)g.scale - (float)y) >= (float)(g.radius - g.scale - 1) || !(fx == fx) || !(fy == fy);
+            if (own && c0 == 0 && maybe_far) {
+                unsigned mask = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
-                if (cx < 0 || cx >= g.Wo || cy < 0 || cy >= g.Ho) continue;
-                int lo, hi;
-                footprint(cx / S_TW, g.ntx, S_TW, g.scale, g.W, lo, hi);
-                bool near = (x >= lo - g.radius) && (x < hi + g.radius);
-                footprint(cy / S_TH, g.nty, S_TH, g.scale, g.H, lo, hi);
-                near = near && (y >= lo - g.radius) && (y < hi + g.radius);
-                if (!near) mask |= 1u << k;
-            }
-            if (mask) {
-                const unsigned slot = atomicAdd(far_count, 1u);
-                if (slot < far_cap) far_list[slot] = ((unsigned long long)((size_t)n * plane + pix) << 4) | mask;
+                for (int k = 0; k < 4; ++k) {
+                    const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+                    if (cx < 0 || cx >= g.Wo || cy < 0 || cy >= g.Ho) continue;
+                    int lo, hi;
+                    footprint(cx / S_TW, g.ntx, S_TW, g.scale, g.W, lo, hi);
+                    bool near = (x >= lo - g.radius) && (x < hi + g.radius);
+                    footprint(cy / S_TH, g.nty, S_TH, g.scale, g.H, lo, hi);
+                    near = near && (y >= lo - g.radius) && (y < hi + g.radius);
+                    if (!near) mask |= 1u << k;
+                }
+                if (mask) {
+                    const unsigned slot = atomicAdd(far_count, 1u);
+                    if (slot < far_cap) far_list[slot] = ((unsigned long long)((size_t)n * plane + pix) << 4) | mask;
+                }
             }
         }
     }
@@ -165,7 +255,15 @@ __global__ void __launch_bounds__(S_NT) splat_tile_kernel(const float* __restric
     for (int i = tid; i < cg * S_TH * S_TW; i += S_NT) {
         const int c = i / (S_TH * S_TW), r = (i / S_TW) % S_TH, col = i % S_TW;
         const int oy_ = Y0 + r, ox_ = X0 + col;
-        if (oy_ < g.Ho && ox_ < g.Wo) out_n[(size_t)c * oplane + (size_t)oy_ * g.Wo + ox_] = acc[c][r][col];
+        if (oy_ < g.Ho && ox_ < g.Wo) {
+            float v = (float)((double)(long long)acc[c][r][col] * kinv_s[c]);
+            const unsigned f = (flags[r][col] >> (3 * c)) & 7u;
+            if (f) {       // IEEE: NaN dominates, inf - inf = NaN, otherwise the infinity
+                const float inf = __builtin_huge_valf();
+                v = ((f & 1u) || (f & 6u) == 6u) ? __builtin_nanf("") : ((f & 2u) ? inf : -inf);
+            }
+            out_n[(size_t)c * oplane + (size_t)oy_ * g.Wo + ox_] = v;
+        }
     }
 }
 
@@ -615,8 +713,10 @@ static inline int stream_grid(size_t total, int block) {
 
 using namespace ofd;
 
+constexpr int S_MAXC = 256;     // channels the per-plane maxima area of the workspace is sized for
 extern "C" size_t ofd_splat_workspace_bytes(int B, int H, int W) {
-    return 16 + sizeof(unsigned long long) * (size_t)B * H * W;
+    // far-corner counter | per-(sample, channel) |in| maxima | far-corner list
+    return 16 + (size_t)B * S_MAXC * 4 + sizeof(unsigned long long) * (size_t)B * H * W;
 }
 
 extern "C" int ofd_splat_fwd(const float* in, const float* flow, float* out, int B, int C, int H, int W, int scale,
@@ -630,14 +730,24 @@ extern "C" int ofd_splat_fwd(const float* in, const float* flow, float* out, int
         set_error("splat_fwd: workspace %zu < %zu", workspace_bytes, ofd_splat_workspace_bytes(B, H, W));
         return OFD_ERR_WORKSPACE;
     }
+    OFD_CHECK_ARG(C <= S_MAXC, "splat_fwd: C=%d > %d", C, S_MAXC);
     hipStream_t s = (hipStream_t)stream;
     unsigned int* count = (unsigned int*)workspace;
-    unsigned long long* list = (unsigned long long*)((char*)workspace + 16);
+    unsigned int* absmax = (unsigned int*)((char*)workspace + 16);
+    unsigned long long* list = (unsigned long long*)((char*)workspace + 16 + (size_t)B * S_MAXC * 4);
     const unsigned cap = (unsigned)((size_t)B * H * W);
-    OFD_HIP(hipMemsetAsync(count, 0, 16, s));
+    OFD_HIP(hipMemsetAsync(count, 0, 16 + (size_t)B * C * 4, s));
+    {
+        const size_t plane = (size_t)H * W;
+        int gx = (int)((plane / 4 + 255) / 256);
+        gx = gx < 1 ? 1 : (gx > 24 ? 24 : gx);
+        splat_absmax_kernel<<<dim3(gx, B * C), 256, 0, s>>>(in, absmax, plane);
+    }
+    static bool attr = false;
+    if (!attr) { OFD_HIP(hipFuncSetAttribute((const void*)splat_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES)); attr = true; }
     for (int c0 = 0; c0 < C; c0 += S_CG) {
         const int cg = (C - c0 < S_CG) ? (C - c0) : S_CG;
-        splat_tile_kernel<<<dim3(g.ntx, g.nty, B), S_NT, 0, s>>>(in, flow, out, list, count, cap, g, c0, cg);
+        splat_tile_kernel<<<dim3(g.ntx, g.nty, B), S_NT, S_LDS_BYTES, s>>>(in, flow, out, list, count, cap, absmax, g, c0, cg);
     }
     splat_far_kernel<<<256, 256, 0, s>>>(in, flow, out, list, count, cap, g);
     OFD_LAUNCH_CHECK();
