@@ -509,26 +509,46 @@ class ConditionalDiffusion(nn.Module):
     # -- training loss -----------------------------------------------------------------------
     def p_losses(self, x_start, t, noise=None, offset_noise_strength=None, external_cond=None, additional_tgt=None,
                  additional_weight=None, model_out_override=None):
-        """DD:823-891 for targets without the pyramid levels (target='flow'/'target' level 1)."""
+        """DD:823-891."""
         noise = default(noise, lambda: torch.randn_like(x_start))
         x = self.q_sample(x_start=x_start, t=t, noise=noise)
         if model_out_override is None:
-            model_out = self.model_with_condition(x, t, None, external_cond=external_cond, additional_tgt=additional_tgt)
+            model_out_full = self.model_with_condition(x, t, None, external_cond=external_cond, additional_tgt=additional_tgt)
+            model_out = model_out_full
             if additional_tgt is not None:
-                model_out = model_out[:, :-1 * additional_tgt.shape[1]]
+                model_out = model_out_full[:, :-1 * additional_tgt.shape[1]]
         else:
             model_out, _ = model_out_override
         target = x_start                                                               # pred_x0 (DD:876-877)
-        if target.shape[1] == 5 or additional_tgt is not None:
-            raise NotImplementedError("pyramid loss of target='joint'/'target' (DD:902-961) is a next-round row (SURVEY 8f next-4)")
+        if additional_tgt is not None:                                                 # target='target' (DD:884-885)
+            additional_out = model_out_full[:, -1 * additional_tgt.shape[1]:] if model_out_override is None else model_out_override[1]
+            return self._loss(model_out, target, t, additional_tgt, external_cond, additional_out, additional_weight)
+        if target.shape[1] == 5:                                                       # target='joint' (DD:886-887)
+            return self._loss(model_out[:, :3], target[:, :3], t, target[:, 3:], external_cond, model_out[:, 3:], 0.0)
         return self._loss(model_out[:, :3], target[:, :3], t)
 
     def _loss(self, image_out, target, t=None, flow_tgt=None, external_cond=None, flow_out=None, additional_weight=None):
-        """DD:893-983, level 1 only: nanmean of the NaN-masked squared error (no SNR weighting,
-        DD:975-980; anomaly mode and prints dropped)."""
-        if flow_tgt is not None:
-            raise NotImplementedError("pyramid levels need target='joint'")
-        return nan_mse(image_out, target, reduction="mean")
+        """DD:893-983.  Level 1: NaN-masked squared error of the (warped) image.  With a flow target the
+        reference adds pyramid levels 2, 4, 8, 16: the condition image splatted by the PREDICTED flow at
+        1/level resolution (`self.model._warp(cond, flow_out, scale=level)`) against the target image
+        splatted by zero flow at the same scale, weighted level^4; the loss is the `nanmean` of the
+        concatenation of all levels = sum_L L^4 S_L / sum_L N_L.  (The flow-MSE term, the SNR weighting,
+        anomaly mode and the prints are disabled / dropped as in the reference, DD:963-980.)  Every piece
+        is a HIP kernel with its own backward: splat (forward, d/dflow), NaN-masked reductions."""
+        from .warp import nan_sq_sum
+        if flow_tgt is None:
+            return nan_mse(image_out, target, reduction="mean")
+        levels = [1, 2, 4, 8, 16]                                                      # DD:896
+        s1, n1 = nan_sq_sum(image_out, target)
+        num, den = s1, n1
+        for level in levels[1:]:
+            image_out_ = self.model._warp(external_cond, flow_out, scale=level)       # DD:936
+            with torch.no_grad():
+                image_out_tgt = self.model._warp(target, torch.zeros_like(flow_out), scale=level)   # DD:941
+            s, n = nan_sq_sum(image_out_, image_out_tgt)
+            num = num + s * float(level ** 4)                                          # DD:956
+            den = den + n
+        return num / den.float()
 
     def forward(self, img, external_cond=None, *args, **kwargs):
         """DD:985-993."""

@@ -134,6 +134,38 @@ class _NanMseMean(torch.autograd.Function):
         return dp.view(ctx.shape), None
 
 
+class _NanSqSum(torch.autograd.Function):
+    """(sum, count) of the squared error over the entries where neither side is NaN; the sum is differentiable
+    w.r.t. the prediction.  Building block of the pyramid loss (DD:902-973), whose `nanmean` over the
+    concatenation of all levels is sum_L L^4 S_L / sum_L N_L."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        p, t = L.f32c(pred).reshape(-1), L.f32c(target).reshape(-1)
+        res = torch.empty(2, dtype=torch.float64, device=p.device)
+        L.check(L.lib().ofd_nan_mse_sum(L.ptr(p), L.ptr(t), p.numel(), L.ptr(res), L.stream()))
+        ctx.save_for_backward(p, t)
+        ctx.shape = pred.shape
+        ctx.mark_non_differentiable(res)
+        return res[0].float(), res
+
+    @staticmethod
+    def backward(ctx, gsum, _gres):
+        p, t = ctx.saved_tensors
+        g = L.f32c(gsum).reshape(1)
+        unit = torch.tensor([0.0, 1.0], dtype=torch.float64, device=p.device)     # count 1: the kernel divides by it
+        dp = torch.empty_like(p)
+        L.check(L.lib().ofd_nan_mse_grad(L.ptr(p), L.ptr(t), p.numel(), L.ptr(unit), L.ptr(g), L.ptr(dp), L.stream()))
+        return dp.view(ctx.shape), None
+
+
+def nan_sq_sum(pred, target):
+    """returns (sum of squared errors over non-NaN pairs [differentiable], count [fp64 0-dim])."""
+    L.require_gpu(pred, target)
+    s, res = _NanSqSum.apply(pred, target)
+    return s, res[1]
+
+
 def nan_mse(pred, target, reduction="mean"):
     """WP:260-271.  reduction='mean' runs the fused HIP reduction (differentiable w.r.t. pred);
     'none' returns the compacted squared errors (dynamic shape, as the reference)."""

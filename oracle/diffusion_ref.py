@@ -119,3 +119,18 @@ def p_losses_flow(S, model_fn, x0, cond, t, noise):
     x = q_sample(S, x0, t, noise)
     out = model_fn(x, cond, t)
     return torch.nanmean(nan_mse_none(out[:, :3], x0[:, :3]))
+
+
+def pyramid_loss(image_out, target, cond, flow_out, flow_max, dim=3, levels=(1, 2, 4, 8, 16)):
+    """DD:893-983 with a flow target (target='joint' / 'target'): level 1 is the NaN-masked squared error of
+    the warped image; level L > 1 compares `_warp(cond, flow_out, scale=L)` with `_warp(target, 0, scale=L)`
+    (FD:35-36: `_warp(image, flow, **kw) = warp(image[:, :dim], None, flow * flow_max, mode='forward', **kw)`),
+    weighted L^4 (DD:956); `nanmean` over the concatenation (DD:973).  Flow-MSE term and SNR weighting are
+    disabled in the reference (DD:963-980)."""
+    from . import warp_ref as WR
+    loss = nan_mse_none(image_out, target)
+    for level in levels[1:]:
+        io = WR.warp(cond[:, :dim], None, flow_out * flow_max, mode="forward", scale=level)
+        it = WR.warp(target[:, :dim], None, torch.zeros_like(flow_out) * flow_max, mode="forward", scale=level)
+        loss = torch.cat((loss, nan_mse_none(io, it) * level ** 4), dim=0)
+    return torch.nanmean(loss)

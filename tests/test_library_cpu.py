@@ -41,7 +41,7 @@ def test_argument_errors_without_gpu(libpath):
     """argument validation happens before any HIP call: usable (and tested) on a CPU-only host"""
     from opticalflowdiffusion_amd import _lib
     L = _lib.lib()
-    assert L.ofd_splat_workspace_bytes(2, 8, 8) == 16 + 8 * 2 * 8 * 8
+    assert L.ofd_splat_workspace_bytes(2, 8, 8) == 16 + 2 * 256 * 4 + 8 * 2 * 8 * 8
     rc = L.ofd_splat_fwd(None, None, None, 1, 1, 8, 8, 3, 0, 0, 4, None, 0, None)      # null pointers
     assert rc == -1 and b"null" in L.ofd_last_error()
     rc = L.ofd_splat_fwd(None, None, None, 1, 1, 8, 8, 16, 0, 0, 4, None, 0, None)     # H // scale == 0

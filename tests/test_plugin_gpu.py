@@ -202,3 +202,66 @@ def test_backward_reports_every_gradient_range_once():
     assert rec.ranges[-1][0] == offs["time_mlp.1.weight"]           # ... the time MLP (fed by every block) last
     with pytest.raises(Exception, match="older forward|tape"):
         nan_mse(out, torch.zeros_like(out)).backward()              # the tape is single-use
+
+
+def test_joint_pyramid_loss_value_and_gradient():
+    """DD:893-983 (the shipped config is target='joint', flow_diffuser.yaml:15): loss value against the oracle
+    pyramid (CPU C splat), and its gradient w.r.t. the predicted flow -- through the splat backward kernel at
+    five scales -- against central differences of the same loss."""
+    from opticalflowdiffusion_amd import FlowDiffuser
+    torch.manual_seed(0)
+    B, H, W = 2, 32, 64
+    fd = FlowDiffuser(dict(target="joint", image_size=[H, W], timesteps=8, flow_max=20, zero_init=False)).cuda()
+    cond = torch.rand(B, 3, H, W) * 2 - 1
+    smooth = lambda t: torch.nn.functional.avg_pool2d(t, 9, 1, 4)
+    flow_gt = smooth(torch.randn(B, 2, H, W) * 2).clamp(-1, 1)                 # normalised flow (x flow_max = px)
+    flow_out = (flow_gt + smooth(torch.randn(B, 2, H, W)) * 0.1)
+    target = WR.warp(cond, None, flow_gt * 20, mode="forward")                # x_start[:, :3] of preprocess (FD:160)
+    fo = flow_out.cuda().requires_grad_(True)
+    image_out = fd._model._warp(cond.cuda(), fo)                              # FD:50: what UnetWithWarp returns
+    loss = fd.model._loss(image_out, target.cuda(), None, flow_gt.cuda(), cond.cuda(), fo, 0.0)
+    ref = D.pyramid_loss(WR.warp(cond, None, flow_out * 20, mode="forward"), target, cond, flow_out, 20.0)
+    assert abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref)), (float(loss), float(ref))
+    loss.backward()
+    g = fo.grad.clone()
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    # the reference's backward IS its softsplat_flowgrad kernel (SS:600-700, not the exact derivative at scale > 1:
+    # DESIGN "frozen / crossed factors"), so the gradient is checked against the oracle's restatement of that kernel
+    # chained by hand: d loss / d splat-output on the valid pixels of every level -> flowgrad -> * flow_max
+    flow_px = flow_out * 20
+    ten_in = torch.cat((cond, torch.ones(B, 1, H, W)), 1)                       # linear_unn: [image * w, w], w = 1 (no NaNs in cond)
+    gouts, n_valid = [], 0
+    for level in (1, 2, 4, 8, 16):
+        ret = WR.splat_out(ten_in, flow_px, level)
+        img = torch.where(ret[:, -1:] > 0, ret[:, :-1], torch.full_like(ret[:, :-1], float("nan")))
+        tgt = target if level == 1 else WR.warp(target, None, torch.zeros_like(flow_px), mode="forward", scale=level)
+        ok = ~(torch.isnan(img) | torch.isnan(tgt))
+        n_valid += int(ok.sum())
+        gi = torch.where(ok, 2.0 * (torch.nan_to_num(img) - torch.nan_to_num(tgt)) * level ** 4, torch.zeros_like(img))
+        gouts.append((level, torch.cat((gi, torch.zeros_like(ret[:, -1:])), 1)))
+    want = sum(WR.splat_flowgrad(ten_in, flow_px, go / n_valid, scale=level) for level, go in gouts) * 20.0
+    assert rel_l2(g.cpu(), want) < 1e-3, rel_l2(g.cpu(), want)
+
+
+def test_joint_training_step_reaches_every_parameter():
+    """FD:218-235 with the shipped target='joint': UnetWithWarp (NaN-safe 9-channel UNet + splat) -> pyramid loss ->
+    backward through splat and UNet -> FusedAdam; the loss falls on a fixed batch."""
+    from opticalflowdiffusion_amd import FlowDiffuser
+    torch.manual_seed(0)
+    B, H, W = 2, 32, 64
+    fd = FlowDiffuser(dict(target="joint", image_size=[H, W], timesteps=50, flow_max=20, zero_init=False, lr=2e-4, weight_decay=0.0)).cuda()
+    fd.log_dict = lambda *a, **k: None
+    opt = fd.configure_optimizers()
+    img = torch.rand(B, 3, H, W, device="cuda")
+    flow = torch.clamp(torch.nn.functional.avg_pool2d(torch.randn(B, 2, H, W, device="cuda") * 30, 9, 1, 4), -20, 20)
+    losses = []
+    for it in range(10):
+        torch.manual_seed(100)
+        loss = fd.training_step((img, img, flow), it)
+        assert torch.isfinite(loss)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in fd.unet.parameters())
+    assert losses[-1] < losses[0], losses

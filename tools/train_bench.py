@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--target", default="flow", choices=["flow", "joint", "target"],
+                    help="flow_diffuser.yaml `target` (the shipped default is joint: UnetWithWarp + pyramid loss; needs H, W % 16 == 0)")
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--dump", default=None)
     a = ap.parse_args()
@@ -31,7 +33,7 @@ def main():
     torch.cuda.set_device(dev)
     P.init(device=dev)
     torch.manual_seed(0)
-    fd = FlowDiffuser(dict(target="flow", image_size=[a.height, a.width], timesteps=1000, flow_max=20, zero_init=False,
+    fd = FlowDiffuser(dict(target=a.target, image_size=[a.height, a.width], timesteps=1000, flow_max=20, zero_init=False,
                            lr=1e-4, weight_decay=0.0, clip=100.0)).to(dev)
     fd.log_dict = lambda *x, **k: None
     P.broadcast_parameters(fd)
@@ -65,7 +67,7 @@ def main():
     res = {"metric": "FlowDiffuser train steps/sec", "value": P.whole_job_rate(a.steps, 1, dt), "unit": "steps/s", "n_gpus": world,
            "samples_per_s": P.whole_job_rate(a.steps * B, world, dt), "ms_per_step": 1e3 * dt / a.steps, "steps": a.steps, "warmup": a.warmup,
            "scaling": "weak", "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": f"train B={B}/GPU {H}x{W} T=1000 Adam", "global_batch": B * world},
+           "config": {"workload": f"train target={a.target} B={B}/GPU {H}x{W} T=1000 Adam", "global_batch": B * world},
            "loss": float(loss), "max_mem_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
     if a.profile:
         prof = fd.unet.profile()
