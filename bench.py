@@ -44,7 +44,15 @@ def cpu_baseline(H, W, batch):
         t0 = time.time()
         R.unet_forward(P, x, cond, t, mode="fp32")
         dt = time.time() - t0
-    return {"value": 1.0 / (dt * batch), "unit": "denoise_steps/s", "cores": torch.get_num_threads(), "kind": "port",
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": 1.0 / (dt * batch), "unit": "denoise_steps/s", "cores": torch.get_num_threads(), "cpu_model": model, "kind": "port",
             "sample": f"1 of {batch} samples: one fp32 UNet forward at 1x5x{H}x{W} in {dt:.1f} s, scaled x{batch}"}
 
 

@@ -273,6 +273,18 @@ int ofd_unet_train_forward(ofd_unet* u, const float* x, int Cx, const float* con
                            float* out, int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 int ofd_unet_backward(ofd_unet* u, const float* dout, ofd_grad_ready_fn on_ready, void* user, void* stream);
 
+/* --------------------------------------------------- forward building blocks of the UNet executor ----
+ * ofd_layernorm_c (DD:116-125): out = LN_channels(x) * g (+ residual), NHWC bf16, npix rows of C channels.
+ * ofd_time_mlp (DD:139-151, 319-324): sinusoidal embedding -> Linear -> GELU -> Linear; also SiLU(temb).
+ * ofd_gn_finalize (DD:181-185): per-(tile, wave, 8-channel) partial sums of a conv epilogue
+ *   (ofd_conv_gn_partial_count floats) -> the folded GroupNorm affine (a, s) per (sample, channel), and
+ *   optionally the statistics [B][8][{mean, rstd}] the backward needs. */
+int ofd_layernorm_c(const void* x, const float* g, const void* residual, void* out, size_t npix, int C, float eps, void* stream);
+int ofd_time_mlp(const int64_t* t, const float* w1, const float* b1, const float* w2, const float* b2,
+                 float* temb, float* temb_silu, int B, int dim, void* stream);
+int ofd_gn_finalize(const float* partial, int B, int H, int W, int C, const float* gamma, const float* beta,
+                    const float* ss, int ss_stride, int ss_offset, float* a_out, float* s_out, float* stats_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

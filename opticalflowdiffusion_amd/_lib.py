@@ -103,6 +103,9 @@ SIGNATURES = {
     "ofd_unet_train_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ofd_unet_backward": (c_int, [c_void_p, c_void_p, GRAD_READY, c_void_p, c_void_p]),
     "ofd_nan_mse_grad": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ofd_layernorm_c": (c_int, [c_void_p] * 4 + [c_size_t, c_int, c_float, c_void_p]),
+    "ofd_time_mlp": (c_int, [c_void_p] * 7 + [c_int, c_int, c_void_p]),
+    "ofd_gn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ofd_conv_weight_prep": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_float, c_int, c_void_p]),
 }
 

@@ -489,3 +489,19 @@ extern "C" int ofd_final_conv_backward(const void* x, const float* w, const floa
     OFD_CHECK_ARG(x && w && dy && dx && dw && db, "final_conv_backward: null argument");
     return k_final_conv_bwd((const bf16_t*)x, w, dy, (bf16_t*)dx, dw, db, B, H, W, C, out_dim, (hipStream_t)stream);
 }
+
+// forward building blocks of the executor, exported for callers that compose their own blocks (SURVEY 8b export set)
+extern "C" int ofd_layernorm_c(const void* x, const float* g, const void* residual, void* out, size_t npix, int C, float eps, void* stream) {
+    OFD_CHECK_ARG(x && g && out, "layernorm_c: null argument");
+    return k_layernorm_c((const bf16_t*)x, g, (const bf16_t*)residual, (bf16_t*)out, npix, C, eps, (hipStream_t)stream);
+}
+extern "C" int ofd_time_mlp(const int64_t* t, const float* w1, const float* b1, const float* w2, const float* b2, float* temb, float* temb_silu,
+                            int B, int dim, void* stream) {
+    OFD_CHECK_ARG(t && w1 && b1 && w2 && b2 && temb && temb_silu && B > 0, "time_mlp: bad argument");
+    return k_time_mlp(t, w1, b1, w2, b2, temb, temb_silu, B, dim, (hipStream_t)stream);
+}
+extern "C" int ofd_gn_finalize(const float* partial, int B, int H, int W, int C, const float* gamma, const float* beta, const float* ss,
+                               int ss_stride, int ss_offset, float* a_out, float* s_out, float* stats_out, void* stream) {
+    OFD_CHECK_ARG(partial && gamma && beta && a_out && s_out, "gn_finalize: null argument");
+    return k_gn_finalize(partial, B, H, W, C, gamma, beta, ss, ss_stride, ss_offset, a_out, s_out, (hipStream_t)stream, stats_out);
+}
