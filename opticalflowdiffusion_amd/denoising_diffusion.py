@@ -258,11 +258,15 @@ class Unet(nn.Module):
         if sync is not None:
             sync.finish(flat)
         self._ticket += 1                   # tape consumed
+        # autograd gets views of ONE copy of the flat buffer (a single 143 MB device copy): handing out views of
+        # the executor's own buffer would alias a surviving `.grad` from the previous step with the incoming
+        # gradient (zero_grad(set_to_none=False) / gradient accumulation: `grad += grad` would double it)
+        snap = flat.clone()
         grads = []
         for i, name in enumerate(self._names):
             p = self._param(name)
             off = self._goffsets[i]
-            grads.append(flat[off:off + p.numel()].view(p.shape))
+            grads.append(snap[off:off + p.numel()].view(p.shape))
         return grads
 
     def read_tap(self, name, shape):

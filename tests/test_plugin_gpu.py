@@ -265,3 +265,27 @@ def test_joint_training_step_reaches_every_parameter():
         losses.append(float(loss.detach()))
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in fd.unet.parameters())
     assert losses[-1] < losses[0], losses
+
+
+def test_gradient_accumulation_and_zero_grad_in_place():
+    """two backward passes without clearing add up (accumulate_grad_batches > 1, XB:203), and
+    zero_grad(set_to_none=False) followed by a backward gives the plain gradient again"""
+    from opticalflowdiffusion_amd import Unet
+    from opticalflowdiffusion_amd.warp import nan_mse
+    torch.manual_seed(0)
+    net = Unet(64, channels=5, out_dim=2).cuda()
+    x, c, t = torch.randn(1, 2, 16, 16, device="cuda"), torch.randn(1, 3, 16, 16, device="cuda"), torch.tensor([3], device="cuda")
+    tgt = torch.zeros(1, 2, 16, 16, device="cuda")
+
+    def backward():
+        nan_mse(net(x, external_cond=c, time=t), tgt).backward()
+
+    backward()
+    g1 = [p.grad.clone() for p in net.parameters()]
+    backward()
+    for p, g in zip(net.parameters(), g1):
+        assert torch.allclose(p.grad, 2 * g, rtol=1e-5, atol=1e-8)
+    net.zero_grad(set_to_none=False)
+    backward()
+    for p, g in zip(net.parameters(), g1):
+        assert torch.allclose(p.grad, g, rtol=1e-5, atol=1e-8)
