@@ -1,0 +1,74 @@
+"""Input side of the FlowDiffuser path: the Middlebury `.flo` codec the reference's Sintel
+loader uses (datasets/animation/sintel.py:59-65) and an offline procedural dataset with the reference's
+batch contract `(img in [0,1] (3,H,W), tgt (3,H,W), flow px (2,H,W); flow channel 0 = x)`.
+
+Host-side file / tensor plumbing only -- no arithmetic of the hot path lives here.
+"""
+import struct
+
+import numpy as np
+import torch
+
+FLO_MAGIC = 202021.25          # 'PIEH' as little-endian float32
+
+
+def read_flo(path):
+    """sintel.py:59-65: float32 magic, int32 width, int32 height, then h*w*2 float32 (x, y interleaved).
+    Returns (h, w, 2) float32.  Unlike the reference the magic and the payload size are checked."""
+    with open(path, "rb") as f:
+        head = f.read(12)
+        if len(head) != 12:
+            raise ValueError(f"{path}: truncated .flo header")
+        magic, w, h = struct.unpack("<fii", head)
+        if magic != FLO_MAGIC:
+            raise ValueError(f"{path}: bad .flo magic {magic!r} (expected {FLO_MAGIC})")
+        if w <= 0 or h <= 0 or w * h > (1 << 28):
+            raise ValueError(f"{path}: implausible .flo size {w}x{h}")
+        data = np.fromfile(f, np.float32, count=h * w * 2)
+    if data.size != h * w * 2:
+        raise ValueError(f"{path}: truncated .flo payload ({data.size} of {h * w * 2} floats)")
+    return data.reshape(h, w, 2)
+
+
+def write_flo(path, flow_hw2):
+    a = np.ascontiguousarray(np.asarray(flow_hw2, dtype=np.float32))
+    if a.ndim != 3 or a.shape[2] != 2:
+        raise ValueError("write_flo expects (h, w, 2)")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<fii", FLO_MAGIC, a.shape[1], a.shape[0]))
+        a.tofile(f)
+
+
+def flo_to_tensor(flow_hw2, size=None):
+    """(h, w, 2) -> (2, H, W) tensor, channel 0 = x displacement.  With `size=(H, W)` the field is resized
+    bilinearly AND rescaled (the reference resizes without rescaling the vectors, sintel.py:80)."""
+    t = torch.from_numpy(np.ascontiguousarray(flow_hw2)).permute(2, 0, 1).float()
+    if size is not None and tuple(size) != tuple(t.shape[-2:]):
+        h, w = t.shape[-2:]
+        t = torch.nn.functional.interpolate(t[None], size=tuple(size), mode="bilinear", align_corners=False)[0]
+        t[0] *= size[1] / w
+        t[1] *= size[0] / h
+    return t
+
+
+class SyntheticFlowPairs(torch.utils.data.Dataset):
+    """Offline stand-in for the Sintel frame pairs (the files are absent, sintel.py:19-21): smooth random colour
+    images and Sintel-like flow magnitudes (N(0, sigma^2) px box-filtered 9x9, clamped to +-flow_max), SURVEY 8d.
+    Deterministic per (seed, index); every rank / worker can draw its own disjoint indices."""
+
+    def __init__(self, length, height, width, flow_sigma=8.0, flow_max=20.0, seed=0):
+        self.length, self.h, self.w = int(length), int(height), int(width)
+        self.sigma, self.fmax, self.seed = float(flow_sigma), float(flow_max), int(seed)
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        if not 0 <= i < self.length:
+            raise IndexError(i)
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        box = lambda t, k: torch.nn.functional.avg_pool2d(t[None], k, 1, k // 2)[0]
+        img = box(torch.rand(3, self.h, self.w, generator=g), 5)
+        img = (img - img.amin()) / (img.amax() - img.amin() + 1e-8)
+        flow = box(torch.randn(2, self.h, self.w, generator=g) * self.sigma * 9.0, 9).clamp(-self.fmax, self.fmax)
+        return img, img.clone(), flow
