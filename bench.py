@@ -207,7 +207,7 @@ def main():
                                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                                 "algorithmic_flops_per_launch": k["flops"] / max(k["launches"], 1), "avg_launch_ms": per_launch_ms,
                                 "launches": k["launches"]}
-            c3 = [prof[n] for n in ("conv_igemm_kernel<3,128>", "conv_igemm_kernel<3,64>", "conv3x3_c64_pingpong_kernel")]
+            c3 = [prof[n] for n in ("conv_igemm_kernel<3,128>", "conv_igemm_kernel<3,64>", "conv3x3_c64_pingpong_kernel") if n in prof]
             line["conv3x3_all_tflops"] = sum(v["flops"] for v in c3) / (sum(v["ms"] for v in c3) * 1e-3) / 1e12
             line["kernel_ms_per_step"] = {n: v["ms"] / args.steps for n, v in prof.items()}
         if train is not None:

@@ -176,7 +176,7 @@ typedef struct {
 
 typedef struct {
     int B, H, W;            /* OUTPUT spatial size */
-    int ksize;              /* 1, 3 or 7 */
+    int ksize;              /* 1, 3 or 7; 2 = one phase of an up-sampled 3x3 (see up2_phase) */
     int n_src;              /* 1..4 */
     ofd_conv_src src[4];
     int Cout;               /* multiple of 64 */
@@ -191,6 +191,10 @@ typedef struct {
     void* out;              /* bf16 NHWC (B,H,W,Cout) */
     float* gn_partial;      /* optional: GroupNorm partial sums [b][tile][wave][Cout/8][2] (sum, sum of squares of
                                the stored values), ofd_conv_gn_partial_count floats */
+    int up2_phase;          /* ksize 2 only: 1 + py*2 + px.  Upsample(x2, nearest) + 3x3 (DD:89-93) as four 2x2 convs on
+                               the LOW-RES source: B,H,W are the low-res size, `out` is the (2H, 2W) tensor and this
+                               launch writes its pixels (2y+py, 2x+px); weights from ofd_conv_upsample_phase_weight_prep
+                               (+ (up2_phase-1) * 4*Cin*Cout elements) */
 } ofd_conv_args;
 
 int ofd_conv_forward(const ofd_conv_args* a, void* stream);
@@ -210,6 +214,8 @@ int ofd_conv_weight_prep(const float* w_oihw, void* w_out, int Cout, int Cin, in
  *                  forward's input sources and dY; ofd_conv_wgrad_finish converts to the OIHW parameter
  *                  gradient, through weight standardisation when ws_eps >= 0 (DD:109-112).
  * bias gradient  : ofd_channel_sum (out[C] += column sums; zero it first). */
+/* 3x3 OIHW fp32 -> the four collapsed 2x2 kernels of the phase decomposition, 4 x [4 taps][Cin/8][Cout][8] bf16 */
+int ofd_conv_upsample_phase_weight_prep(const float* w_oihw, void* w_out, int Cout, int Cin, void* stream);
 int ofd_conv_dgrad_weight_prep(const void* w_fwd, void* w_t, int Cout, int Cin, int ksize, void* stream);
 int ofd_conv_wgrad(const ofd_conv_args* fwd, const void* dy, float* dw_acc, void* stream);
 int ofd_conv7_wgrad(const void* x16, const void* dy, float* dw_acc, int B, int H, int W, void* stream);

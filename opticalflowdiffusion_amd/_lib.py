@@ -31,7 +31,8 @@ class ConvArgs(ctypes.Structure):
     _fields_ = [("B", c_int), ("H", c_int), ("W", c_int), ("ksize", c_int), ("n_src", c_int),
                 ("src", ConvSrc * 4), ("Cout", c_int), ("weight", c_void_p), ("bias", c_void_p),
                 ("in_scale", c_void_p), ("in_shift", c_void_p), ("residual", c_void_p), ("res_act", c_void_p),
-                ("res_scale", c_void_p), ("res_shift", c_void_p), ("out", c_void_p), ("gn_partial", c_void_p)]
+                ("res_scale", c_void_p), ("res_shift", c_void_p), ("out", c_void_p), ("gn_partial", c_void_p),
+                ("up2_phase", c_int)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/ofd.h
@@ -106,6 +107,7 @@ SIGNATURES = {
     "ofd_layernorm_c": (c_int, [c_void_p] * 4 + [c_size_t, c_int, c_float, c_void_p]),
     "ofd_time_mlp": (c_int, [c_void_p] * 7 + [c_int, c_int, c_void_p]),
     "ofd_gn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ofd_conv_upsample_phase_weight_prep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ofd_conv_weight_prep": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_float, c_int, c_void_p]),
 }
 

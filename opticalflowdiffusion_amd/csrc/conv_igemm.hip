@@ -34,7 +34,7 @@ struct Cfg {
     static constexpr int NC = CK / 8;                       // 16-byte units per pixel
     static constexpr int PAD = KS / 2;
     static constexpr int IH = TH + KS - 1, IW = TW + KS - 1, NPIX = IH * IW;
-    static constexpr int STAGES = (KS == 3) ? 9 : (KS == 7 ? 7 : 1);   // weight slabs per chunk
+    static constexpr int STAGES = (KS == 3) ? 9 : (KS == 7 ? 7 : (KS == 2 ? 4 : 1));   // weight slabs per chunk
     static constexpr int KSTEPS = (KS == 7) ? 7 : 4;                    // MFMA k-steps per slab
     static constexpr int SC8 = KSTEPS * 2;                              // 8-channel rows per slab
     // X tile in LDS is unit-major: [NC channel-octets][NPIX+1 slots][16 B] (see PP_US below)
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
         for (int i = 0; i < C::XPT; ++i) {
             const int p = min(tid / C::NC + i * (NTHREADS / C::NC), C::NPIX - 1);
             const int ty = p / C::IW, tx = p - ty * C::IW;
-            const int iy = oy0 - C::PAD + ty, ix = ox0 - C::PAD + tx;
+            const int iy = oy0 - (KS == 2 ? P.pad_y : C::PAD) + ty, ix = ox0 - (KS == 2 ? P.pad_x : C::PAD) + tx;
             const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
             okmask |= (ok ? 1u : 0u) << i;
             const int cy = min(max(iy, 0), P.H - 1), cx = min(max(ix, 0), P.W - 1);
@@ -242,8 +242,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             if (!DEEP && g + 1 < total_slabs) conv_load_w<KS, BN>(w1, P.weight, cin8, P.Cout, n0, kc, st + 1, tid);
             __syncthreads();   // lds_x (st == 0) and the W buffer of slab g are complete
             const unsigned char* wbuf = lds_w + (g & 1) * C::W_BYTES;
-            const int ky = (KS == 3) ? st / 3 : (KS == 7 ? st : 0);
-            const int kx3 = (KS == 3) ? st % 3 : 0;
+            const int ky = (KS == 3) ? st / 3 : (KS == 7 ? st : (KS == 2 ? st / 2 : 0));
+            const int kx3 = (KS == 3) ? st % 3 : (KS == 2 ? st % 2 : 0);
 #pragma unroll
             for (int ks = 0; ks < C::KSTEPS; ++ks) {
                 const int kx = (KS == 7) ? ks : kx3;
@@ -289,6 +289,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
         const int oy = oy0 + wave * 2 + pt, ox = ox0 + l31;
         const bool ok = oy < P.H && ox < P.W && !(dbg & 16);
         const size_t pix = ((size_t)b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1);   // clamped: loads stay in bounds
+        // KS == 2: this launch is one phase of an up-sampled 3x3 -> the output pixel is (2y + oy, 2x + ox) of a (2H, 2W) tensor
+        const size_t opix = (KS == 2) ? ((size_t)b * (2 * P.H) + 2 * min(oy, P.H - 1) + P.out_oy) * (2 * P.W) + 2 * min(ox, P.W - 1) + P.out_ox : pix;
 #pragma unroll
         for (int nt = 0; nt < C::NTN; ++nt) {
             uint2 q[4];
@@ -332,7 +334,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             for (int g = 0; g < 4; g += 2) {
                 const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
                 const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
-                if (ok) *(uint4*)(P.out + pix * P.Cout + n0 + nt * 32 + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                if (ok) *(uint4*)(P.out + opix * P.Cout + n0 + nt * 32 + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
             }
         }
     }
@@ -921,6 +923,27 @@ __global__ void __launch_bounds__(256) conv_weight_prep_kernel(const float* __re
     }
 }
 
+// nearest-x2 up-sample followed by a 3x3 conv (DD:89-93) = four 2x2 convs on the LOW-RES input, one per output phase
+// (py, px): output row 2y+py reads up-sampled rows 2y+py-1 .. 2y+py+1 = low-res rows {y-1, y, y} (py = 0) or {y, y, y+1}
+// (py = 1), so the three kernel rows collapse onto two source rows (same in x).  2.25x fewer MACs than convolving the
+// up-sampled tensor.  out: 4 x [2x2 taps][Cin/8][Cout][8] bf16 (phase = py*2+px, tap = dy*2+dx); the collapsed weights are
+// summed in fp32 and rounded once.
+__global__ void __launch_bounds__(256) upsample_phase_weight_prep_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin) {
+    const int o = blockIdx.x, c8n = Cin / 8;
+    const float* wo = w + (size_t)o * Cin * 9;
+    for (int i = threadIdx.x; i < Cin * 16; i += 256) {
+        const int ci = i / 16, ph = (i / 4) % 4, tap = i % 4;
+        const int py = ph >> 1, px = ph & 1, dy = tap >> 1, dx = tap & 1;
+        // kernel rows / columns that land on low-res offset d of phase p
+        const int ky0 = (py == 0) ? (dy == 0 ? 0 : 1) : (dy == 0 ? 0 : 2), ky1 = (py == 0) ? (dy == 0 ? 0 : 2) : (dy == 0 ? 1 : 2);
+        const int kx0 = (px == 0) ? (dx == 0 ? 0 : 1) : (dx == 0 ? 0 : 2), kx1 = (px == 0) ? (dx == 0 ? 0 : 2) : (dx == 0 ? 1 : 2);
+        float v = 0.0f;
+        for (int ky = ky0; ky <= ky1; ++ky)
+            for (int kx = kx0; kx <= kx1; ++kx) v += wo[(size_t)ci * 9 + ky * 3 + kx];
+        out[(size_t)ph * 4 * Cin * Cout + (((size_t)tap * c8n + ci / 8) * Cout + o) * 8 + (ci % 8)] = f2bf(v);
+    }
+}
+
 template <int KS, int BN>
 static int launch_conv(const ConvParams& P, hipStream_t s) {
     using C = Cfg<KS, BN>;
@@ -938,7 +961,9 @@ static int launch_conv(const ConvParams& P, hipStream_t s) {
 int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     OFD_CHECK_ARG(a && a->out && a->weight, "conv: null out/weight");
     OFD_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0, "conv: bad shape");
-    OFD_CHECK_ARG(a->ksize == 1 || a->ksize == 3 || a->ksize == 7, "conv: ksize %d unsupported", a->ksize);
+    OFD_CHECK_ARG(a->ksize == 1 || a->ksize == 2 || a->ksize == 3 || a->ksize == 7, "conv: ksize %d unsupported", a->ksize);
+    OFD_CHECK_ARG((a->ksize == 2) == (a->up2_phase >= 1 && a->up2_phase <= 4), "conv: ksize 2 is one phase (up2_phase 1..4) of an up-sampled 3x3");
+    OFD_CHECK_ARG(a->ksize != 2 || (!a->residual && !a->res_act && !a->gn_partial), "conv: phase convs take no residual / GroupNorm statistics");
     OFD_CHECK_ARG(a->Cout > 0 && a->Cout % 64 == 0, "conv: Cout=%d must be a multiple of 64", a->Cout);
     OFD_CHECK_ARG(a->n_src >= 1 && a->n_src <= 4, "conv: n_src=%d", a->n_src);
     OFD_CHECK_ARG(!(a->in_scale) == !(a->in_shift), "conv: in_scale/in_shift must come together");
@@ -970,6 +995,10 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     P.weight = (const bf16_t*)a->weight; P.bias = a->bias; P.in_scale = a->in_scale; P.in_shift = a->in_shift;
     P.residual = (const bf16_t*)a->residual; P.res_act = (const bf16_t*)a->res_act; P.res_scale = a->res_scale; P.res_shift = a->res_shift;
     P.out = (bf16_t*)a->out; P.gn_partial = a->gn_partial;
+    if (a->ksize == 2) {
+        const int py = (a->up2_phase - 1) >> 1, px = (a->up2_phase - 1) & 1;
+        P.pad_y = 1 - py; P.pad_x = 1 - px; P.out_oy = py; P.out_ox = px;
+    }
     { static int dbg_env = -1; if (dbg_env < 0) { const char* e = getenv("OFD_CONV_DBG"); dbg_env = e ? atoi(e) : 0; } P.dbg = dbg_env; }
     const bool wide = (a->Cout % 128 == 0);
     static int no_pp = -1;
@@ -994,6 +1023,7 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     if (a->ksize == 3 && use_ws) return wide ? launch_conv_ws<128>(P, s) : launch_conv_ws<64>(P, s);
     if (a->ksize == 3) return wide ? launch_conv<3, 128>(P, s) : launch_conv<3, 64>(P, s);
     if (a->ksize == 1) return wide ? launch_conv<1, 128>(P, s) : launch_conv<1, 64>(P, s);
+    if (a->ksize == 2) return wide ? launch_conv<2, 128>(P, s) : launch_conv<2, 64>(P, s);
     return launch_conv<7, 64>(P, s);
 }
 
@@ -1013,6 +1043,13 @@ extern "C" int ofd_conv_weight_prep(const float* w_oihw, void* w_out, int Cout, 
     OFD_CHECK_ARG(w_oihw && w_out && Cout > 0 && Cin > 0 && Cin_pad >= Cin && Cin_pad % 8 == 0, "weight_prep: bad argument");
     OFD_CHECK_ARG(!unshuffle || (Cin % 4 == 0 && Cin == Cin_pad), "weight_prep: unshuffle needs Cin %% 4 == 0");
     conv_weight_prep_kernel<<<Cout, 256, 0, (hipStream_t)stream>>>(w_oihw, (bf16_t*)w_out, Cout, Cin, Cin_pad, ksize, ws_eps, unshuffle);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" int ofd_conv_upsample_phase_weight_prep(const float* w_oihw, void* w_out, int Cout, int Cin, void* stream) {
+    OFD_CHECK_ARG(w_oihw && w_out && Cout > 0 && Cin > 0 && Cin % 8 == 0, "upsample_phase_weight_prep: bad argument");
+    upsample_phase_weight_prep_kernel<<<Cout, 256, 0, (hipStream_t)stream>>>(w_oihw, (bf16_t*)w_out, Cout, Cin);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

@@ -2,6 +2,7 @@
 // sequence of HIP launches on the caller's stream.  Parameters keep the reference's state-dict
 // names and order (denoising_diffusion.py:272-361; registration order downs, ups, mid).
 // Host code only: every kernel lives in conv_igemm.hip / blocks.hip.
+#include <cstdlib>
 #include "unet_exec.h"
 
 using namespace ofd;
@@ -89,7 +90,12 @@ static void build_registry(ofd_unet* u) {
         add_resblock(u, p + ".0", co + ci, co);
         add_resblock(u, p + ".1", co + ci, co);
         add_linattn(u, p + ".2", co);
-        if (i < 3) add_conv(u, p + ".3.1", ci, co, 3, true, -1.0f);
+        if (i < 3) {
+            add_conv(u, p + ".3.1", ci, co, 3, true, -1.0f);
+            ConvDesc& d = u->convs.back();              // Upsample(x2) + 3x3 also as four 2x2 phase kernels (forward)
+            d.phase_off = (long)u->n_wbuf;
+            u->n_wbuf += (size_t)16 * co * ci;
+        }
         else add_conv(u, p + ".3", ci, co, 3, true, -1.0f);
     }
     const int mid = u->dims[4];
@@ -270,6 +276,37 @@ static void plain_conv(Ctx& c, const std::string& prefix, const std::vector<SrcS
     }
 }
 
+// Upsample(x2, nearest) + 3x3 (DD:89-93) as four 2x2 phase convs on the low-res tensor: 2.25x fewer MACs than
+// convolving the up-sampled tensor.  The tape records the op in its reference form (the backward differentiates that).
+static void upsample_conv(Ctx& c, const std::string& prefix, const SrcSpec& src_up, Tensor out) {
+    ofd_unet* u = c.u;
+    const ConvDesc& d = u->convs[u->cindex.at(prefix)];
+    static int no_phase = -1;
+    if (no_phase < 0) { const char* e = getenv("OFD_NO_PHASE_UPSAMPLE"); no_phase = (e && atoi(e)) ? 1 : 0; }
+    if (d.phase_off < 0 || no_phase) { plain_conv(c, prefix, {src_up}, out); return; }
+    if (c.rc != OFD_OK) return;
+    const Tensor& lo = src_up.t;
+    const double px = (double)c.B * out.H * out.W;
+    c.begin(PC_CONVUP, 2.0 * px * d.Cout * (double)d.Cin * 9 /* algorithmic: as the reference executes it */, px * 2.0 * (d.Cout + d.Cin / 4.0),
+            prefix + " " + std::to_string(d.Cin) + "->" + std::to_string(d.Cout) + " @" + std::to_string(out.H) + "x" + std::to_string(out.W) + " (4 phases)");
+    for (int ph = 0; ph < 4; ++ph) {
+        ofd_conv_args a{};
+        a.B = c.B; a.H = lo.H; a.W = lo.W; a.ksize = 2; a.n_src = 1; a.Cout = d.Cout;
+        a.src[0].src = lo.p; a.src[0].channels = lo.C; a.src[0].src_channels = lo.C;
+        a.weight = u->d_wbuf + d.phase_off + (size_t)ph * 4 * d.Cin * d.Cout;
+        a.bias = u->P(prefix + ".bias");
+        a.out = out.p;
+        a.up2_phase = ph + 1;
+        RUN(conv_forward_impl(&a, c.s));
+    }
+    c.end();
+    if (c.train) {
+        TapeRec r;
+        r.kind = TK_CONV; r.name = prefix; r.srcs = {src_up}; r.out = out;
+        u->tape.push_back(r);
+    }
+}
+
 int run_forward(Ctx& c, const float* x, int Cx, const float* cond, int Cc, const int64_t* t, float* out, int H, int W, float* temb,
                 float* temb_silu) {
     ofd_unet* u = c.u;
@@ -342,7 +379,7 @@ int run_forward(Ctx& c, const float* x, int Cx, const float* cond, int Cc, const
         if (i < 3) {
             Tensor d = c.keep(ci, xcur.H * 2, xcur.W * 2);
             SrcSpec s; s.t = xcur; s.upsample = 1;
-            plain_conv(c, p + ".3.1", {s}, d);
+            upsample_conv(c, p + ".3.1", s, d);
             xcur = d;
         } else {
             Tensor d = c.keep(ci, xcur.H, xcur.W);
@@ -500,6 +537,10 @@ extern "C" int ofd_unet_prepare(ofd_unet* u, void* stream) {
     for (auto& c : u->convs) {
         int rc = ofd_conv_weight_prep(u->P(c.wname), u->d_wbuf + c.w_off, c.Cout, c.Cin, c.Cin_pad, c.ksize, c.ws_eps, c.unshuffle, stream);
         if (rc != OFD_OK) return rc;
+        if (c.phase_off >= 0) {
+            rc = ofd_conv_upsample_phase_weight_prep(u->P(c.wname), u->d_wbuf + c.phase_off, c.Cout, c.Cin, stream);
+            if (rc != OFD_OK) return rc;
+        }
     }
     for (auto& kv : u->la_fused) {
         const std::string& name = kv.first;

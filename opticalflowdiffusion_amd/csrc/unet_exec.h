@@ -23,6 +23,7 @@ struct ConvDesc {
     float ws_eps;        // < 0: plain conv
     int unshuffle;
     size_t w_off;        // bf16 elements into d_wbuf
+    long phase_off = -1; // up-sample convs: 4 collapsed 2x2 kernels (bf16 elements into d_wbuf), else -1
 };
 
 struct Tensor {
@@ -31,10 +32,11 @@ struct Tensor {
     bf16_t* g = nullptr;     // gradient buffer (training forward only)
 };
 
-enum ProfClass { PC_CONV3 = 0, PC_CONV3_64, PC_CONV3_PP, PC_CONV1, PC_CONV7, PC_GN, PC_RESOUT, PC_LN, PC_LINATTN, PC_FLASH, PC_MISC, PC_WGRAD3, PC_WGRAD1, PC_DGRAD3, PC_DGRAD1, PC_GNBWD, PC_LABWD, PC_FLASHBWD, PC_COUNT };
+enum ProfClass { PC_CONV3 = 0, PC_CONV3_64, PC_CONV3_PP, PC_CONV1, PC_CONV7, PC_GN, PC_RESOUT, PC_LN, PC_LINATTN, PC_FLASH, PC_MISC, PC_WGRAD3, PC_WGRAD1, PC_DGRAD3, PC_DGRAD1, PC_GNBWD, PC_LABWD, PC_FLASHBWD, PC_CONVUP, PC_COUNT };
 static const char* const kProfNames[PC_COUNT] = {"conv_igemm_kernel<3,128>", "conv_igemm_kernel<3,64>", "conv3x3_c64_pingpong_kernel", "conv1x1_igemm", "conv7x7_igemm", "gn_finalize", "resblock_out",
                                            "layernorm_c", "linear_attention_core", "flash_attention_d32", "misc", "conv_wgrad_kernel<3>", "conv_wgrad_kernel<1>",
-                                           "conv3x3_dgrad", "conv1x1_dgrad", "gn_silu_backward", "linear_attention_backward", "flash_attention_backward"};
+                                           "conv3x3_dgrad", "conv1x1_dgrad", "gn_silu_backward", "linear_attention_backward", "flash_attention_backward",
+                                           "conv_igemm_kernel<2,*> x4 (up-sample conv as 4 phase convs)"};
 
 struct ProfRec {
     int cls;

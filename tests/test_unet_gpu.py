@@ -288,3 +288,39 @@ def test_state_dict_layout_matches_reference_names(L):
     for k, v in sd.items():
         assert tuple(v.shape) == tuple(shapes[k]), k
     assert sum(v.numel() for v in sd.values()) == 35729858
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 32, 128, 64), (2, 11, 40, 256, 128), (1, 5, 9, 64, 64)])
+def test_upsample_conv_as_four_phase_convs(L, B, H, W, Cin, Cout):
+    """Upsample(x2, nearest) + Conv3x3 (DD:89-93) computed as four 2x2 convs on the low-res input (2.25x fewer MACs):
+    same function; the collapsed weights are rounded to bf16 once, hence the slightly wider per-op tolerance."""
+    torch.manual_seed(0)
+    x = q(torch.randn(B, Cin, H, W))
+    w = torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout) * 0.1
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), q(w), bias, padding=1)
+    wp = torch.empty(4 * 4 * Cin * Cout, dtype=torch.bfloat16, device="cuda")
+    wd = w.contiguous().cuda()
+    L.check(L.lib().ofd_conv_upsample_phase_weight_prep(L.ptr(wd), L.ptr(wp), Cout, Cin, L.stream()))
+    xd = to_nhwc(x)
+    out = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    bd = bias.cuda()
+    for ph in range(4):
+        a = L.ConvArgs()
+        a.B, a.H, a.W, a.ksize, a.n_src, a.Cout = B, H, W, 2, 1, Cout
+        a.src[0].src, a.src[0].channels, a.src[0].src_channels = xd.data_ptr(), Cin, Cin
+        a.weight = wp.data_ptr() + ph * 4 * Cin * Cout * 2
+        a.bias, a.out, a.up2_phase = bd.data_ptr(), out.data_ptr(), ph + 1
+        L.check(L.lib().ofd_conv_forward(ctypes.byref(a), L.stream()))
+    torch.cuda.synchronize()
+    got = from_nhwc(out)
+    assert torch.isfinite(got).all()                       # every output pixel written by exactly one phase
+    # vs the per-tap-rounded weights of the bf16c contract: two different bf16 roundings of the same fp32 kernel ...
+    check_close(got, ref, tol=4e-3, what="phase-decomposed upsample conv")
+    # ... and vs the un-rounded fp32 weights the collapsed kernels are at least as close as the per-tap rounding is
+    exact = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, bias, padding=1)
+    assert rel_l2(got, q(exact)) <= 1.25 * rel_l2(q(ref), q(exact)) + 1e-4
+    # argument errors
+    a.up2_phase = 0
+    with pytest.raises(L.OfdError, match="phase"):
+        L.check(L.lib().ofd_conv_forward(ctypes.byref(a), L.stream()))
