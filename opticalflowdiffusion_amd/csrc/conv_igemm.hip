@@ -958,6 +958,8 @@ static int launch_conv(const ConvParams& P, hipStream_t s) {
     return OFD_OK;
 }
 
+int launch_conv3x3_c64_rw(const ConvParams& P, hipStream_t s);     // conv_rw.hip
+
 int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     OFD_CHECK_ARG(a && a->out && a->weight, "conv: null out/weight");
     OFD_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0, "conv: bad shape");
@@ -1003,6 +1005,10 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     const bool wide = (a->Cout % 128 == 0);
     static int no_pp = -1;
     if (no_pp < 0) { const char* e = getenv("OFD_NO_PINGPONG"); no_pp = (e && atoi(e)) ? 1 : 0; }
+    static int use_rw = -1;
+    if (use_rw < 0) { const char* e = getenv("OFD_CONV_RW"); use_rw = e ? atoi(e) : 0; }      // register-window variant: opt-in (conv_rw.hip)
+    if (a->ksize == 3 && a->Cout == 64 && P.Cin_total == 64 && a->n_src == 1 && P.src[0].mode == 0 && !a->residual && !a->res_act && use_rw)
+        return launch_conv3x3_c64_rw(P, s);
     if (a->ksize == 3 && a->Cout == 64 && P.Cin_total == 64 && a->n_src == 1 && P.src[0].mode == 0 && !a->residual && !a->res_act && !no_pp) {
         static bool attr_set = false;
         if (!attr_set) {
