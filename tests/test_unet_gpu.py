@@ -324,3 +324,43 @@ def test_upsample_conv_as_four_phase_convs(L, B, H, W, Cin, Cout):
     a.up2_phase = 0
     with pytest.raises(L.OfdError, match="phase"):
         L.check(L.lib().ofd_conv_forward(ctypes.byref(a), L.stream()))
+
+
+def test_exported_building_blocks(L):
+    """ofd_layernorm_c / ofd_time_mlp / ofd_gn_finalize (SURVEY 8b export set) against the oracle ops."""
+    torch.manual_seed(0)
+    lib = L.lib()
+    # LayerNorm over channels (DD:116-125) with a residual
+    npix, C = 300, 128
+    x, res = q(torch.randn(1, C, npix, 1) * 2 + 0.3), q(torch.randn(1, C, npix, 1))
+    g = 1 + 0.2 * torch.randn(C)
+    want = R.layer_norm_c(x, g.view(1, C, 1, 1), 1e-5) + res
+    xd, rd, gd = to_nhwc(x), to_nhwc(res), g.cuda()
+    out = torch.empty_like(xd)
+    L.check(lib.ofd_layernorm_c(L.ptr(xd), L.ptr(gd), L.ptr(rd), L.ptr(out), npix, C, 1e-5, L.stream()))
+    check_close(from_nhwc(out), want, what="layernorm_c")
+    # time MLP (DD:139-151, 319-324)
+    P = default_init_params(5, seed=1)
+    t = torch.tensor([0, 17, 999])
+    want_t = R.time_mlp(P, t, 64)
+    dev = lambda n: P[n].contiguous().cuda()
+    temb, ts = torch.empty(3, 256, device="cuda"), torch.empty(3, 256, device="cuda")
+    td = t.cuda()
+    w1, b1, w2, b2 = dev("time_mlp.1.weight"), dev("time_mlp.1.bias"), dev("time_mlp.3.weight"), dev("time_mlp.3.bias")
+    L.check(lib.ofd_time_mlp(L.ptr(td), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(temb), L.ptr(ts), 3, 64, L.stream()))
+    assert rel_l2(temb.cpu(), want_t) < 1e-5 and rel_l2(ts.cpu(), F.silu(want_t)) < 1e-5
+    # GroupNorm finalize: partial sums of a conv epilogue -> folded affine + statistics
+    B, H, W, C = 2, 13, 40, 64
+    xin = q(torch.randn(B, 64, H, W))
+    w = torch.randn(C, 64, 3, 3) / 24
+    outc, gn = run_conv(L, B, H, W, 3, [dict(t=to_nhwc(xin))], C, prep_weight(L, w, 3, -1.0), want_gn=True)
+    h = from_nhwc(outc)
+    gamma, beta = 1 + 0.1 * torch.randn(C), 0.1 * torch.randn(C)
+    a, s, st = (torch.empty(B, C, device="cuda"), torch.empty(B, C, device="cuda"), torch.empty(B, 8, 2, device="cuda"))
+    gam, bet = gamma.cuda(), beta.cuda()
+    L.check(lib.ofd_gn_finalize(L.ptr(gn), B, H, W, C, L.ptr(gam), L.ptr(bet), None, 0, 0, L.ptr(a), L.ptr(s), L.ptr(st), L.stream()))
+    torch.cuda.synchronize()
+    got = h * a.cpu()[:, :, None, None] + s.cpu()[:, :, None, None]
+    assert rel_l2(got, F.group_norm(h, 8, gamma, beta, 1e-5)) < 1e-4
+    hg = h.view(B, 8, -1)
+    assert torch.allclose(st.cpu()[..., 0], hg.mean(-1), atol=1e-4) and torch.allclose(st.cpu()[..., 1], (hg.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-3)
