@@ -191,6 +191,9 @@ typedef struct {
     void* out;              /* bf16 NHWC (B,H,W,Cout) */
     float* gn_partial;      /* optional: GroupNorm partial sums [b][tile][wave][Cout/8][2] (sum, sum of squares of
                                the stored values), ofd_conv_gn_partial_count floats */
+    void* out2;             /* split output (data gradients of a conv over two concatenated sources): channels */
+    const void* residual2;  /*   [0, split) -> out / residual with pixel stride split, [split, Cout) -> out2 / residual2 */
+    int split;              /*   with stride Cout - split; multiple of 64, 0 = off */
     int up2_phase;          /* ksize 2 only: 1 + py*2 + px.  Upsample(x2, nearest) + 3x3 (DD:89-93) as four 2x2 convs on
                                the LOW-RES source: B,H,W are the low-res size, `out` is the (2H, 2W) tensor and this
                                launch writes its pixels (2y+py, 2x+px); weights from ofd_conv_upsample_phase_weight_prep

@@ -32,7 +32,7 @@ class ConvArgs(ctypes.Structure):
                 ("src", ConvSrc * 4), ("Cout", c_int), ("weight", c_void_p), ("bias", c_void_p),
                 ("in_scale", c_void_p), ("in_shift", c_void_p), ("residual", c_void_p), ("res_act", c_void_p),
                 ("res_scale", c_void_p), ("res_shift", c_void_p), ("out", c_void_p), ("gn_partial", c_void_p),
-                ("up2_phase", c_int)]
+                ("out2", c_void_p), ("residual2", c_void_p), ("split", c_int), ("up2_phase", c_int)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/ofd.h

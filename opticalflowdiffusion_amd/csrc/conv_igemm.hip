@@ -293,6 +293,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
         const size_t opix = (KS == 2) ? ((size_t)b * (2 * P.H) + 2 * min(oy, P.H - 1) + P.out_oy) * (2 * P.W) + 2 * min(ox, P.W - 1) + P.out_ox : pix;
 #pragma unroll
         for (int nt = 0; nt < C::NTN; ++nt) {
+            // destination of this 32-channel block (uniform per workgroup and nt): the second one when the output is split
+            const bool second = P.split > 0 && n0 + nt * 32 >= P.split;
+            bf16_t* const o_base = second ? P.out2 : P.out;
+            const bf16_t* const r_base = second ? P.residual2 : P.residual;
+            const int o_stride = P.split > 0 ? (second ? P.Cout - P.split : P.split) : P.Cout;
+            const int o_c0 = n0 + nt * 32 - (second ? P.split : 0);
             uint2 q[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -313,8 +319,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
                     v[2] += silu_f(bf2f((bf16_t)(r.y & 0xffffu)) * sc.z + sh.z);
                     v[3] += silu_f(bf2f((bf16_t)(r.y >> 16)) * sc.w + sh.w);
                 }
-                if (P.residual) {
-                    const uint2 r = *(const uint2*)(P.residual + pix * P.Cout + c);
+                if (r_base) {
+                    const uint2 r = *(const uint2*)(r_base + pix * o_stride + o_c0 + 8 * g + 4 * half);
                     v[0] += bf2f((bf16_t)(r.x & 0xffffu));
                     v[1] += bf2f((bf16_t)(r.x >> 16));
                     v[2] += bf2f((bf16_t)(r.y & 0xffffu));
@@ -334,7 +340,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             for (int g = 0; g < 4; g += 2) {
                 const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
                 const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
-                if (ok) *(uint4*)(P.out + opix * P.Cout + n0 + nt * 32 + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                if (ok) *(uint4*)(o_base + opix * o_stride + o_c0 + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
             }
         }
     }
@@ -970,6 +976,8 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     OFD_CHECK_ARG(a->n_src >= 1 && a->n_src <= 4, "conv: n_src=%d", a->n_src);
     OFD_CHECK_ARG(!(a->in_scale) == !(a->in_shift), "conv: in_scale/in_shift must come together");
     OFD_CHECK_ARG(!a->res_act || (a->res_scale && a->res_shift), "conv: res_act needs res_scale/res_shift");
+    OFD_CHECK_ARG(a->split == 0 || (a->split > 0 && a->split < a->Cout && a->split % 64 == 0 && a->out2 && a->ksize != 2 && !a->gn_partial && !a->res_act),
+                  "conv: split=%d needs out2, a multiple of 64 below Cout, no GroupNorm statistics", a->split);
     const int ck = a->ksize == 7 ? 16 : 64;
     ConvParams P{};
     P.B = a->B; P.H = a->H; P.W = a->W; P.Cout = a->Cout; P.n_src = a->n_src;
@@ -997,6 +1005,7 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     P.weight = (const bf16_t*)a->weight; P.bias = a->bias; P.in_scale = a->in_scale; P.in_shift = a->in_shift;
     P.residual = (const bf16_t*)a->residual; P.res_act = (const bf16_t*)a->res_act; P.res_scale = a->res_scale; P.res_shift = a->res_shift;
     P.out = (bf16_t*)a->out; P.gn_partial = a->gn_partial;
+    P.out2 = (bf16_t*)a->out2; P.residual2 = (const bf16_t*)a->residual2; P.split = a->split;
     if (a->ksize == 2) {
         const int py = (a->up2_phase - 1) >> 1, px = (a->up2_phase - 1) & 1;
         P.pad_y = 1 - py; P.pad_x = 1 - px; P.out_oy = py; P.out_ox = px;
@@ -1007,7 +1016,7 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     if (no_pp < 0) { const char* e = getenv("OFD_NO_PINGPONG"); no_pp = (e && atoi(e)) ? 1 : 0; }
     static int use_rw = -1;
     if (use_rw < 0) { const char* e = getenv("OFD_CONV_RW"); use_rw = e ? atoi(e) : 0; }      // register-window variant: opt-in (conv_rw.hip)
-    if (a->ksize == 3 && a->Cout == 64 && P.Cin_total == 64 && a->n_src == 1 && P.src[0].mode == 0 && !a->residual && !a->res_act && use_rw)
+    if (a->ksize == 3 && a->Cout == 64 && P.Cin_total == 64 && a->n_src == 1 && P.src[0].mode == 0 && !a->residual && !a->res_act && use_rw && !a->split)
         return launch_conv3x3_c64_rw(P, s);
     if (a->ksize == 3 && a->Cout == 64 && P.Cin_total == 64 && a->n_src == 1 && P.src[0].mode == 0 && !a->residual && !a->res_act && !no_pp) {
         static bool attr_set = false;
@@ -1026,7 +1035,7 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     // (DESIGN.md section 4), so it is opt-in for A/B runs: OFD_CONV_WS=1
     static int use_ws = -1;
     if (use_ws < 0) { const char* e = getenv("OFD_CONV_WS"); use_ws = (e && atoi(e)) ? 1 : 0; }
-    if (a->ksize == 3 && use_ws) return wide ? launch_conv_ws<128>(P, s) : launch_conv_ws<64>(P, s);
+    if (a->ksize == 3 && use_ws && !a->split) return wide ? launch_conv_ws<128>(P, s) : launch_conv_ws<64>(P, s);
     if (a->ksize == 3) return wide ? launch_conv<3, 128>(P, s) : launch_conv<3, 64>(P, s);
     if (a->ksize == 1) return wide ? launch_conv<1, 128>(P, s) : launch_conv<1, 64>(P, s);
     if (a->ksize == 2) return wide ? launch_conv<2, 128>(P, s) : launch_conv<2, 64>(P, s);

@@ -27,6 +27,11 @@ struct ConvParams {
     const float* res_shift;
     bf16_t* out;
     float* gn_partial;
+    // split output (data gradient of a conv over two concatenated sources): channels [0, split) go to `out` / `residual`
+    // with pixel stride `split`, channels [split, Cout) to out2 / residual2 with stride Cout - split; split = 0: off
+    bf16_t* out2;
+    const bf16_t* residual2;
+    int split;
     int pad_y, pad_x;   // KS == 2 (one phase of an up-sampled 3x3): rows / columns of padding above / left of the tile
     int out_oy, out_ox; // KS == 2: the output is (2H, 2W) and this launch writes pixels (2y + out_oy, 2x + out_ox)
     int dbg;            // diagnostic ablation bits (OFD_CONV_DBG), 0 in production

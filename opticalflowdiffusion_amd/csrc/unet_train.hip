@@ -43,8 +43,13 @@ static void fill_args(ofd_conv_args& a, int B, int H, int W, int ksize, int Cout
 
 // backward of one convolution: bias and weight gradients into the flat gradient buffer; returns the
 // gradient w.r.t. the concatenated (virtual) input [B][H][W][cin] in scratch (+ `add` when given)
-// gradient w.r.t. a single same-resolution source goes straight into that source's gradient buffer
-static bool direct_target(const std::vector<SrcSpec>& srcs) { return srcs.size() == 1 && !srcs[0].upsample && !srcs[0].unshuffle && srcs[0].t.g; }
+// gradient w.r.t. a single same-resolution source goes straight into that source's gradient buffer; over two
+// concatenated same-resolution sources the conv epilogue splits its output between their two buffers
+static bool plain_src(const SrcSpec& s) { return !s.upsample && !s.unshuffle && s.t.g; }
+static bool direct_target(const std::vector<SrcSpec>& srcs) {
+    if (srcs.size() == 1) return plain_src(srcs[0]);
+    return srcs.size() == 2 && plain_src(srcs[0]) && plain_src(srcs[1]) && srcs[0].t.C % 64 == 0 && srcs[1].t.C % 64 == 0 && srcs[0].t.p != srcs[1].t.p;
+}
 
 static Tensor conv_backward(Bwd& b, const std::string& prefix, const std::vector<SrcSpec>& srcs, const bf16_t* dy, int H, int W, bool need_dx,
                             const bf16_t* add, bool bias_done = false, bool to_source = false) {
@@ -76,6 +81,24 @@ static Tensor conv_backward(Bwd& b, const std::string& prefix, const std::vector
     c.end();
     if (!need_dx) return D;
     const bool direct = to_source && direct_target(srcs);
+    if (direct && srcs.size() == 2) {
+        // split epilogue: (+)= into both sources' gradients; `add` (if any) must already be inside them
+        if (add) { set_error("conv_backward: split output takes no extra addend"); c.rc = OFD_ERR_STATE; return D; }
+        const Tensor &t0 = srcs[0].t, &t1 = srcs[1].t;
+        ofd_conv_args a{};
+        a.B = B; a.H = H; a.W = W; a.ksize = d.ksize; a.n_src = 1; a.Cout = cin;
+        a.src[0].src = dy; a.src[0].channels = d.Cout; a.src[0].src_channels = d.Cout;
+        a.weight = u->d_wtbuf + d.w_off;
+        a.out = t0.g; a.out2 = t1.g; a.split = t0.C;
+        a.residual = b.has(t0) ? t0.g : nullptr;
+        a.residual2 = b.has(t1) ? t1.g : nullptr;
+        c.begin(d.ksize == 3 ? PC_DGRAD3 : PC_DGRAD1, 2.0 * px * d.Cout * (double)d.Cin * taps, px * 2.0 * (d.Cout + cin), prefix + " dgrad (split)");
+        RUN(conv_forward_impl(&a, c.s));
+        c.end();
+        b.mark(t0); b.mark(t1);
+        D = t0; D.p = t0.g;
+        return D;
+    }
     if (direct) {
         // (+)= into the source's gradient: the conv epilogue adds `residual`, which may alias the output
         const Tensor& t = srcs[0].t;
@@ -156,6 +179,11 @@ static void resblock_backward(Bwd& b, const TapeRec& r, float* dss, float* dts) 
         const bool direct = direct_target(r.srcs);
         D = conv_backward(b, name + ".block1.proj", r.srcs, r.h1.g, H, W, true, dout, true, direct);     // + identity residual
         if (direct) return;
+    } else if (direct_target(r.srcs)) {
+        // both data gradients (block1.proj, res_conv) accumulate straight into the sources' gradient buffers
+        conv_backward(b, name + ".block1.proj", r.srcs, r.h1.g, H, W, true, nullptr, true, true);
+        conv_backward(b, name + ".res_conv", r.srcs, dout, H, W, true, nullptr, false, true);
+        return;
     } else {
         Tensor D1 = conv_backward(b, name + ".block1.proj", r.srcs, r.h1.g, H, W, true, nullptr, true);
         D = conv_backward(b, name + ".res_conv", r.srcs, dout, H, W, true, D1.p);
