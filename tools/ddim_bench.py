@@ -20,7 +20,8 @@ def main():
     cond = torch.rand(a.batch, 3, a.height, a.width, device=dev) * 2 - 1
     flow = torch.zeros(a.batch, 2, a.height, a.width, device=dev)
     with torch.no_grad():
-        fd.model.ddim_sample((2, 2, a.height, a.width), external_cond=cond[:2])            # warm-up (weights prepared)
+        # warm-up at the full batch: prepares the weights and allocates the workspace (a 96 GB hipMalloc takes seconds)
+        fd.unet(torch.randn(a.batch, 2, a.height, a.width, device=dev), external_cond=cond, time=torch.zeros(a.batch, dtype=torch.long, device=dev))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         samples, traj = fd.sample(cond, flow)
