@@ -35,6 +35,35 @@ __device__ __forceinline__ bf16x8 lc_frag(const float* f) {
 }
 
 constexpr int FC_CH = 96;             // forward pass 1 chunk (two 24 KB tiles + scan scratch within the 64 KB static LDS)
+// 32 channels of one head for this lane's pixel: accumulator register 4g+j holds channel 8g + 4*half + j.  One
+// v_permlane32_swap per dword pairs the half-waves so that every lane stores 16 bytes (8 consecutive channels):
+// half as many store instructions, 32 contiguous bytes per pixel and instruction.  All lanes must call it.
+__device__ __forceinline__ void lc_store_head(bf16_t* dst, const uint2 (&q)[4], int half, bool ok) {
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+        const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
+        if (ok) *(uint4*)(dst + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+    }
+}
+
+// inverse of lc_store_head: two 16-byte loads + permlane swaps give this lane its 16 accumulator-layout channels
+// (register 4g+j <-> channel 8g + 4*half + j) of a 32-channel head.  All lanes must call it (clamped address).
+__device__ __forceinline__ void lc_load_head(const bf16_t* src, int half, float (&f)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+        const uint4 v = *(const uint4*)(src + 8 * g + 8 * half);
+        const auto rx = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
+        const unsigned w4[4] = {rx[0], ry[0], rx[1], ry[1]};     // quad g: (x, y), quad g+1: (x, y)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[4 * g + 2 * j] = bf2f((bf16_t)(w4[j] & 0xffffu));
+            f[4 * g + 2 * j + 1] = bf2f((bf16_t)(w4[j] >> 16));
+        }
+    }
+}
+
 // ---- forward pass 1: partial {m[32], l[32], ctx[32][32]} per (sample*head, part); grid (nparts, B) ----
 // workgroup = 4 waves = 4 heads; online max over chunks of 96 pixels (accumulators rescaled per row d)
 __global__ void __launch_bounds__(256) lc_ctx_partial_kernel(const bf16_t* __restrict__ qkv, float* __restrict__ partial, int n, int span, int nparts) {
@@ -133,12 +162,14 @@ __global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5, b = blockIdx.y;
     lc_stage_matrix(ct, ctx + (size_t)b * 4096, true, tid);
     __syncthreads();
-    for (int p0 = (blockIdx.x * 4 + wave) * 32; p0 < n; p0 += gridDim.x * 128) {
+    // wave = head; the four waves of a workgroup share a 32-pixel tile (keeps a wave's register footprint -- and so the
+    // number of waves in flight to hide the load latency -- independent of the head count)
+    for (int p0 = blockIdx.x * 32; p0 < n; p0 += gridDim.x * 32) {
         const int p = min(p0 + l31, n - 1);
         const bf16_t* row = qkv + ((size_t)b * n + p) * 384;
         bf16_t* orow = out + ((size_t)b * n + p) * 128;
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
+        const int h = wave;
+        {
             float q[16];
             lc_unpack8(*(const u32x4*)(row + h * 32 + half * 8), &q[0]);
             lc_unpack8(*(const u32x4*)(row + h * 32 + 16 + half * 8), &q[8]);
@@ -158,10 +189,11 @@ __global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ 
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(ct, h, 0, l31, half), lc_frag(&q[0]), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(ct, h, 1, l31, half), lc_frag(&q[8]), acc, 0, 0, 0);
-            if (p0 + l31 < n) {
+            {
+                uint2 qo[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *(uint2*)(orow + h * 32 + 8 * g + 4 * half) = make_uint2(f2bf2(acc[4 * g], acc[4 * g + 1]), f2bf2(acc[4 * g + 2], acc[4 * g + 3]));
+                for (int g = 0; g < 4; ++g) qo[g] = make_uint2(f2bf2(acc[4 * g], acc[4 * g + 1]), f2bf2(acc[4 * g + 2], acc[4 * g + 3]));
+                lc_store_head(orow + h * 32, qo, half, p0 + l31 < n);
             }
         }
     }
@@ -245,14 +277,16 @@ __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restr
     }
     __syncthreads();
     const float inv_n = 1.0f / (float)n;
-    for (int p0 = (blockIdx.x * 4 + wave) * 32; p0 < n; p0 += gridDim.x * 128) {
+    // wave = head; the four waves of a workgroup share a 32-pixel tile (keeps a wave's register footprint -- and so the
+    // number of waves in flight to hide the load latency -- independent of the head count)
+    for (int p0 = blockIdx.x * 32; p0 < n; p0 += gridDim.x * 32) {
         const int p = min(p0 + l31, n - 1);
         const bool ok = p0 + l31 < n;
         const bf16_t* row = qkv + ((size_t)b * n + p) * 384;
         const bf16_t* grow = dout + ((size_t)b * n + p) * 128;
         bf16_t* drow = dqkv + ((size_t)b * n + p) * 384;
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
+        const int h = wave;
+        {
             f32x16 acc;
             // ---- dq
             const bf16x8 g0 = *(const bf16x8*)(grow + h * 32 + half * 8), g1 = *(const bf16x8*)(grow + h * 32 + 16 + half * 8);
@@ -262,12 +296,7 @@ __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restr
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(cA, h, 1, l31, half), g1, acc, 0, 0, 0);
             {
                 float q[16];      // accumulator layout: register 4g+j <-> d = 8g + 4*half + j
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint2 v = *(const uint2*)(row + h * 32 + 8 * g + 4 * half);
-                    q[4 * g] = bf2f((bf16_t)(v.x & 0xffffu)); q[4 * g + 1] = bf2f((bf16_t)(v.x >> 16));
-                    q[4 * g + 2] = bf2f((bf16_t)(v.y & 0xffffu)); q[4 * g + 3] = bf2f((bf16_t)(v.y >> 16));
-                }
+                lc_load_head(row + h * 32, half, q);
                 float mx = q[0];
 #pragma unroll
                 for (int j = 1; j < 16; ++j) mx = fmaxf(mx, q[j]);
@@ -281,13 +310,12 @@ __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { q[j] *= rs; acc[j] *= LC_SCALE; t += q[j] * acc[j]; }
                 t += __shfl_xor(t, 32, 64);
-                if (ok) {
+                uint2 qo[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *(uint2*)(drow + h * 32 + 8 * g + 4 * half) =
-                            make_uint2(f2bf2(q[4 * g] * (acc[4 * g] - t), q[4 * g + 1] * (acc[4 * g + 1] - t)),
+                for (int g = 0; g < 4; ++g)
+                    qo[g] = make_uint2(f2bf2(q[4 * g] * (acc[4 * g] - t), q[4 * g + 1] * (acc[4 * g + 1] - t)),
                                        f2bf2(q[4 * g + 2] * (acc[4 * g + 2] - t), q[4 * g + 3] * (acc[4 * g + 3] - t)));
-                }
+                lc_store_head(drow + h * 32, qo, half, ok);
             }
             // ---- dk
             const bf16x8 v0 = *(const bf16x8*)(row + 256 + h * 32 + half * 8), v1 = *(const bf16x8*)(row + 256 + h * 32 + 16 + half * 8);
@@ -295,17 +323,20 @@ __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restr
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dA, h, 0, l31, half), v0, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dA, h, 1, l31, half), v1, acc, 0, 0, 0);
-            if (ok) {
+            {
+                uint2 qo[4];
+                float kc[16];
+                lc_load_head(row + 128 + h * 32, half, kc);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int d0 = h * 32 + 8 * g + 4 * half;
-                    const uint2 kv = *(const uint2*)(row + 128 + d0);
                     const float4 m4 = *(const float4*)&Ms[d0], l4 = *(const float4*)&Li[d0], s4 = *(const float4*)&Ss[d0];
-                    const float k0 = __expf(bf2f((bf16_t)(kv.x & 0xffffu)) - m4.x) * l4.x, k1 = __expf(bf2f((bf16_t)(kv.x >> 16)) - m4.y) * l4.y;
-                    const float k2 = __expf(bf2f((bf16_t)(kv.y & 0xffffu)) - m4.z) * l4.z, k3 = __expf(bf2f((bf16_t)(kv.y >> 16)) - m4.w) * l4.w;
-                    *(uint2*)(drow + 128 + d0) = make_uint2(f2bf2(k0 * (acc[4 * g] * inv_n - s4.x), k1 * (acc[4 * g + 1] * inv_n - s4.y)),
-                                                            f2bf2(k2 * (acc[4 * g + 2] * inv_n - s4.z), k3 * (acc[4 * g + 3] * inv_n - s4.w)));
+                    const float k0 = __expf(kc[4 * g] - m4.x) * l4.x, k1 = __expf(kc[4 * g + 1] - m4.y) * l4.y;
+                    const float k2 = __expf(kc[4 * g + 2] - m4.z) * l4.z, k3 = __expf(kc[4 * g + 3] - m4.w) * l4.w;
+                    qo[g] = make_uint2(f2bf2(k0 * (acc[4 * g] * inv_n - s4.x), k1 * (acc[4 * g + 1] * inv_n - s4.y)),
+                                       f2bf2(k2 * (acc[4 * g + 2] * inv_n - s4.z), k3 * (acc[4 * g + 3] * inv_n - s4.w)));
                 }
+                lc_store_head(drow + 128 + h * 32, qo, half, ok);
             }
             // ---- dv
             float kk[16];
@@ -321,11 +352,12 @@ __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restr
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dT, h, 0, l31, half), lc_frag(&kk[0]), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dT, h, 1, l31, half), lc_frag(&kk[8]), acc, 0, 0, 0);
-            if (ok) {
+            {
+                uint2 qo[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *(uint2*)(drow + 256 + h * 32 + 8 * g + 4 * half) =
-                        make_uint2(f2bf2(acc[4 * g] * inv_n, acc[4 * g + 1] * inv_n), f2bf2(acc[4 * g + 2] * inv_n, acc[4 * g + 3] * inv_n));
+                    qo[g] = make_uint2(f2bf2(acc[4 * g] * inv_n, acc[4 * g + 1] * inv_n), f2bf2(acc[4 * g + 2] * inv_n, acc[4 * g + 3] * inv_n));
+                lc_store_head(drow + 256 + h * 32, qo, half, ok);
             }
         }
     }
@@ -368,8 +400,8 @@ int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_
     lc_parts(B, n, nparts, span);
     lc_ctx_partial_kernel<<<dim3(nparts, B), 256, 0, s>>>(qkv, partial, n, span, nparts);
     launch_la_ctx_combine(partial, ctx, B, nparts, 1.0f / (float)n, ml_out, s);
-    int gx = cdiv(n, 128);
-    if (gx > 1024) gx = 1024;
+    int gx = cdiv(n, 32);
+    if (gx > 2048) gx = 2048;
     lc_out_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, ctx, out, n);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
@@ -386,8 +418,8 @@ int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const flo
     float* S = dctx + (size_t)B * 4 * 1024;
     lc_dctx_partial_kernel<<<dim3(nparts, B), 256, 0, s>>>(qkv, dout, partial, n, span, nparts);
     lc_bwd_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, dctx, S, nparts);
-    int gx = cdiv(n, 128);
-    if (gx > 1024) gx = 1024;
+    int gx = cdiv(n, 32);
+    if (gx > 2048) gx = 2048;
     lc_bwd_apply_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, dout, ctx, dctx, ml, S, dqkv, n);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
