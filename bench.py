@@ -113,7 +113,8 @@ def main():
     ap.add_argument("--dump-launches", default=None, help="CSV path: one row per kernel launch of the timed region")
     ap.add_argument("--train-steps", type=int, default=3, help="timed training steps of the extra `train` object (0: skip)")
     ap.add_argument("--train-warmup", type=int, default=1)
-    ap.add_argument("--with-train", action="store_true", help="run the training leg for N > 1 too (default: N = 1 only)")
+    ap.add_argument("--with-train", action="store_true", help="(accepted for compatibility: the training leg runs for every N)")
+    ap.add_argument("--train-timeout", type=float, default=300.0, help="watchdog of the training leg, seconds")
     args = ap.parse_args()
 
     from opticalflowdiffusion_amd import parallel
@@ -122,6 +123,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if os.environ.get("OFD_FORCE_DEVICE") is not None:       # rehearsal: several ranks on one GPU (with OFD_DIST_BACKEND=gloo)
+        local_rank = int(os.environ["OFD_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -168,18 +171,9 @@ def main():
 
     elapsed = parallel.max_over_ranks(elapsed, dev)
 
-    train = None
-    if args.train_steps > 0 and (world == 1 or args.with_train):
-        del img, noises
-        unet._ws = None                      # hand the inference workspace back before the training one is sized
-        torch.cuda.empty_cache()
-        try:
-            train = train_leg(args, dev, rank, world, H, W)
-        except Exception as e:               # the headline metric must survive a failure of the extra leg
-            if world > 1:
-                raise
-            train = {"error": f"{type(e).__name__}: {e}"}
-
+    # ---- the JSON line is assembled BEFORE the extra training leg; a watchdog guarantees it is printed exactly once even
+    # if that leg hangs (e.g. a collective that never completes on some node): the headline metric must survive it
+    line = None
     if rank == 0:
         steps_per_s = parallel.whole_job_rate(args.steps, world, elapsed)
         line = {
@@ -210,11 +204,37 @@ def main():
             c3 = [prof[n] for n in ("conv_igemm_kernel<3,128>", "conv_igemm_kernel<3,64>", "conv3x3_c64_pingpong_kernel") if n in prof]
             line["conv3x3_all_tflops"] = sum(v["flops"] for v in c3) / (sum(v["ms"] for v in c3) * 1e-3) / 1e12
             line["kernel_ms_per_step"] = {n: v["ms"] / args.steps for n, v in prof.items()}
-        if train is not None:
-            line["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(H, W, B)
-        print(json.dumps(line), flush=True)
+
+    import threading
+    emitted, lock = threading.Event(), threading.Lock()
+
+    def emit(train, hard_exit):
+        with lock:
+            if not emitted.is_set():
+                emitted.set()
+                if rank == 0:
+                    if train is not None:
+                        line["train"] = train
+                    print(json.dumps(line), flush=True)
+        if hard_exit:
+            os._exit(0)
+
+    train = None
+    if args.train_steps > 0:
+        del img, noises
+        unet._ws = None                      # hand the inference workspace back before the training one is sized
+        torch.cuda.empty_cache()
+        dog = threading.Timer(args.train_timeout, emit, args=({"error": f"training leg did not finish within {args.train_timeout} s"}, True))
+        dog.daemon = True
+        dog.start()
+        try:
+            train = train_leg(args, dev, rank, world, H, W)
+        except Exception as e:
+            train = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
+    emit(train, False)
     if world > 1:
         dist.destroy_process_group()
 

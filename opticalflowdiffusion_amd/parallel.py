@@ -21,7 +21,9 @@ def init(backend=None, device=None):
     """init_process_group from the torchrun environment; no-op for a single process."""
     rank, local_rank, world = env_rank_world()
     if world > 1 and not dist.is_initialized():
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # OFD_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (gloo moves CUDA
+        # tensors through the host; RCCL refuses two ranks on one device)
+        backend = os.environ.get("OFD_DIST_BACKEND") or backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, **kw)
     return rank, local_rank, world
