@@ -25,7 +25,7 @@
 namespace ofd {
 
 struct SplatGeom {
-    int B, C, H, W, Ho, Wo, scale, ox, oy, radius, ntx, nty, dbg;
+    int B, C, H, W, Ho, Wo, scale, ox, oy, radius, ntx, nty;
 };
 
 constexpr int S_TH = 64, S_TW = 64, S_CG = 4, S_NT = 1024;
@@ -697,8 +697,7 @@ static int make_geom(SplatGeom& g, int B, int C, int H, int W, int scale, int ox
     OFD_CHECK_ARG(scale >= 1 && H / scale > 0 && W / scale > 0, "splat: bad scale %d for %dx%d", scale, H, W);
     OFD_CHECK_ARG(ox >= 0 && oy >= 0 && ox < scale && oy < scale, "splat: offset (%d,%d) must be in [0,scale)", ox, oy);
     OFD_CHECK_ARG((size_t)B * H * W < (1ull << 31), "splat: B*H*W must be < 2^31");
-    g = SplatGeom{B, C, H, W, H / scale, W / scale, scale, ox, oy, radius < 0 ? 0 : radius, 0, 0, 0};
-    { static int d = -1; if (d < 0) { const char* e = getenv("OFD_SPLAT_DBG"); d = e ? atoi(e) : 0; } g.dbg = d; }
+    g = SplatGeom{B, C, H, W, H / scale, W / scale, scale, ox, oy, radius < 0 ? 0 : radius, 0, 0};
     g.ntx = cdiv(g.Wo, S_TW);
     g.nty = cdiv(g.Ho, S_TH);
     return OFD_OK;
