@@ -302,20 +302,33 @@ __global__ void __launch_bounds__(256, 2) la_out_fused_kernel(const bf16_t* __re
             for (int r = 0; r < 16; ++r) { acc_o[rt][r] -= mean; q += acc_o[rt][r] * acc_o[rt][r]; }
         q += __shfl_xor(q, 32, 64);
         const float rstd = rsqrtf(q * (1.0f / C) + eps_post);
-        if (pix < n) {
-            bf16_t* yrow = y + ((size_t)b * n + pix) * C;
+        {
+            // 16-byte accesses: pairs of register quads are exchanged between the half-waves (v_permlane32_swap) so that a
+            // lane loads / stores 8 consecutive channels; every lane takes part, out-of-range pixels use a clamped row
+            const bool ok = pix < n;
+            bf16_t* yrow = y + ((size_t)b * n + min(pix, n - 1)) * C;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c0 = rt * 32 + 8 * g + 4 * half;
-                    const float4 gv = *(const float4*)(s_g2 + c0);
-                    const uint2 xr = *(const uint2*)(xrow + c0);
-                    const float o0 = acc_o[rt][4 * g] * rstd * gv.x + bf2f((bf16_t)(xr.x & 0xffffu));
-                    const float o1 = acc_o[rt][4 * g + 1] * rstd * gv.y + bf2f((bf16_t)(xr.x >> 16));
-                    const float o2 = acc_o[rt][4 * g + 2] * rstd * gv.z + bf2f((bf16_t)(xr.y & 0xffffu));
-                    const float o3 = acc_o[rt][4 * g + 3] * rstd * gv.w + bf2f((bf16_t)(xr.y >> 16));
-                    *(uint2*)(yrow + c0) = make_uint2(la_pack2(o0, o1), la_pack2(o2, o3));
+                for (int g = 0; g < 4; g += 2) {
+                    const uint4 xv = *(const uint4*)(xrow + rt * 32 + 8 * g + 8 * half);
+                    const auto sx = __builtin_amdgcn_permlane32_swap(xv.x, xv.z, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(xv.y, xv.w, false, false);
+                    const unsigned xq[2][2] = {{sx[0], sy[0]}, {sx[1], sy[1]}};      // residual of quad g, quad g+1
+                    uint2 qo[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int c0 = rt * 32 + 8 * (g + k) + 4 * half;
+                        const float4 gv = *(const float4*)(s_g2 + c0);
+                        const float o0 = acc_o[rt][4 * (g + k)] * rstd * gv.x + bf2f((bf16_t)(xq[k][0] & 0xffffu));
+                        const float o1 = acc_o[rt][4 * (g + k) + 1] * rstd * gv.y + bf2f((bf16_t)(xq[k][0] >> 16));
+                        const float o2 = acc_o[rt][4 * (g + k) + 2] * rstd * gv.z + bf2f((bf16_t)(xq[k][1] & 0xffffu));
+                        const float o3 = acc_o[rt][4 * (g + k) + 3] * rstd * gv.w + bf2f((bf16_t)(xq[k][1] >> 16));
+                        qo[k] = make_uint2(la_pack2(o0, o1), la_pack2(o2, o3));
+                    }
+                    const auto rx = __builtin_amdgcn_permlane32_swap(qo[0].x, qo[1].x, false, false);
+                    const auto ry = __builtin_amdgcn_permlane32_swap(qo[0].y, qo[1].y, false, false);
+                    if (ok) *(uint4*)(yrow + rt * 32 + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
                 }
         }
     }
