@@ -300,6 +300,29 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             const int o_stride = P.split > 0 ? (second ? P.Cout - P.split : P.split) : P.Cout;
             const int o_c0 = n0 + nt * 32 - (second ? P.split : 0);
             uint2 q[4];
+            // epilogue inputs as 16-byte loads: a lane reads channels 8g + 8*half .. +7 (g even) and one permlane32_swap per
+            // dword hands every lane the two register quads (8g + 4*half, 8(g+1) + 4*half) it accumulates
+            uint2 ra[4], rr[4];
+            if (P.res_act) {
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    const uint4 t4 = *(const uint4*)(P.res_act + pix * P.Cout + n0 + nt * 32 + 8 * g + 8 * half);
+                    const auto sx = __builtin_amdgcn_permlane32_swap(t4.x, t4.z, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(t4.y, t4.w, false, false);
+                    ra[g] = make_uint2(sx[0], sy[0]);
+                    ra[g + 1] = make_uint2(sx[1], sy[1]);
+                }
+            }
+            if (r_base) {
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    const uint4 t4 = *(const uint4*)(r_base + pix * o_stride + o_c0 + 8 * g + 8 * half);
+                    const auto sx = __builtin_amdgcn_permlane32_swap(t4.x, t4.z, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(t4.y, t4.w, false, false);
+                    rr[g] = make_uint2(sx[0], sy[0]);
+                    rr[g + 1] = make_uint2(sx[1], sy[1]);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = n0 + nt * 32 + 8 * g + 4 * half;
@@ -311,7 +334,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                 }
                 if (P.res_act) {
-                    const uint2 r = *(const uint2*)(P.res_act + pix * P.Cout + c);
+                    const uint2 r = ra[g];
                     const float4 sc = *(const float4*)(P.res_scale + (size_t)b * P.Cout + c);
                     const float4 sh = *(const float4*)(P.res_shift + (size_t)b * P.Cout + c);
                     v[0] += silu_f(bf2f((bf16_t)(r.x & 0xffffu)) * sc.x + sh.x);
@@ -320,7 +343,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
                     v[3] += silu_f(bf2f((bf16_t)(r.y >> 16)) * sc.w + sh.w);
                 }
                 if (r_base) {
-                    const uint2 r = *(const uint2*)(r_base + pix * o_stride + o_c0 + 8 * g + 4 * half);
+                    const uint2 r = rr[g];
                     v[0] += bf2f((bf16_t)(r.x & 0xffffu));
                     v[1] += bf2f((bf16_t)(r.x >> 16));
                     v[2] += bf2f((bf16_t)(r.y & 0xffffu));
