@@ -284,17 +284,18 @@ def test_flash_attention_backward(L, B, n):
         assert e < 2e-2, f"d{nm}: {e:.3e}"
 
 
-def test_unet_training_step_gradients(L):
+@pytest.mark.parametrize("B,H,W", [(2, 32, 48), (3, 24, 40)])
+def test_unet_training_step_gradients(L, B, H, W):
     """End to end: loss.backward() through the HIP training executor vs autograd on the oracle UNet
-    (bf16c contract) with the same parameters -- every one of the 276 parameter gradients."""
+    (bf16c contract) with the same parameters -- every one of the 276 parameter gradients.  The second shape has
+    partial pixel tiles at every level (40 = 32 + 8 columns, 24 / 12 / 6 / 3 rows)."""
     from opticalflowdiffusion_amd import Unet
     from opticalflowdiffusion_amd.warp import nan_mse
     torch.manual_seed(7)
-    B, H, W = 2, 32, 48
     net = Unet(64, channels=5, out_dim=2).cuda()
     x = torch.randn(B, 2, H, W)
     cond = torch.rand(B, 3, H, W) * 2 - 1
-    t = torch.tensor([17, 803])
+    t = torch.tensor([17, 803, 400][:B])
     target = torch.randn(B, 2, H, W)
     target[0, :, 3:5, 7:9] = float("nan")
     out = net(x.cuda(), external_cond=cond.cuda(), time=t.cuda())
