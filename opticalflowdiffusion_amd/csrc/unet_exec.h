@@ -1,7 +1,9 @@
 // Shared declarations of the UNet executor (unet.hip: registry + inference forward; unet_train.hip:
 // training forward tape + backward).  Host code only.
 #pragma once
+#include <array>
 #include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 #include "blocks.h"
@@ -106,6 +108,9 @@ struct ofd_unet {
     bool wt_prepared = false;
     std::vector<TapeRec> tape;
     TrainState ts;
+    // workspace plans of the training step, keyed by (B, H, W): {small, persist, scratch} bytes (a plan is a dry run of the
+    // whole forward + backward: worth caching, three of them per step showed up as host time at small resolutions)
+    std::map<std::tuple<int, int, int>, std::array<size_t, 3>> plans;
     // last forward: taps
     std::map<std::string, Tensor> taps;
     int last_B = 0;

@@ -314,6 +314,12 @@ static int run_backward(Ctx& c, const float* dout, const TrainLayout& L, float* 
 // size planning: a dry training forward + backward that allocates and counts but launches nothing
 static int plan(ofd_unet* u, int B, int H, int W, TrainLayout& L) {
     L = small_layout(u, B);
+    auto hit = u->plans.find(std::make_tuple(B, H, W));
+    if (hit != u->plans.end()) {
+        L.persist_b = hit->second[1];
+        L.scratch_b = hit->second[2];
+        return OFD_OK;
+    }
     Ctx c;
     c.u = u; c.s = nullptr; c.B = B; c.train = true; c.dry = true;
     c.persist = (char*)4096; c.persist_cap = (size_t)1 << 60;
@@ -332,6 +338,7 @@ static int plan(ofd_unet* u, int B, int H, int W, TrainLayout& L) {
         L.scratch_b = (c.scratch_high + 4095) / 4096 * 4096 + 4096;
     }
     u->tape = saved_tape; u->ts = saved_ts; u->taps = saved_taps; u->last_B = saved_B;
+    if (rc == OFD_OK) u->plans[std::make_tuple(B, H, W)] = {L.small_b, L.persist_b, L.scratch_b};
     return rc;
 }
 

@@ -63,12 +63,21 @@ class SyntheticFlowPairs(torch.utils.data.Dataset):
     def __len__(self):
         return self.length
 
-    def __getitem__(self, i):
+    def sample(self, i, device="cpu"):
+        """sample i generated ON `device` (deterministic per (seed, index, device type): the CPU and GPU generators differ)."""
         if not 0 <= i < self.length:
             raise IndexError(i)
-        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        g = torch.Generator(device=device).manual_seed(self.seed * 1000003 + i)
         box = lambda t, k: torch.nn.functional.avg_pool2d(t[None], k, 1, k // 2)[0]
-        img = box(torch.rand(3, self.h, self.w, generator=g), 5)
+        img = box(torch.rand(3, self.h, self.w, generator=g, device=device), 5)
         img = (img - img.amin()) / (img.amax() - img.amin() + 1e-8)
-        flow = box(torch.randn(2, self.h, self.w, generator=g) * self.sigma * 9.0, 9).clamp(-self.fmax, self.fmax)
+        flow = box(torch.randn(2, self.h, self.w, generator=g, device=device) * self.sigma * 9.0, 9).clamp(-self.fmax, self.fmax)
         return img, img.clone(), flow
+
+    def __getitem__(self, i):
+        return self.sample(i, "cpu")
+
+    def batch(self, first, count, device):
+        """`count` consecutive samples (wrapping around) stacked on `device` -- the input pipeline of train.py: generating on
+        the GPU keeps the host out of the step (the CPU box filters cost 50 ms per sample)."""
+        return tuple(torch.stack(x) for x in zip(*(self.sample((first + k) % self.length, device) for k in range(count))))

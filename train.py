@@ -114,8 +114,8 @@ def main(argv=None):
         opt.zero_grad()
         for micro in range(accum):
             base = ((step * accum + micro) * world + rank) * B            # disjoint samples per rank and step
-            batch = [torch.stack(x).to(dev) for x in zip(*(ds[(base + i) % len(ds)] for i in range(B)))]
-            loss = fd.training_step(tuple(batch), step)
+            batch = ds.batch(base, B, dev)
+            loss = fd.training_step(batch, step)
             (loss / accum).backward()
         opt.step()
         step += 1
