@@ -148,6 +148,11 @@ int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float* cond, int
                      float* out, int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 /* debug: copy a named intermediate of the LAST forward (e.g. "init_conv", "downs.0.0",
  * "mid_attn") as NCHW fp32 into dst (numel checked).  Returns OFD_ERR_ARG for unknown names. */
+/* hipGraph replay of ofd_unet_forward (launch-bound regimes: small images, the 1000-step sampling loop).  When enabled,
+ * the inputs are copied to fixed staging buffers inside the workspace, the first call of a (workspace, shape, stream)
+ * configuration runs eagerly, the second is captured into a graph and every later one is a single hipGraphLaunch.
+ * Bit-identical results.  Ignored while profiling is on (per-kernel events need individual launches). */
+int ofd_unet_set_graph(ofd_unet* u, int enabled);
 int ofd_unet_read_tap(ofd_unet* u, const char* name, float* dst, size_t numel, void* stream);
 /* per-kernel-class device time of forwards run with profiling enabled (HIP events on the
  * stream the kernels are launched on).  classes: see ofd_unet_prof_name(). */

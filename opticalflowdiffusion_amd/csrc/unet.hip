@@ -441,6 +441,8 @@ size_t small_bytes(const ofd_unet* u, int B) {
 
 }  // namespace ofd
 
+static void drop_graphs(ofd_unet* u);
+
 static void upload_mlp_descs(ofd_unet* u) {
     std::vector<MlpDesc> descs;
     for (auto& name : u->resblocks) {
@@ -459,6 +461,7 @@ extern "C" int ofd_unet_bind_param_buffer(ofd_unet* u, float* dev_params, size_t
     OFD_CHECK_ARG(floats >= u->n_param_floats, "unet_bind_param_buffer: %zu floats, need %zu", floats, u->n_param_floats);
     OFD_CHECK_ARG(((uintptr_t)dev_params & 15) == 0, "unet_bind_param_buffer: buffer must be 16-byte aligned");
     if (u->owns_params && u->d_params) hipFree(u->d_params);
+    drop_graphs(u);
     u->d_params = dev_params;
     u->owns_params = false;
     for (auto& p : u->params) p.set = true;          // the caller's buffer holds every parameter
@@ -498,6 +501,7 @@ extern "C" void ofd_unet_destroy(ofd_unet* u) {
     if (u->d_mlp) hipFree(u->d_mlp);
     if (u->d_labuf) hipFree(u->d_labuf);
     if (u->d_wtbuf) hipFree(u->d_wtbuf);
+    drop_graphs(u);
     for (auto e : u->pool) hipEventDestroy(e);
     delete u;
 }
@@ -555,9 +559,30 @@ extern "C" int ofd_unet_prepare(ofd_unet* u, void* stream) {
     return OFD_OK;
 }
 
+static size_t staging_bytes(const ofd_unet* u, int B, int H, int W) {
+    // fixed homes of x | cond (together cfg.channels planes), t, out for graph replay
+    auto al = [](size_t n) { return (n + 255) / 256 * 256; };
+    return al((size_t)B * u->cfg.channels * H * W * 4) + al((size_t)B * 8) + al((size_t)B * u->cfg.out_dim * H * W * 4);
+}
+
 extern "C" size_t ofd_unet_workspace_bytes(const ofd_unet* u, int B, int H, int W) {
     if (!u || B <= 0 || H <= 0 || W <= 0) return 0;
-    return persist_bytes(u, B, H, W) + scratch_bytes(u, B, H, W) + small_bytes(u, B) + 1024;
+    return persist_bytes(u, B, H, W) + scratch_bytes(u, B, H, W) + small_bytes(u, B) + 1024 + staging_bytes(u, B, H, W);
+}
+
+static void drop_graphs(ofd_unet* u) {
+    for (auto& g : u->graphs) {
+        if (g.state == 2) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
+    }
+    u->graphs.clear();
+    if (u->cap_stream) { hipStreamDestroy(u->cap_stream); u->cap_stream = nullptr; }
+}
+
+extern "C" int ofd_unet_set_graph(ofd_unet* u, int enabled) {
+    OFD_CHECK_ARG(u, "unet_set_graph: null handle");
+    u->graph_enabled = enabled != 0;
+    if (!u->graph_enabled) drop_graphs(u);
+    return OFD_OK;
 }
 
 extern "C" int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float* cond, int Cc, const int64_t* t, float* out,
@@ -582,8 +607,55 @@ extern "C" int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float
     c.persist = w + sb;
     c.persist_cap = persist_bytes(u, B, H, W);
     c.scratch = c.persist + (c.persist_cap + 255) / 256 * 256;
-    c.scratch_cap = workspace_bytes - (size_t)(c.scratch - w);
-    return run_forward(c, x, Cx, cond, Cc, t, out, H, W, temb, temb_silu);
+    const size_t stg = staging_bytes(u, B, H, W);
+    c.scratch_cap = workspace_bytes - stg - (size_t)(c.scratch - w);
+    if (!u->graph_enabled || u->profiling) return run_forward(c, x, Cx, cond, Cc, t, out, H, W, temb, temb_silu);
+
+    // ---- graph replay: stage the inputs at fixed addresses, (capture once and) launch the whole forward as ONE graph
+    auto al = [](size_t n) { return (n + 255) / 256 * 256; };
+    char* sbase = w + workspace_bytes - stg;
+    sbase = (char*)(((uintptr_t)sbase) & ~(uintptr_t)255);
+    const size_t plane = (size_t)H * W * 4;
+    float* sx = (float*)sbase;                                    // x planes then cond planes, per sample as given
+    float* sc = sx + (size_t)B * Cx * H * W;
+    int64_t* st = (int64_t*)(sbase + al((size_t)B * u->cfg.channels * plane));
+    float* sout = (float*)((char*)st + al((size_t)B * 8));
+    hipStream_t s_ = (hipStream_t)stream;
+    OFD_HIP(hipMemcpyAsync(sx, x, (size_t)B * Cx * plane, hipMemcpyDeviceToDevice, s_));
+    if (cond) OFD_HIP(hipMemcpyAsync(sc, cond, (size_t)B * Cc * plane, hipMemcpyDeviceToDevice, s_));
+    OFD_HIP(hipMemcpyAsync(st, t, (size_t)B * 8, hipMemcpyDeviceToDevice, s_));
+    ofd_unet::GraphEntry* e = nullptr;
+    for (auto& g : u->graphs)
+        if (g.workspace == workspace && g.B == B && g.H == H && g.W == W && g.Cx == Cx && g.Cc == (cond ? Cc : 0) && g.stream == s_) e = &g;
+    int rc = OFD_OK;
+    if (!e) {
+        // first call for this configuration: run eagerly (also performs the one-time function-attribute calls that are
+        // not allowed during capture); the next call captures
+        if (u->graphs.size() >= 8) drop_graphs(u);
+        u->graphs.push_back({workspace, B, H, W, Cx, cond ? Cc : 0, s_, 0, nullptr, nullptr});
+        rc = run_forward(c, sx, Cx, cond ? sc : nullptr, Cc, st, sout, H, W, temb, temb_silu);
+    } else {
+        if (e->state == 0) {
+            if (!u->cap_stream) OFD_HIP(hipStreamCreateWithFlags(&u->cap_stream, hipStreamNonBlocking));
+            OFD_HIP(hipStreamBeginCapture(u->cap_stream, hipStreamCaptureModeThreadLocal));
+            c.s = u->cap_stream;                         // every launch of the forward lands in the capture
+            rc = run_forward(c, sx, Cx, cond ? sc : nullptr, Cc, st, sout, H, W, temb, temb_silu);
+            hipGraph_t g = nullptr;
+            const hipError_t er = hipStreamEndCapture(u->cap_stream, &g);
+            if (rc != OFD_OK || er != hipSuccess || !g) {
+                if (g) hipGraphDestroy(g);
+                if (rc == OFD_OK) { set_error("unet_forward: stream capture failed: %s", hipGetErrorString(er)); rc = OFD_ERR_HIP; }
+                return rc;
+            }
+            hipGraphExec_t ex = nullptr;
+            OFD_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+            e->graph = g; e->exec = ex; e->state = 2;
+        }
+        OFD_HIP(hipGraphLaunch(e->exec, s_));
+    }
+    if (rc != OFD_OK) return rc;
+    OFD_HIP(hipMemcpyAsync(out, sout, (size_t)B * u->cfg.out_dim * plane, hipMemcpyDeviceToDevice, s_));
+    return OFD_OK;
 }
 
 extern "C" int ofd_unet_read_tap(ofd_unet* u, const char* name, float* dst, size_t numel, void* stream) {

@@ -108,6 +108,16 @@ struct ofd_unet {
     bool wt_prepared = false;
     std::vector<TapeRec> tape;
     TrainState ts;
+    // hipGraph replay of the inference forward (ofd_unet_set_graph): one instantiated graph per (workspace, shape, stream);
+    // inputs / output go through fixed staging buffers at the end of the workspace so every kernel argument is static
+    struct GraphEntry {
+        void* workspace; int B, H, W, Cx, Cc; hipStream_t stream;
+        int state;                         // 0: seen once (eager run done), 2: instantiated
+        hipGraph_t graph; hipGraphExec_t exec;
+    };
+    bool graph_enabled = false;
+    hipStream_t cap_stream = nullptr;   // private stream the forward is captured on (the caller's may be the un-capturable null stream)
+    std::vector<GraphEntry> graphs;
     // workspace plans of the training step, keyed by (B, H, W): {small, persist, scratch} bytes (a plan is a dry run of the
     // whole forward + backward: worth caching, three of them per step showed up as host time at small resolutions)
     std::map<std::tuple<int, int, int>, std::array<size_t, 3>> plans;

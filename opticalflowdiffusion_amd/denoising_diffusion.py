@@ -275,6 +275,11 @@ class Unet(nn.Module):
         L.check(L.lib().ofd_unet_read_tap(self._handle, name.encode(), L.ptr(out), out.numel(), L.stream()))
         return out
 
+    def set_graph(self, enabled=True):
+        """replay the inference forward as one hipGraph per (shape, stream) instead of ~250 launches (launch-bound
+        regimes: small images, long sampling loops); bit-identical, ignored while profiling"""
+        L.check(L.lib().ofd_unet_set_graph(self._handle, int(enabled)))
+
     # -- per-kernel-class device timing (HIP events on the launch stream) ----------------------
     def set_profiling(self, enabled, dump_path=None):
         L.check(L.lib().ofd_unet_set_profiling(self._handle, int(enabled)))

@@ -289,3 +289,35 @@ def test_gradient_accumulation_and_zero_grad_in_place():
     backward()
     for p, g in zip(net.parameters(), g1):
         assert torch.allclose(p.grad, g, rtol=1e-5, atol=1e-8)
+
+
+def test_graph_replay_is_bit_identical_and_survives_weight_updates():
+    """ofd_unet_set_graph: eager call, captured call and replays give the same bits; new weights (same buffers,
+    re-prepared) are picked up by the existing graph; another shape gets its own graph."""
+    from opticalflowdiffusion_amd import Unet
+    torch.manual_seed(0)
+    net = Unet(64, channels=5, out_dim=2).cuda()
+    x, c, t = torch.randn(2, 2, 32, 48, device="cuda"), torch.randn(2, 3, 32, 48, device="cuda"), torch.tensor([3, 900], device="cuda")
+    with torch.no_grad():
+        ref = net(x, external_cond=c, time=t).clone()
+        net.set_graph(True)
+        outs = [net(x.clone(), external_cond=c.clone(), time=t.clone()).clone() for _ in range(4)]     # eager, capture, replay, replay
+        assert all(torch.equal(o, ref) for o in outs)
+        x2 = torch.randn_like(x)
+        assert torch.equal(net(x2, external_cond=c, time=t), _eager(net, x2, c, t))
+        for p in net.parameters():                       # an optimizer-style in-place update
+            p.mul_(1.01)
+        got = net(x, external_cond=c, time=t).clone()
+        assert not torch.equal(got, ref) and torch.equal(got, _eager(net, x, c, t))
+        xb = torch.randn(1, 2, 16, 16, device="cuda")
+        cb, tb = torch.randn(1, 3, 16, 16, device="cuda"), torch.tensor([5], device="cuda")
+        o1 = [net(xb, external_cond=cb, time=tb).clone() for _ in range(3)]
+        assert torch.equal(o1[0], o1[2]) and torch.equal(o1[0], _eager(net, xb, cb, tb))
+        net.set_graph(False)
+
+
+def _eager(net, x, c, t):
+    net.set_graph(False)
+    out = net(x, external_cond=c, time=t).clone()
+    net.set_graph(True)
+    return out
