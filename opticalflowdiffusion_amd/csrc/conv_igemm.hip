@@ -41,7 +41,11 @@ struct Cfg {
     static constexpr int US = (NPIX + 1) * 16;
     static constexpr int X_BYTES = NC * US;
     static constexpr int W_BYTES = SC8 * BN * 16;
-    static constexpr int LDS_BYTES = X_BYTES + 2 * W_BYTES;
+    // epilogue: every wave transposes its 64 pixels x BN channels through LDS so that the global stores are fully
+    // coalesced (pixel pitch BN*2 + 16 bytes keeps the 16-byte LDS writes conflict-free)
+    static constexpr int OPITCH = BN * 2 + 16;
+    static constexpr int O_BYTES = 4 * 64 * OPITCH;
+    static constexpr int LDS_BYTES = (X_BYTES + 2 * W_BYTES > O_BYTES) ? X_BYTES + 2 * W_BYTES : O_BYTES;
     static constexpr int XPT = (NPIX * NC + NTHREADS - 1) / NTHREADS;  // 16-B units per thread
     static constexpr int WPT = (SC8 * BN + NTHREADS - 1) / NTHREADS;
     static constexpr int NTN = BN / 32;
@@ -279,6 +283,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
     }
 
     // ---- epilogue: bias, residual forms, bf16 store, GroupNorm partial sums ---------------------
+    // Stores: a wave's accumulators give 32 contiguous bytes per pixel and instruction, a pattern that writes HBM at
+    // 2.9 TB/s (tools/probe/store_pattern_probe.hip); transposed through a private LDS region (64 pixels x BN channels per
+    // wave) consecutive lanes write consecutive 16-byte units of a pixel row: 5.3 - 5.7 TB/s.
+    __syncthreads();                                   // every wave is done with the operand buffers the regions overlap
+    unsigned char* const oreg = smem + wave * 64 * C::OPITCH;
     constexpr int NV = (BN / 8) * 2;
     float stat[NV];
 #pragma unroll
@@ -363,11 +372,30 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             for (int g = 0; g < 4; g += 2) {
                 const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
                 const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
-                if (ok) *(uint4*)(o_base + opix * o_stride + o_c0 + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                *(uint4*)(oreg + (pt * 32 + l31) * C::OPITCH + (nt * 32 + 8 * g + 8 * half) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
             }
         }
     }
 
+    {
+        // copy-out of this wave's region: unit u of pixel p -> lane; UPR consecutive lanes cover one pixel row
+        constexpr int UPR = BN / 8;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the wave's own LDS writes (in order per wave)
+#pragma unroll
+        for (int k = 0; k < UPR; ++k) {
+            const int id = lane + k * 64, pl = id / UPR, cu = id % UPR;       // pl: 0..63 = (row pt, column x)
+            const int oy = oy0 + wave * 2 + (pl >> 5), ox = ox0 + (pl & 31);
+            const bool ok = oy < P.H && ox < P.W && !(dbg & 16);
+            const size_t pix = ((size_t)b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1);
+            const size_t opix = (KS == 2) ? ((size_t)b * (2 * P.H) + 2 * min(oy, P.H - 1) + P.out_oy) * (2 * P.W) + 2 * min(ox, P.W - 1) + P.out_ox : pix;
+            const int c0 = n0 + cu * 8;
+            const bool second = P.split > 0 && c0 >= P.split;
+            bf16_t* const o_base = second ? P.out2 : P.out;
+            const int o_stride = P.split > 0 ? (second ? P.Cout - P.split : P.split) : P.Cout;
+            const uint4 v = *(const uint4*)(oreg + pl * C::OPITCH + cu * 16);
+            if (ok) *(uint4*)(o_base + opix * o_stride + c0 - (second ? P.split : 0)) = v;
+        }
+    }
     if (P.gn_partial) {   // per-wave partial sums: [b][tile][wave][Cout/8][2]; gn_finalize adds them up
         wave_reduce_multi<NV>(stat);
         constexpr int SH_ = (NV == 32) ? 1 : 2;    // lane l holds value index l >> SH_
