@@ -157,44 +157,59 @@ __device__ __forceinline__ bf16x8 lc_afrag(const unsigned char* lds, int h, int 
 }
 
 // ---- forward pass 2: out[n][e] = sum_d ctx[d][e] * softmax_d(q)[n][d] * scale; grid (gx, B) -----------------
+// All global traffic of the per-pixel passes goes through an LDS tile of 32 pixels: whole pixel rows are fetched with the
+// direct global->LDS path (one 1 KB / 256 B instruction per pixel row, no staging registers) and results leave as
+// consecutive 16-byte units of consecutive pixels.  Reading operand fragments straight from global memory (32 bytes per
+// pixel and instruction) ran at ~2.8 TB/s; a padded row pitch keeps the lane-per-pixel LDS reads conflict-free.
+constexpr int LO_PITCH = 256 + 16;        // q part of a pixel row (128 channels) + pad
 __global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ ctx, bf16_t* __restrict__ out, int n) {
     __shared__ __attribute__((aligned(16))) unsigned char ct[4 * 32 * 80];      // ctx^T: rows e, k = d
+    __shared__ __attribute__((aligned(16))) unsigned char st[32 * LO_PITCH];    // q rows in, out rows out
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5, b = blockIdx.y;
     lc_stage_matrix(ct, ctx + (size_t)b * 4096, true, tid);
-    __syncthreads();
-    // wave = head; the four waves of a workgroup share a 32-pixel tile (keeps a wave's register footprint -- and so the
-    // number of waves in flight to hide the load latency -- independent of the head count)
+    const int h = wave;                    // wave = head; the four waves of a workgroup share a 32-pixel tile
     for (int p0 = blockIdx.x * 32; p0 < n; p0 += gridDim.x * 32) {
-        const int p = min(p0 + l31, n - 1);
-        const bf16_t* row = qkv + ((size_t)b * n + p) * 384;
-        bf16_t* orow = out + ((size_t)b * n + p) * 128;
-        const int h = wave;
-        {
-            float q[16];
-            lc_unpack8(*(const u32x4*)(row + h * 32 + half * 8), &q[0]);
-            lc_unpack8(*(const u32x4*)(row + h * 32 + 16 + half * 8), &q[8]);
-            float mx = q[0];
+        __syncthreads();                   // previous tile's copy-out is done (and, first time, ct is staged)
+        {   // 32 pixels x 16 units of q: 512 units, two per thread, consecutive lanes = consecutive units of a pixel row
 #pragma unroll
-            for (int j = 1; j < 16; ++j) mx = fmaxf(mx, q[j]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float sum = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { q[j] = __expf(q[j] - mx); sum += q[j]; }
-            sum += __shfl_xor(sum, 32, 64);
-            const float k = LC_SCALE * __builtin_amdgcn_rcpf(sum);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) q[j] *= k;
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(ct, h, 0, l31, half), lc_frag(&q[0]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(ct, h, 1, l31, half), lc_frag(&q[8]), acc, 0, 0, 0);
-            {
-                uint2 qo[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) qo[g] = make_uint2(f2bf2(acc[4 * g], acc[4 * g + 1]), f2bf2(acc[4 * g + 2], acc[4 * g + 3]));
-                lc_store_head(orow + h * 32, qo, half, p0 + l31 < n);
+            for (int k = 0; k < 2; ++k) {
+                const int id = tid + k * 256, px = id >> 4, u = id & 15;
+                const int p = min(p0 + px, n - 1);
+                *(u32x4*)(st + px * LO_PITCH + u * 16) = *(const u32x4*)(qkv + ((size_t)b * n + p) * 384 + u * 8);
             }
+        }
+        __syncthreads();
+        const unsigned char* row = st + l31 * LO_PITCH;
+        float q[16];
+        lc_unpack8(*(const u32x4*)(row + (h * 32 + half * 8) * 2), &q[0]);
+        lc_unpack8(*(const u32x4*)(row + (h * 32 + 16 + half * 8) * 2), &q[8]);
+        float mx = q[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) mx = fmaxf(mx, q[j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { q[j] = __expf(q[j] - mx); sum += q[j]; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float k = LC_SCALE * __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) q[j] *= k;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(ct, h, 0, l31, half), lc_frag(&q[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(ct, h, 1, l31, half), lc_frag(&q[8]), acc, 0, 0, 0);
+        {   // results over this wave's own q slice of the tile (nobody else reads or writes those 64 bytes per pixel)
+            uint2 qo[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) qo[g] = make_uint2(f2bf2(acc[4 * g], acc[4 * g + 1]), f2bf2(acc[4 * g + 2], acc[4 * g + 3]));
+            lc_store_head((bf16_t*)(st + l31 * LO_PITCH) + h * 32, qo, half, true);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int id = tid + k * 256, px = id >> 4, u = id & 15;
+            if (p0 + px < n) *(u32x4*)(out + ((size_t)b * n + p0 + px) * 128 + u * 8) = *(const u32x4*)(st + px * LO_PITCH + u * 16);
         }
     }
 }
@@ -261,11 +276,19 @@ __global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __re
 //   dq_raw = sm(q) * (dq - <sm(q), dq>), dq = scale * ctx . dout          (MFMA rows d, A = ctx)
 //   dk_raw = k * (dctx . v / n - S),    k = exp(k_raw - M) / L            (MFMA rows d, A = dctx)
 //   dv     = dctx^T . k / n                                               (MFMA rows e, A = dctx^T)
+constexpr int LB_PITCH = 1024 + 16;       // qkv row (768 B) | dout row (256 B) | pad
+constexpr int LB_LDS = 3 * 4 * 32 * 80 + 3 * 128 * 4 + 32 * LB_PITCH;
 __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ ctx,
                                                            const float* __restrict__ dctx, const float* __restrict__ ml, const float* __restrict__ S,
                                                            bf16_t* __restrict__ dqkv, int n) {
-    __shared__ __attribute__((aligned(16))) unsigned char cA[4 * 32 * 80], dA[4 * 32 * 80], dT[4 * 32 * 80];
-    __shared__ __attribute__((aligned(16))) float Ms[128], Li[128], Ss[128];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
+    unsigned char* cA = lb_smem;
+    unsigned char* dA = cA + 4 * 32 * 80;
+    unsigned char* dT = dA + 4 * 32 * 80;
+    float* Ms = (float*)(dT + 4 * 32 * 80);
+    float* Li = Ms + 128;
+    float* Ss = Li + 128;
+    unsigned char* st = (unsigned char*)(Ss + 128);    // [32 pixels][qkv 768 B | dout 256 B | pad]; dqkv overwrites qkv in place
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5, b = blockIdx.y;
     lc_stage_matrix(cA, ctx + (size_t)b * 4096, false, tid);
     lc_stage_matrix(dA, dctx + (size_t)b * 4096, false, tid);
@@ -275,90 +298,90 @@ __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restr
         Li[tid] = ml[((size_t)b * 4 + (tid >> 5)) * 64 + 32 + (tid & 31)];
         Ss[tid] = S[((size_t)b * 4 + (tid >> 5)) * 32 + (tid & 31)];
     }
-    __syncthreads();
     const float inv_n = 1.0f / (float)n;
-    // wave = head; the four waves of a workgroup share a 32-pixel tile (keeps a wave's register footprint -- and so the
-    // number of waves in flight to hide the load latency -- independent of the head count)
+    const int h = wave;                    // wave = head; the four waves of a workgroup share a 32-pixel tile
     for (int p0 = blockIdx.x * 32; p0 < n; p0 += gridDim.x * 32) {
-        const int p = min(p0 + l31, n - 1);
-        const bool ok = p0 + l31 < n;
-        const bf16_t* row = qkv + ((size_t)b * n + p) * 384;
-        const bf16_t* grow = dout + ((size_t)b * n + p) * 128;
-        bf16_t* drow = dqkv + ((size_t)b * n + p) * 384;
-        const int h = wave;
+        __syncthreads();                   // previous tile's copy-out is done (and, first time, the matrices are staged)
+        // one direct global->LDS instruction per pixel row: lanes 0..47 fetch the qkv row, lanes 48..63 the dout row
+        for (int px = wave; px < 32; px += 4) {
+            const size_t p = (size_t)b * n + min(p0 + px, n - 1);
+            const bf16_t* src = lane < 48 ? qkv + p * 384 + lane * 8 : dout + p * 128 + (lane - 48) * 8;
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(st + px * LB_PITCH), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned char* row = st + l31 * LB_PITCH;
+        // everything this wave needs of its head, before any of it is overwritten
+        const bf16x8 g0 = *(const bf16x8*)(row + 768 + (h * 32 + half * 8) * 2), g1 = *(const bf16x8*)(row + 768 + (h * 32 + 16 + half * 8) * 2);
+        const bf16x8 v0 = *(const bf16x8*)(row + 512 + (h * 32 + half * 8) * 2), v1 = *(const bf16x8*)(row + 512 + (h * 32 + 16 + half * 8) * 2);
+        float q[16], kc[16], kk[16];
+        lc_load_head((const bf16_t*)row + h * 32, half, q);               // accumulator layout
+        lc_load_head((const bf16_t*)row + 128 + h * 32, half, kc);
+        lc_unpack8(*(const u32x4*)(row + 256 + (h * 32 + half * 8) * 2), &kk[0]);      // operand layout
+        lc_unpack8(*(const u32x4*)(row + 256 + (h * 32 + 16 + half * 8) * 2), &kk[8]);
+        f32x16 acc;
+        uint2 qo[4];
+        // ---- dq
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(cA, h, 0, l31, half), g0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(cA, h, 1, l31, half), g1, acc, 0, 0, 0);
         {
-            f32x16 acc;
-            // ---- dq
-            const bf16x8 g0 = *(const bf16x8*)(grow + h * 32 + half * 8), g1 = *(const bf16x8*)(grow + h * 32 + 16 + half * 8);
+            float mx = q[0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(cA, h, 0, l31, half), g0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(cA, h, 1, l31, half), g1, acc, 0, 0, 0);
-            {
-                float q[16];      // accumulator layout: register 4g+j <-> d = 8g + 4*half + j
-                lc_load_head(row + h * 32, half, q);
-                float mx = q[0];
+            for (int j = 1; j < 16; ++j) mx = fmaxf(mx, q[j]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.0f;
 #pragma unroll
-                for (int j = 1; j < 16; ++j) mx = fmaxf(mx, q[j]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                float sum = 0.0f;
+            for (int j = 0; j < 16; ++j) { q[j] = __expf(q[j] - mx); sum += q[j]; }
+            sum += __shfl_xor(sum, 32, 64);
+            const float rs = __builtin_amdgcn_rcpf(sum);
+            float t = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { q[j] = __expf(q[j] - mx); sum += q[j]; }
-                sum += __shfl_xor(sum, 32, 64);
-                const float rs = __builtin_amdgcn_rcpf(sum);
-                float t = 0.0f;
+            for (int j = 0; j < 16; ++j) { q[j] *= rs; acc[j] *= LC_SCALE; t += q[j] * acc[j]; }
+            t += __shfl_xor(t, 32, 64);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { q[j] *= rs; acc[j] *= LC_SCALE; t += q[j] * acc[j]; }
-                t += __shfl_xor(t, 32, 64);
-                uint2 qo[4];
+            for (int g = 0; g < 4; ++g)
+                qo[g] = make_uint2(f2bf2(q[4 * g] * (acc[4 * g] - t), q[4 * g + 1] * (acc[4 * g + 1] - t)),
+                                   f2bf2(q[4 * g + 2] * (acc[4 * g + 2] - t), q[4 * g + 3] * (acc[4 * g + 3] - t)));
+            lc_store_head((bf16_t*)row + h * 32, qo, half, true);
+        }
+        // ---- dk
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    qo[g] = make_uint2(f2bf2(q[4 * g] * (acc[4 * g] - t), q[4 * g + 1] * (acc[4 * g + 1] - t)),
-                                       f2bf2(q[4 * g + 2] * (acc[4 * g + 2] - t), q[4 * g + 3] * (acc[4 * g + 3] - t)));
-                lc_store_head(drow + h * 32, qo, half, ok);
-            }
-            // ---- dk
-            const bf16x8 v0 = *(const bf16x8*)(row + 256 + h * 32 + half * 8), v1 = *(const bf16x8*)(row + 256 + h * 32 + 16 + half * 8);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dA, h, 0, l31, half), v0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dA, h, 1, l31, half), v1, acc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dA, h, 0, l31, half), v0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dA, h, 1, l31, half), v1, acc, 0, 0, 0);
-            {
-                uint2 qo[4];
-                float kc[16];
-                lc_load_head(row + 128 + h * 32, half, kc);
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = h * 32 + 8 * g + 4 * half;
+            const float4 m4 = *(const float4*)&Ms[d0], l4 = *(const float4*)&Li[d0], s4 = *(const float4*)&Ss[d0];
+            const float k0 = __expf(kc[4 * g] - m4.x) * l4.x, k1 = __expf(kc[4 * g + 1] - m4.y) * l4.y;
+            const float k2 = __expf(kc[4 * g + 2] - m4.z) * l4.z, k3 = __expf(kc[4 * g + 3] - m4.w) * l4.w;
+            qo[g] = make_uint2(f2bf2(k0 * (acc[4 * g] * inv_n - s4.x), k1 * (acc[4 * g + 1] * inv_n - s4.y)),
+                               f2bf2(k2 * (acc[4 * g + 2] * inv_n - s4.z), k3 * (acc[4 * g + 3] * inv_n - s4.w)));
+        }
+        lc_store_head((bf16_t*)row + 128 + h * 32, qo, half, true);
+        // ---- dv
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d0 = h * 32 + 8 * g + 4 * half;
-                    const float4 m4 = *(const float4*)&Ms[d0], l4 = *(const float4*)&Li[d0], s4 = *(const float4*)&Ss[d0];
-                    const float k0 = __expf(kc[4 * g] - m4.x) * l4.x, k1 = __expf(kc[4 * g + 1] - m4.y) * l4.y;
-                    const float k2 = __expf(kc[4 * g + 2] - m4.z) * l4.z, k3 = __expf(kc[4 * g + 3] - m4.w) * l4.w;
-                    qo[g] = make_uint2(f2bf2(k0 * (acc[4 * g] * inv_n - s4.x), k1 * (acc[4 * g + 1] * inv_n - s4.y)),
-                                       f2bf2(k2 * (acc[4 * g + 2] * inv_n - s4.z), k3 * (acc[4 * g + 3] * inv_n - s4.w)));
-                }
-                lc_store_head(drow + 128 + h * 32, qo, half, ok);
-            }
-            // ---- dv
-            float kk[16];
-            lc_unpack8(*(const u32x4*)(row + 128 + h * 32 + half * 8), &kk[0]);
-            lc_unpack8(*(const u32x4*)(row + 128 + h * 32 + 16 + half * 8), &kk[8]);
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int d0 = h * 32 + 16 * s2 + 8 * half;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int d0 = h * 32 + 16 * s + 8 * half;
+            for (int j = 0; j < 8; ++j) kk[8 * s2 + j] = __expf(kk[8 * s2 + j] - Ms[d0 + j]) * Li[d0 + j];
+        }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) kk[8 * s + j] = __expf(kk[8 * s + j] - Ms[d0 + j]) * Li[d0 + j];
-            }
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dT, h, 0, l31, half), lc_frag(&kk[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dT, h, 1, l31, half), lc_frag(&kk[8]), acc, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dT, h, 0, l31, half), lc_frag(&kk[0]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lc_afrag(dT, h, 1, l31, half), lc_frag(&kk[8]), acc, 0, 0, 0);
-            {
-                uint2 qo[4];
+        for (int g = 0; g < 4; ++g)
+            qo[g] = make_uint2(f2bf2(acc[4 * g] * inv_n, acc[4 * g + 1] * inv_n), f2bf2(acc[4 * g + 2] * inv_n, acc[4 * g + 3] * inv_n));
+        lc_store_head((bf16_t*)row + 256 + h * 32, qo, half, true);
+        __syncthreads();
+        // copy-out: 32 pixels x 48 units of dqkv, consecutive lanes = consecutive 16-byte units (pixel rows are contiguous)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    qo[g] = make_uint2(f2bf2(acc[4 * g] * inv_n, acc[4 * g + 1] * inv_n), f2bf2(acc[4 * g + 2] * inv_n, acc[4 * g + 3] * inv_n));
-                lc_store_head(drow + 256 + h * 32, qo, half, ok);
-            }
+        for (int k = 0; k < 6; ++k) {
+            const int id = tid + k * 256, px = id / 48, u = id - px * 48;
+            if (p0 + px < n) *(u32x4*)(dqkv + ((size_t)b * n + p0 + px) * 384 + u * 8) = *(const u32x4*)(st + px * LB_PITCH + u * 16);
         }
     }
 }
@@ -420,7 +443,9 @@ int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const flo
     lc_bwd_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, dctx, S, nparts);
     int gx = cdiv(n, 32);
     if (gx > 2048) gx = 2048;
-    lc_bwd_apply_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, dout, ctx, dctx, ml, S, dqkv, n);
+    static bool attr = false;
+    if (!attr) { OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS)); attr = true; }
+    lc_bwd_apply_kernel<<<dim3(gx, B), 256, LB_LDS, s>>>(qkv, dout, ctx, dctx, ml, S, dqkv, n);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
