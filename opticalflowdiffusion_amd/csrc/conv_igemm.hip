@@ -45,7 +45,7 @@ struct Cfg {
     // coalesced (pixel pitch BN*2 + 16 bytes keeps the 16-byte LDS writes conflict-free)
     static constexpr int OPITCH = BN * 2 + 16;
     static constexpr int O_BYTES = 4 * 64 * OPITCH;
-    static constexpr int LDS_BYTES = (X_BYTES + 2 * W_BYTES > O_BYTES) ? X_BYTES + 2 * W_BYTES : O_BYTES;
+    static constexpr int LDS_BYTES = (KS != 1 || X_BYTES + 2 * W_BYTES > O_BYTES) ? X_BYTES + 2 * W_BYTES : O_BYTES;
     static constexpr int XPT = (NPIX * NC + NTHREADS - 1) / NTHREADS;  // 16-B units per thread
     static constexpr int WPT = (SC8 * BN + NTHREADS - 1) / NTHREADS;
     static constexpr int NTN = BN / 32;
@@ -286,7 +286,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
     // Stores: a wave's accumulators give 32 contiguous bytes per pixel and instruction, a pattern that writes HBM at
     // 2.9 TB/s (tools/probe/store_pattern_probe.hip); transposed through a private LDS region (64 pixels x BN channels per
     // wave) consecutive lanes write consecutive 16-byte units of a pixel row: 5.3 - 5.7 TB/s.
-    __syncthreads();                                   // every wave is done with the operand buffers the regions overlap
+    // Measured on one box (A/B): the 1x1 convs gain 4.5 % (64->384: 2.0 -> 1.6 ms), the MFMA-bound 3x3 / 7x7 kernels lose
+    // 0.5 - 1 % to the extra LDS pass, so only the 1x1 instantiations take this path.
+    constexpr bool XPOSE = (KS == 1);
+    if (XPOSE) __syncthreads();                        // every wave is done with the operand buffers the regions overlap
     unsigned char* const oreg = smem + wave * 64 * C::OPITCH;
     constexpr int NV = (BN / 8) * 2;
     float stat[NV];
@@ -372,12 +375,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             for (int g = 0; g < 4; g += 2) {
                 const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
                 const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
-                *(uint4*)(oreg + (pt * 32 + l31) * C::OPITCH + (nt * 32 + 8 * g + 8 * half) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                if (!XPOSE) { if (ok) *(uint4*)(o_base + opix * o_stride + o_c0 + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]); }
+                else *(uint4*)(oreg + (pt * 32 + l31) * C::OPITCH + (nt * 32 + 8 * g + 8 * half) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
             }
         }
     }
 
-    {
+    if (XPOSE) {
         // copy-out of this wave's region: unit u of pixel p -> lane; UPR consecutive lanes cover one pixel row
         constexpr int UPR = BN / 8;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the wave's own LDS writes (in order per wave)
