@@ -452,13 +452,22 @@ struct PPX {
     unsigned okmask;
 };
 
+// staging map: wave w of a group owns the 85 tile pixels [85 w, 85 w + 85) (8 pixels x 8 channel octets per instruction, 11
+// instructions; the surplus 3 re-write the last pixel).  Owning a CONTIGUOUS range is what lets the epilogue borrow exactly
+// the bytes this same wave overwrites next (pp_epilogue).
+constexpr int PP_PPW = 85;
+__device__ __forceinline__ int pp_pixel(int gt, int i) {
+    const int wv = gt >> 6, lane = gt & 63;
+    return wv * PP_PPW + min((lane >> 3) + i * 8, PP_PPW - 1);
+}
+
 __device__ __forceinline__ void pp_load_x(PPX& xr, const ConvParams& P, const PPTile& T, int gt) {
     const int c8 = gt & 7;
     const bf16_t* base = P.src[0].ptr + (size_t)T.b * P.H * P.W * P.src[0].src_channels + P.src[0].ch_offset + c8 * 8;
     unsigned ok_all = 0;
 #pragma unroll
     for (int i = 0; i < 11; ++i) {
-        const int p = min((gt >> 3) + i * 32, 339);
+        const int p = pp_pixel(gt, i);
         const int ty = p / 34, tx = p - ty * 34;
         const int iy = T.oy0 - 1 + ty, ix = T.ox0 - 1 + tx;
         const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
@@ -481,7 +490,7 @@ __device__ __forceinline__ void pp_write_x(const PPX& xr, const ConvParams& P, c
     }
 #pragma unroll
     for (int i = 0; i < 11; ++i) {
-        const int p = min((gt >> 3) + i * 32, 339);
+        const int p = pp_pixel(gt, i);
         u32x4 v = xr.v[i];
         if (P.in_scale) {
 #pragma unroll
@@ -536,16 +545,23 @@ __device__ __forceinline__ void pp_mfma(f32x16 (&acc)[2][2], const unsigned char
 // v_permlane32_swap per dword between quads g and g+1 gives the lower half-wave 8 consecutive
 // channels of quad g and the upper half-wave those of quad g+1 -> half as many store instructions
 // (the 8-byte form is store-issue bound).
-__device__ __forceinline__ void pp_epilogue(const f32x16 (&acc)[2][2], const ConvParams& P, const PPTile& T, const float* s_bias, int wv, int lane) {
+__device__ __forceinline__ void pp_epilogue(const f32x16 (&acc)[2][2], const ConvParams& P, const PPTile& T, const float* s_bias, int wv, int lane,
+                                            unsigned char* xbuf) {
     const int l31 = lane & 31, half = lane >> 5;
     float stat[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) stat[i] = 0.0f;
+    // The stores go through LDS so that they leave fully coalesced (a lane-per-pixel store pattern writes at 2.9 TB/s, consecutive
+    // 16-byte units of a pixel row at 5.3+, tools/probe/store_pattern_probe.hip).  The group's input buffer is dead during its
+    // VALU phase, but there is no group-level barrier: every wave therefore borrows only the bytes IT stages next (its 85-pixel
+    // slice of each of the 8 octet rows, 1360 B each): region row r (144 B: 64 channels + pad) lives in octet row r / 9.
+    unsigned char* const reg0 = xbuf + wv * PP_PPW * 16;
+    auto region = [&](int r) { return reg0 + (r / 9) * PP_US + (r % 9) * 144; };
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
         const int oy = T.oy0 + wv * 2 + pt, ox = T.ox0 + l31;
         const bool ok = oy < P.H && ox < P.W;
-        const size_t pix = ((size_t)T.b * P.H + oy) * P.W + ox;
+        unsigned char* const rrow = region(pt * 32 + l31);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             uint2 q[4];
@@ -565,9 +581,17 @@ __device__ __forceinline__ void pp_epilogue(const f32x16 (&acc)[2][2], const Con
             for (int g = 0; g < 4; g += 2) {
                 const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
                 const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
-                if (ok) *(uint4*)(P.out + pix * 64 + nt * 32 + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                *(uint4*)(rrow + (nt * 32 + 8 * g + 8 * half) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
             }
         }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's own LDS writes
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                              // 64 pixels x 8 units: 8 lanes per pixel row, 8 pixels per instruction
+        const int id = lane + k * 64, pl = id >> 3, cu = id & 7;
+        const int oy = T.oy0 + wv * 2 + (pl >> 5), ox = T.ox0 + (pl & 31);
+        const uint4 v = *(const uint4*)(region(pl) + cu * 16);
+        if (oy < P.H && ox < P.W) *(uint4*)(P.out + (((size_t)T.b * P.H + oy) * P.W + ox) * 64 + cu * 8) = v;
     }
     if (P.gn_partial) {
         wave_reduce_multi<16>(stat);
@@ -619,12 +643,12 @@ __global__ void __launch_bounds__(PP_THREADS, 1) conv3x3_c64_pingpong_kernel(con
             if (!(P.dbg & 1)) pp_load_x(xr, P, nxt, gt);
             if (!(P.dbg & 4)) pp_mfma(acc, lds_w, xbuf, wv, l31, half);
         } else if (i > 0) {
-            if (prev.valid && !(P.dbg & 16)) pp_epilogue(acc, P, prev, s_bias, wv, lane);
+            if (prev.valid && !(P.dbg & 16)) pp_epilogue(acc, P, prev, s_bias, wv, lane, xbuf);
             if (!(P.dbg & 32)) pp_write_x(xr, P, cur, xbuf, gt);
         }
         pp_barrier();
         if (group == 0) {
-            if (cur.valid && !(P.dbg & 16)) pp_epilogue(acc, P, cur, s_bias, wv, lane);
+            if (cur.valid && !(P.dbg & 16)) pp_epilogue(acc, P, cur, s_bias, wv, lane, xbuf);
             if (!(P.dbg & 32)) pp_write_x(xr, P, nxt, xbuf, gt);
         } else {
             if (!(P.dbg & 1)) pp_load_x(xr, P, nxt, gt);
@@ -634,7 +658,7 @@ __global__ void __launch_bounds__(PP_THREADS, 1) conv3x3_c64_pingpong_kernel(con
         prev = cur;
         cur = nxt;
     }
-    if (group == 1 && n_iter > 0 && prev.valid) pp_epilogue(acc, P, prev, s_bias, wv, lane);
+    if (group == 1 && n_iter > 0 && prev.valid) pp_epilogue(acc, P, prev, s_bias, wv, lane, xbuf);
 }
 
 // ================================================================================================
