@@ -537,12 +537,20 @@ __global__ void __launch_bounds__(GT_THREADS) grid_warp_tile_kernel(const float*
         f0 = *(const float4*)(flow + (size_t)n * 2 * plane + pix);
         f1 = *(const float4*)(flow + (size_t)n * 2 * plane + plane + pix);
     };
-    int t = blockIdx.x;
-    if (t >= ntiles) return;
+    // XCD-aware order: in every round of gridDim.x tiles the workgroups of one XCD (blockIdx % 8) take a contiguous run (two
+    // tile rows at W = 1024), so the halos neighbouring windows share are served by that XCD's L2 instead of being fetched
+    // once per XCD.
+    auto tile_of = [&](int l) {
+        const int g = gridDim.x, k = l / g, b = l - k * g;
+        return ((g & 7) == 0 && (k + 1) * g <= ntiles) ? k * g + (b & 7) * (g >> 3) + (b >> 3) : l;
+    };
+    int l = blockIdx.x;
+    if (l >= ntiles) return;
+    int t = tile_of(l);
     float4 f0, f1;
     flow_of(t, f0, f1);
     issue(t, 0, min(C, 3));
-    while (t < ntiles) {
+    while (l < ntiles) {
         const int n = t / tpi, t_in = t - n * tpi;
         const int ox0 = (t_in % tiles_x) * GT_W, oy0 = (t_in / tiles_x) * GT_H, wx0 = ox0 - GT_RX, wy0 = oy0 - GT_RY;
         const int y = oy0 + (tid >> 4), x4 = ox0 + (tid & 15) * 4;
@@ -550,9 +558,13 @@ __global__ void __launch_bounds__(GT_THREADS) grid_warp_tile_kernel(const float*
         const int yc = min(y, H - 1), xc4 = min(x4, W - 4);
         const size_t pix = (size_t)yc * W + xc4;
         const float fl0[4] = {f0.x, f0.y, f0.z, f0.w}, fl1[4] = {f1.x, f1.y, f1.z, f1.w};
-        float w[4][4], m[4];
+        float w[4][4], m[4], wx[4][2], wy[4][2];
         unsigned inb[4], inw[4];
-        int li[4], gi[4];
+        int li[4], gi[4], x0s[4], y0s[4];
+        // `inner`: every corner of the thread's four pixels is inside the image AND inside the staged window -- the case of all
+        // waves away from the image border.  Then every in-bounds bit is set and the mask is 1 (the four weights sum to 1 within
+        // a few ulp, far above the 0.999 threshold of WP:116), so the per-corner bookkeeping below is skipped altogether.
+        bool inner = true;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float ix, iy;
@@ -560,29 +572,43 @@ __global__ void __launch_bounds__(GT_THREADS) grid_warp_tile_kernel(const float*
             const float fx0 = floorf(ix), fy0 = floorf(iy);
             const bool finite = fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
             const int x0 = finite ? (int)fx0 : -10, y0 = finite ? (int)fy0 : -10;
-            const float wx0_ = fx0 + 1.0f - ix, wx1 = ix - fx0, wy0_ = fy0 + 1.0f - iy, wy1 = iy - fy0;
-            const bool bx0 = x0 >= 0 && x0 < W, bx1 = x0 + 1 >= 0 && x0 + 1 < W, by0 = y0 >= 0 && y0 < H, by1 = y0 + 1 >= 0 && y0 + 1 < H;
-            w[j][0] = wx0_ * wy0_;
-            w[j][1] = wx1 * wy0_;
-            w[j][2] = wx0_ * wy1;
-            w[j][3] = wx1 * wy1;
-            inb[j] = (bx0 && by0 ? 1u : 0u) | (bx1 && by0 ? 2u : 0u) | (bx0 && by1 ? 4u : 0u) | (bx1 && by1 ? 8u : 0u);
-            float ms = 0.0f;                                   // sum of in-bounds weights = grid_sample(ones)
-            if (bx0 && by0) ms += wx0_ * wy0_;
-            if (bx1 && by0) ms += wx1 * wy0_;
-            if (bx0 && by1) ms += wx0_ * wy1;
-            if (bx1 && by1) ms += wx1 * wy1;
-            if (ms < 0.999f) ms = 0.0f;                        // WP:116-117
-            if (ms > 0.0f) ms = 1.0f;
-            m[j] = ms;
+            wx[j][0] = fx0 + 1.0f - ix; wx[j][1] = ix - fx0; wy[j][0] = fy0 + 1.0f - iy; wy[j][1] = iy - fy0;
+            w[j][0] = wx[j][0] * wy[j][0];
+            w[j][1] = wx[j][1] * wy[j][0];
+            w[j][2] = wx[j][0] * wy[j][1];
+            w[j][3] = wx[j][1] * wy[j][1];
             const int lx = x0 - wx0, ly = y0 - wy0;            // window coordinates of the north-west corner
-            const bool wxa = lx >= 0 && lx < GT_WW, wxb = lx + 1 >= 0 && lx + 1 < GT_WW, wya = ly >= 0 && ly < GT_WH, wyb = ly + 1 >= 0 && ly + 1 < GT_WH;
-            inw[j] = (wxa && wya ? 1u : 0u) | (wxb && wya ? 2u : 0u) | (wxa && wyb ? 4u : 0u) | (wxb && wyb ? 8u : 0u);
             li[j] = ly * GT_WW + lx;
             gi[j] = y0 * W + x0;
+            x0s[j] = x0; y0s[j] = y0;
+            inner = inner && (unsigned)x0 < (unsigned)(W - 1) && (unsigned)y0 < (unsigned)(H - 1) && (unsigned)lx < (unsigned)(GT_WW - 1) &&
+                    (unsigned)ly < (unsigned)(GT_WH - 1);
+        }
+        if (!inner) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x0 = x0s[j], y0 = y0s[j];
+                const float wx0_ = wx[j][0], wx1 = wx[j][1], wy0_ = wy[j][0], wy1 = wy[j][1];
+                const bool bx0 = x0 >= 0 && x0 < W, bx1 = x0 + 1 >= 0 && x0 + 1 < W, by0 = y0 >= 0 && y0 < H, by1 = y0 + 1 >= 0 && y0 + 1 < H;
+                inb[j] = (bx0 && by0 ? 1u : 0u) | (bx1 && by0 ? 2u : 0u) | (bx0 && by1 ? 4u : 0u) | (bx1 && by1 ? 8u : 0u);
+                float ms = 0.0f;                                   // sum of in-bounds weights = grid_sample(ones)
+                if (bx0 && by0) ms += wx0_ * wy0_;
+                if (bx1 && by0) ms += wx1 * wy0_;
+                if (bx0 && by1) ms += wx0_ * wy1;
+                if (bx1 && by1) ms += wx1 * wy1;
+                if (ms < 0.999f) ms = 0.0f;                        // WP:116-117
+                if (ms > 0.0f) ms = 1.0f;
+                m[j] = ms;
+                const int lx = x0 - wx0, ly = y0 - wy0;
+                const bool wxa = lx >= 0 && lx < GT_WW, wxb = lx + 1 >= 0 && lx + 1 < GT_WW, wya = ly >= 0 && ly < GT_WH, wyb = ly + 1 >= 0 && ly + 1 < GT_WH;
+                inw[j] = (wxa && wya ? 1u : 0u) | (wxb && wya ? 2u : 0u) | (wxa && wyb ? 4u : 0u) | (wxb && wyb ? 8u : 0u);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { inb[j] = 15u; inw[j] = 15u; m[j] = 1.0f; }
         }
         const bool all_in_window = (inw[0] & inw[1] & inw[2] & inw[3]) == 15u;
-        const int tn = t + gridDim.x;
+        const int ln = l + gridDim.x, tn = ln < ntiles ? tile_of(ln) : ntiles;
         for (int c0 = 0; c0 < C; c0 += 3) {
             const int cg = min(C - c0, 3);
             if (c0 > 0) {
@@ -597,8 +623,18 @@ __global__ void __launch_bounds__(GT_THREADS) grid_warp_tile_kernel(const float*
                 const float* sp = second + ((size_t)n * C + c) * plane;
                 const float* wc = win + cc * GT_CH;
                 float o[4];
-                if (all_in_window) {
-                    // common case: the four corners of all four pixels are staged -> branch-free, paired LDS reads
+                if (inner) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float c0v = wc[li[j]], c1v = wc[li[j] + 1], c2v = wc[li[j] + GT_WW], c3v = wc[li[j] + GT_WW + 1];
+                        float acc = c0v * w[j][0];
+                        acc += c1v * w[j][1];
+                        acc += c2v * w[j][2];
+                        acc += c3v * w[j][3];
+                        o[j] = acc;
+                    }
+                } else if (all_in_window) {
+                    // the four corners of all four pixels are staged -> paired LDS reads, in-bounds bits gate the sum
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float c0v = wc[li[j]], c1v = wc[li[j] + 1], c2v = wc[li[j] + GT_WW], c3v = wc[li[j] + GT_WW + 1];
@@ -642,6 +678,7 @@ __global__ void __launch_bounds__(GT_THREADS) grid_warp_tile_kernel(const float*
         __syncthreads();                                       // LDS is free again
         if (tn < ntiles) issue(tn, 0, min(C, 3));
         t = tn;
+        l = ln;
     }
 }
 
