@@ -157,6 +157,26 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.0f;
 
+    // 1x1 with the ResnetBlock output fused in (res_act): the activation tile the epilogue adds is independent of the K loop, so
+    // its loads are issued here and land while the input tiles stream (a workgroup is otherwise a serial chain of three
+    // memory round trips: X chunk 0, X chunk 1, res_act).  Only the 64-channel instantiation has the registers.
+    constexpr bool PRE = (KS == 1 && BN == 64);
+    uint4 pre_ra[PRE ? 2 : 1][PRE ? C::NTN : 1][2];
+    if constexpr (PRE) {
+        if (P.res_act) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int oy = oy0 + wave * 2 + pt, ox = ox0 + l31;
+                const size_t pix = ((size_t)b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1);
+#pragma unroll
+                for (int nt = 0; nt < C::NTN; ++nt)
+#pragma unroll
+                    for (int gi = 0; gi < 2; ++gi)
+                        pre_ra[pt][nt][gi] = *(const uint4*)(P.res_act + pix * P.Cout + n0 + nt * 32 + 16 * gi + 8 * half);
+            }
+        }
+    }
+
     // Weight pipeline: slab g = kc*STAGES + st lives in registers for two stages before it is written
     // to its LDS buffer (g & 1): the global load of slab g+2 is issued at the top of stage g and
     // consumed at the end of stage g+1, so ~2 stages of MFMA work cover the L2 latency.  The
@@ -318,7 +338,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             if (P.res_act) {
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
-                    const uint4 t4 = *(const uint4*)(P.res_act + pix * P.Cout + n0 + nt * 32 + 8 * g + 8 * half);
+                    uint4 t4;
+                    if constexpr (PRE) t4 = pre_ra[pt][nt][g >> 1];
+                    else t4 = *(const uint4*)(P.res_act + pix * P.Cout + n0 + nt * 32 + 8 * g + 8 * half);
                     const auto sx = __builtin_amdgcn_permlane32_swap(t4.x, t4.z, false, false);
                     const auto sy = __builtin_amdgcn_permlane32_swap(t4.y, t4.w, false, false);
                     ra[g] = make_uint2(sx[0], sy[0]);
