@@ -13,7 +13,7 @@
  *   softsplat_new.py:489-565          cuda_launch("softsplat_ingrad")   -> ofd_splat_bwd_in
  *   softsplat_new.py:600-700          cuda_launch("softsplat_flowgrad") -> ofd_splat_bwd_flow
  *   warp.py:121-156   warp_forward_flow (NaN handling + holes)          -> ofd_warp_prep / ofd_warp_holes
- *   warp.py:95-119    warp_backward_flow (2x F.grid_sample + mask)      -> ofd_grid_warp_fwd
+ *   warp.py:95-119    warp_backward_flow (2x F.grid_sample + mask)      -> ofd_grid_warp_fwd, ofd_grid_warp_bwd
  *   denoising_diffusion.py:363-417    Unet.forward                      -> ofd_unet_forward
  *   denoising_diffusion.py:666-698    p_mean_variance + p_sample update -> ofd_ddpm_update
  *   denoising_diffusion.py:750-767    ddim_sample update                -> ofd_ddim_update
@@ -74,6 +74,14 @@ int ofd_warp_holes(const float* splat, float* img, int B, int C, int Ho, int Wo,
  * out, mask: (B,C,H,W); mask may be NULL.  bilinear, zeros padding, align_corners=True. */
 int ofd_grid_warp_fwd(const float* second, const float* flow, float* out, float* mask,
                       int B, int C, int H, int W, void* stream);
+/* Backward of the call above (what autograd derives for WP:95-119; the thresholded mask has no gradient).
+ * grad_second (B,C,H,W): bilinear scatter of grad_out to the forward's four corners (the splat kernel on grid_sample's
+ *   coordinates; needs a workspace of ofd_splat_workspace_bytes(B,H,W); radius as in ofd_splat_fwd, >= the largest |flow|
+ *   keeps the far-corner list empty).  NULL: skipped.
+ * grad_flow (B,2,H,W): ATen's grid gradient chained through the reference's normalisation (its (W-1)/2 and 2/(W-1) factors
+ *   are applied in the reference's order); channel 1 receives d/dx.  NULL: skipped (second may then be NULL). */
+int ofd_grid_warp_bwd(const float* second, const float* flow, const float* grad_out, float* grad_second, float* grad_flow,
+                      int B, int C, int H, int W, int radius, void* workspace, size_t workspace_bytes, void* stream);
 /* integer north-west corner (ix_nw, iy_nw) per pixel, int32 (B,H,W,2): index parity tests. */
 int ofd_grid_warp_corners(const float* flow, int32_t* corners, int B, int H, int W, void* stream);
 

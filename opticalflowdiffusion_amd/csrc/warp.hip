@@ -26,20 +26,36 @@ namespace ofd {
 
 struct SplatGeom {
     int B, C, H, W, Ho, Wo, scale, ox, oy, radius, ntx, nty;
+    int grid;     // 1: targets are grid_sample's un-normalised coordinates (adjoint of warp_backward_flow), scale 1
 };
 
 constexpr int S_TH = 64, S_TW = 64, S_CG = 4, S_NT = 1024;
 constexpr int SKIPPED = -(1 << 30);
+
+// ---- grid_sample backward warp (WP:95-119): exact op order of the reference expression -------
+__device__ __forceinline__ void grid_coords(float flow_c0, float flow_c1, int x, int y, int H, int W, float& ix, float& iy) {
+    // flow.flip(1): channel 1 displaces x, channel 0 displaces y (WP:105-106)
+    const float gx = (float)x + flow_c1;
+    const float gy = (float)y + flow_c0;
+    const float vx = 2.0f * gx / (float)max(W - 1, 1) - 1.0f;       // WP:108
+    const float vy = 2.0f * gy / (float)max(H - 1, 1) - 1.0f;       // WP:109
+    ix = ((vx + 1.0f) / 2.0f) * (float)(W - 1);                       // ATen align_corners un-normalise
+    iy = ((vy + 1.0f) / 2.0f) * (float)(H - 1);
+}
 
 // variant 0: forward (SS:374-390), 1: ingrad (SS:515-533), 2: flowgrad (SS:628-647).
 // Same float/double mix as the reference source: the bare 1.0 literals are double.
 template <int VARIANT>
 __device__ __forceinline__ bool splat_remap(float flow_x, float flow_y, int x, int y, const SplatGeom& g,
                                             float& fx, float& fy, float& dxx, float& dyy) {
-    float fltX = (float)x + flow_x;
-    float fltY = (float)y + flow_y;
     dxx = 0.0f;
     dyy = 0.0f;
+    if (VARIANT == 0 && g.grid) {      // (flow_x, flow_y) are channels (0, 1) of the flow: grid_coords applies the reference's flip
+        grid_coords(flow_x, flow_y, x, y, g.H, g.W, fx, fy);
+        return fabsf(fx) < 1.0e9f && fabsf(fy) < 1.0e9f;       // the forward kernels' rule: otherwise no corner is in bounds
+    }
+    float fltX = (float)x + flow_x;
+    float fltY = (float)y + flow_y;
     if (!isfinite(fltX) || !isfinite(fltY)) return false;
     const bool guard = (VARIANT == 0) ? (g.scale > 1) : true;
     const float fW = (float)g.W, fH = (float)g.H, fs = (float)g.scale, fox = (float)g.ox, foy = (float)g.oy;
@@ -403,17 +419,6 @@ __global__ void __launch_bounds__(256) warp_holes_kernel(const float* __restrict
     }
 }
 
-// ---- grid_sample backward warp (WP:95-119): exact op order of the reference expression -------
-__device__ __forceinline__ void grid_coords(float flow_c0, float flow_c1, int x, int y, int H, int W, float& ix, float& iy) {
-    // flow.flip(1): channel 1 displaces x, channel 0 displaces y (WP:105-106)
-    const float gx = (float)x + flow_c1;
-    const float gy = (float)y + flow_c0;
-    const float vx = 2.0f * gx / (float)max(W - 1, 1) - 1.0f;       // WP:108
-    const float vy = 2.0f * gy / (float)max(H - 1, 1) - 1.0f;       // WP:109
-    ix = ((vx + 1.0f) / 2.0f) * (float)(W - 1);                       // ATen align_corners un-normalise
-    iy = ((vy + 1.0f) / 2.0f) * (float)(H - 1);
-}
-
 // One thread = 4 consecutive output pixels: flow and outputs move as 16-byte accesses, and the two
 // corners of a row are ONE 8-byte (4-byte aligned) gather, so 6 gathers per pixel instead of 12.
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -682,6 +687,38 @@ __global__ void __launch_bounds__(GT_THREADS) grid_warp_tile_kernel(const float*
     }
 }
 
+// Gradient of warp_backward_flow's output with respect to the flow (ATen grid_sampler_2d_backward's grid gradient chained
+// through the reference's normalisation WP:108-109; the thresholded mask has no gradient).  A gather: one thread per pixel.
+__global__ void __launch_bounds__(256) grid_warp_flowgrad_kernel(const float* __restrict__ second, const float* __restrict__ flow,
+                                                                 const float* __restrict__ gout, float* __restrict__ gflow, int B, int C, int H, int W) {
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    const float mx = (float)(W - 1) / 2.0f, my = (float)(H - 1) / 2.0f;          // align_corners un-normalise multipliers
+    const float dx = (float)max(W - 1, 1), dy = (float)max(H - 1, 1);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / plane, pix = i % plane;
+        const int y = (int)(pix / W), x = (int)(pix % W);
+        float ix, iy;
+        grid_coords(flow[n * 2 * plane + pix], flow[n * 2 * plane + plane + pix], x, y, H, W, ix, iy);
+        float gix = 0.0f, giy = 0.0f;
+        if (fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f) {
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            const int x0 = (int)fx0, y0 = (int)fy0;
+            const bool bx0 = x0 >= 0 && x0 < W, bx1 = x0 + 1 >= 0 && x0 + 1 < W, by0 = y0 >= 0 && y0 < H, by1 = y0 + 1 >= 0 && y0 + 1 < H;
+            const float ex = fx0 + 1.0f - ix, wx = ix - fx0, ey = fy0 + 1.0f - iy, wy = iy - fy0;
+            for (int c = 0; c < C; ++c) {
+                const float* sp = second + (n * C + c) * plane;
+                const float go = gout[(n * C + c) * plane + pix];
+                if (bx0 && by0) { const float v = sp[(size_t)y0 * W + x0];           gix -= v * ey * go; giy -= v * ex * go; }
+                if (bx1 && by0) { const float v = sp[(size_t)y0 * W + x0 + 1];       gix += v * ey * go; giy -= v * wx * go; }
+                if (bx0 && by1) { const float v = sp[(size_t)(y0 + 1) * W + x0];     gix -= v * wy * go; giy += v * ex * go; }
+                if (bx1 && by1) { const float v = sp[(size_t)(y0 + 1) * W + x0 + 1]; gix += v * wy * go; giy += v * wx * go; }
+            }
+        }
+        gflow[n * 2 * plane + plane + pix] = (mx * gix) / dx * 2.0f;      // channel 1 displaces x (the flip of WP:105)
+        gflow[n * 2 * plane + pix] = (my * giy) / dy * 2.0f;
+    }
+}
+
 // scalar fallback (W % 4 != 0 or W < 2)
 __global__ void __launch_bounds__(256) grid_warp_scalar_kernel(const float* __restrict__ second, const float* __restrict__ flow,
                                                                float* __restrict__ out, float* __restrict__ mask, int B, int C, int H, int W) {
@@ -734,7 +771,7 @@ static int make_geom(SplatGeom& g, int B, int C, int H, int W, int scale, int ox
     OFD_CHECK_ARG(scale >= 1 && H / scale > 0 && W / scale > 0, "splat: bad scale %d for %dx%d", scale, H, W);
     OFD_CHECK_ARG(ox >= 0 && oy >= 0 && ox < scale && oy < scale, "splat: offset (%d,%d) must be in [0,scale)", ox, oy);
     OFD_CHECK_ARG((size_t)B * H * W < (1ull << 31), "splat: B*H*W must be < 2^31");
-    g = SplatGeom{B, C, H, W, H / scale, W / scale, scale, ox, oy, radius < 0 ? 0 : radius, 0, 0};
+    g = SplatGeom{B, C, H, W, H / scale, W / scale, scale, ox, oy, radius < 0 ? 0 : radius, 0, 0, 0};
     g.ntx = cdiv(g.Wo, S_TW);
     g.nty = cdiv(g.Ho, S_TH);
     return OFD_OK;
@@ -750,6 +787,8 @@ static inline int stream_grid(size_t total, int block) {
 using namespace ofd;
 
 constexpr int S_MAXC = 256;     // channels the per-plane maxima area of the workspace is sized for
+static int splat_launch(const float* in, const float* flow, float* out, const SplatGeom& g, void* workspace, hipStream_t s);
+
 extern "C" size_t ofd_splat_workspace_bytes(int B, int H, int W) {
     // far-corner counter | per-(sample, channel) |in| maxima | far-corner list
     return 16 + (size_t)B * S_MAXC * 4 + sizeof(unsigned long long) * (size_t)B * H * W;
@@ -767,7 +806,11 @@ extern "C" int ofd_splat_fwd(const float* in, const float* flow, float* out, int
         return OFD_ERR_WORKSPACE;
     }
     OFD_CHECK_ARG(C <= S_MAXC, "splat_fwd: C=%d > %d", C, S_MAXC);
-    hipStream_t s = (hipStream_t)stream;
+    return splat_launch(in, flow, out, g, workspace, (hipStream_t)stream);
+}
+
+static int splat_launch(const float* in, const float* flow, float* out, const SplatGeom& g, void* workspace, hipStream_t s) {
+    const int B = g.B, C = g.C, H = g.H, W = g.W;
     unsigned int* count = (unsigned int*)workspace;
     unsigned int* absmax = (unsigned int*)((char*)workspace + 16);
     unsigned long long* list = (unsigned long long*)((char*)workspace + 16 + (size_t)B * S_MAXC * 4);
@@ -868,6 +911,33 @@ extern "C" int ofd_grid_warp_fwd(const float* second, const float* flow, float* 
     else
         grid_warp_scalar_kernel<<<stream_grid((size_t)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(second, flow, out, mask, B, C, H, W);
     OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" int ofd_grid_warp_bwd(const float* second, const float* flow, const float* grad_out, float* grad_second, float* grad_flow,
+                                 int B, int C, int H, int W, int radius, void* workspace, size_t workspace_bytes, void* stream) {
+    OFD_CHECK_ARG(flow && grad_out && (grad_second || grad_flow) && B > 0 && C > 0 && H > 0 && W > 0, "grid_warp_bwd: bad argument");
+    OFD_CHECK_ARG(!grad_flow || second, "grid_warp_bwd: the flow gradient needs the image");
+    hipStream_t s = (hipStream_t)stream;
+    if (grad_second) {
+        // adjoint of the bilinear gather = bilinear scatter of grad_out to the same four corners: the splat kernel with
+        // grid_sample's coordinates (bit-identical corner indices to ofd_grid_warp_fwd)
+        SplatGeom g;
+        int rc = make_geom(g, B, C, H, W, 1, 0, 0, radius);
+        if (rc) return rc;
+        g.grid = 1;
+        OFD_CHECK_ARG(workspace && g.nty <= 65535 && B <= 65535 && C <= S_MAXC, "grid_warp_bwd: workspace / grid");
+        if (workspace_bytes < ofd_splat_workspace_bytes(B, H, W)) {
+            set_error("grid_warp_bwd: workspace %zu < %zu", workspace_bytes, ofd_splat_workspace_bytes(B, H, W));
+            return OFD_ERR_WORKSPACE;
+        }
+        rc = splat_launch(grad_out, flow, grad_second, g, workspace, s);
+        if (rc) return rc;
+    }
+    if (grad_flow) {
+        grid_warp_flowgrad_kernel<<<stream_grid((size_t)B * H * W, 256), 256, 0, s>>>(second, flow, grad_out, grad_flow, B, C, H, W);
+        OFD_LAUNCH_CHECK();
+    }
     return OFD_OK;
 }
 

@@ -79,17 +79,46 @@ def warp_forward_flow(first, second, flow, scale=1, set_nans=True, get_variance=
     return img
 
 
+class _GridWarp(torch.autograd.Function):
+    """warp_backward_flow (WP:95-119) with the gradients autograd derives for it: d/d second is the bilinear scatter of the
+    incoming gradient (the splat kernel on grid_sample's coordinates), d/d flow ATen's grid gradient; the thresholded mask
+    (WP:116-117 overwrites every element) carries none."""
+
+    @staticmethod
+    def forward(ctx, second, flow):
+        second, flow = L.f32c(second), L.f32c(flow)
+        B, C, H, W = second.shape
+        out = torch.empty_like(second)
+        mask = torch.empty_like(second)
+        L.check(L.lib().ofd_grid_warp_fwd(L.ptr(second), L.ptr(flow), L.ptr(out), L.ptr(mask), B, C, H, W, L.stream()))
+        ctx.save_for_backward(second, flow)
+        ctx.mark_non_differentiable(mask)
+        return out, mask
+
+    @staticmethod
+    def backward(ctx, g_out, _g_mask):
+        from .softsplat import DEFAULT_RADIUS, _workspace
+        second, flow = ctx.saved_tensors
+        B, C, H, W = second.shape
+        g_out = L.f32c(g_out)
+        need_second, need_flow = ctx.needs_input_grad
+        g_second = torch.empty_like(second) if need_second else None
+        g_flow = torch.empty_like(flow) if need_flow else None
+        if need_second or need_flow:
+            lib = L.lib()
+            ws = _workspace(second.device, lib.ofd_splat_workspace_bytes(B, H, W)) if need_second else None
+            L.check(lib.ofd_grid_warp_bwd(L.ptr(second), L.ptr(flow), L.ptr(g_out), L.ptr(g_second) if need_second else None,
+                                          L.ptr(g_flow) if need_flow else None, B, C, H, W, DEFAULT_RADIUS,
+                                          L.ptr(ws) if need_second else None, ws.numel() if need_second else 0, L.stream()))
+        return g_second, g_flow
+
+
 def warp_backward_flow(first, second, flow):
     """WP:95-119: returns (output, mask)."""
     L.require_gpu(second, flow)
-    if second.requires_grad or flow.requires_grad:
-        raise L.OfdError("warp(mode='backward') is forward-only in this build (FlowDiffuser never differentiates it)")
-    second, flow = L.f32c(second), L.f32c(flow)
-    B, C, H, W = second.shape
-    out = torch.empty_like(second)
-    mask = torch.empty_like(second)
-    L.check(L.lib().ofd_grid_warp_fwd(L.ptr(second), L.ptr(flow), L.ptr(out), L.ptr(mask), B, C, H, W, L.stream()))
-    return out, mask
+    if flow.shape != (second.shape[0], 2, second.shape[2], second.shape[3]):
+        raise L.OfdError(f"flow must be (B,2,H,W) for second {tuple(second.shape)}, got {tuple(flow.shape)}")
+    return _GridWarp.apply(second, flow)
 
 
 def grid_warp_corners(flow):

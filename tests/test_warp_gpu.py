@@ -167,6 +167,39 @@ def test_grid_sample_warp_against_reference_goldens(ofd):
         assert torch.equal(c[..., 0], ix) and torch.equal(c[..., 1], iy), tag
 
 
+def test_grid_sample_warp_gradients_against_oracle_autograd(ofd):
+    """warp(mode='backward') is differentiable like the reference's (autograd through WP:95-119): d/d second (bilinear scatter)
+    and d/d flow (ATen's grid gradient) against CPU autograd of the oracle restatement, incl. targets outside the image, the
+    border rows/columns and a wide tile-crossing case."""
+    from oracle import warp_ref as WR
+    torch.manual_seed(21)
+    for (B, C, H, W, amp) in [(2, 3, 20, 32, 3.0), (1, 2, 37, 64, 12.0), (1, 3, 70, 132, 30.0), (2, 1, 9, 8, 6.0)]:
+        img = torch.rand(B, C, H, W)
+        flow = (torch.rand(B, 2, H, W) * 2 - 1) * amp
+        flow[0, :, 0, 0] = 0.25                                   # an interior sub-pixel case at the corner
+        gout = torch.randn(B, C, H, W)
+        a, b = img.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+        ro, rm = WR.warp_backward_flow(a, b)
+        (ro * gout).sum().backward()
+        x, f = img.cuda().requires_grad_(True), flow.cuda().requires_grad_(True)
+        o, m = ofd.warp(None, x, f, mode="backward")
+        assert not m.requires_grad
+        (o * gout.cuda()).sum().backward()
+        scale_s = float(a.grad.abs().max()) + 1e-6
+        scale_f = float(b.grad.abs().max()) + 1e-6
+        assert float((x.grad.cpu() - a.grad).abs().max()) < 2e-5 * scale_s + 1e-6, (B, C, H, W)
+        assert float((f.grad.cpu() - b.grad).abs().max()) < 2e-5 * scale_f + 1e-6, (B, C, H, W)
+    # only one of the two gradients requested
+    x = img.cuda().requires_grad_(True)
+    o, _ = ofd.warp(None, x, flow.cuda(), mode="backward")
+    o.sum().backward()
+    assert x.grad is not None
+    f = flow.cuda().requires_grad_(True)
+    o, _ = ofd.warp(None, img.cuda(), f, mode="backward")
+    o.sum().backward()
+    assert f.grad is not None and bool(torch.isfinite(f.grad).all())
+
+
 def test_grid_sample_warp_full_size_properties(ofd):
     """BASELINE size (16,3,440,1024): zero flow is the identity up to the fp32 round trip, and a
     constant integer shift equals a slice (size-independent properties; the oracle is too slow here)."""
@@ -181,6 +214,15 @@ def test_grid_sample_warp_full_size_properties(ofd):
     out, mask = ofd.warp(None, img, f, mode="backward")
     assert float((out[:, :, 2:, :-3] - img[:, :, :-2, 3:]).abs().max()) < 2e-4
     assert bool((mask[:, :, :2] == 0).all()) and bool((mask[:, :, :, -3:] == 0).all())
+    # adjoint identity at full size: <warp(img), g> == <img, warp^T(g)> for the scatter kernel behind d/d second
+    fr = (torch.rand(16, 2, 440, 1024, device="cuda") * 2 - 1) * 20.0
+    g = torch.randn(16, 3, 440, 1024, device="cuda")
+    x = img.clone().requires_grad_(True)
+    o, _ = ofd.warp(None, x, fr, mode="backward")
+    lhs = float((o.detach().double() * g.double()).sum())
+    (o * g).sum().backward()
+    rhs = float((img.double() * x.grad.double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), 1.0) + 1e-2
 
 
 def test_splat_full_size_properties(ofd):

@@ -55,6 +55,14 @@ def main():
     print(json.dumps({"kernel": "splat_bwd_in", "ms": ms, "GBps": 40.0 * px / ms / 1e6}))
     ms = timed(lambda: check(lib().ofd_splat_bwd_flow(ptr(img4), ptr(flow), ptr(g), ptr(gf), B, 4, H, W, 1, 0, 0, stream())))
     print(json.dumps({"kernel": "splat_bwd_flow", "ms": ms, "GBps": 48.0 * px / ms / 1e6}))
+    # grid_sample warp backward: d/d second = scatter (splat kernel on grid coordinates), d/d flow = gather
+    g3 = torch.rand(B, 3, H, W, device="cuda")
+    ws = torch.empty(lib().ofd_splat_workspace_bytes(B, H, W), dtype=torch.uint8, device="cuda")
+    gs, gfl = torch.empty_like(img3), torch.empty_like(flow)
+    ms = timed(lambda: check(lib().ofd_grid_warp_bwd(ptr(img3), ptr(flow), ptr(g3), ptr(gs), None, B, 3, H, W, 24, ptr(ws), ws.numel(), stream())))
+    print(json.dumps({"kernel": "grid_warp_bwd d/d second (scatter)", "ms": ms, "GBps": 32.0 * px / ms / 1e6}))
+    ms = timed(lambda: check(lib().ofd_grid_warp_bwd(ptr(img3), ptr(flow), ptr(g3), None, ptr(gfl), B, 3, H, W, 24, None, 0, stream())))
+    print(json.dumps({"kernel": "grid_warp_bwd d/d flow (gather)", "ms": ms, "GBps": 40.0 * px / ms / 1e6}))
     # CPU oracle on a bounded sample (1 of 16 samples)
     from oracle import warp_ref as WR
     t0 = time.time()
