@@ -132,6 +132,9 @@ typedef struct {
     int out_dim;        /* 2 */
     int eps_mode;       /* 0: eps 1e-5 everywhere (reference precision 32);
                            1: per-site eps the reference uses under bf16 autocast (DD:107,122) */
+    int no_time;        /* 0: Unet(time_in=True) (the diffusion UNet).  1: Unet(time_in=False) (DD:306-324, FD:110 with
+                           is_diffusion=False; flow_learner.py:93-98): no time MLP, ResnetBlocks without scale/shift
+                           (DD:192-195), the `t` argument of the forward calls is ignored and may be NULL */
 } ofd_unet_config;
 
 int ofd_unet_create(const ofd_unet_config* cfg, ofd_unet** out);

@@ -19,7 +19,7 @@ class OfdError(RuntimeError):
 
 
 class UnetConfig(ctypes.Structure):
-    _fields_ = [("dim", c_int), ("channels", c_int), ("out_dim", c_int), ("eps_mode", c_int)]
+    _fields_ = [("dim", c_int), ("channels", c_int), ("out_dim", c_int), ("eps_mode", c_int), ("no_time", c_int)]
 
 
 class ConvSrc(ctypes.Structure):

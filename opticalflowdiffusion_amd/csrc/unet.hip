@@ -42,8 +42,10 @@ static void add_conv(ofd_unet* u, const std::string& prefix, int co, int ci, int
 
 static void add_resblock(ofd_unet* u, const std::string& name, int ci, int co) {
     const int tdim = u->cfg.dim * 4;
-    add_param(u, name + ".mlp.1.weight", {co * 2, tdim});
-    add_param(u, name + ".mlp.1.bias", {co * 2});
+    if (!u->cfg.no_time) {
+        add_param(u, name + ".mlp.1.weight", {co * 2, tdim});
+        add_param(u, name + ".mlp.1.bias", {co * 2});
+    }
     add_conv(u, name + ".block1.proj", co, ci, 3, true, site_eps(u, name + ".block1.proj"));
     add_param(u, name + ".block1.norm.weight", {co});
     add_param(u, name + ".block1.norm.bias", {co});
@@ -71,10 +73,12 @@ static void build_registry(ofd_unet* u) {
     u->dims = {dim, dim, dim * 2, dim * 4, dim * 8};
     const int tdim = dim * 4;
     add_conv(u, "init_conv", dim, u->cfg.channels, 7, true, -1.0f);
-    add_param(u, "time_mlp.1.weight", {tdim, dim});
-    add_param(u, "time_mlp.1.bias", {tdim});
-    add_param(u, "time_mlp.3.weight", {tdim, tdim});
-    add_param(u, "time_mlp.3.bias", {tdim});
+    if (!u->cfg.no_time) {
+        add_param(u, "time_mlp.1.weight", {tdim, dim});
+        add_param(u, "time_mlp.1.bias", {tdim});
+        add_param(u, "time_mlp.3.weight", {tdim, tdim});
+        add_param(u, "time_mlp.3.bias", {tdim});
+    }
     for (int i = 0; i < 4; ++i) {
         const int ci = u->dims[i], co = u->dims[i + 1];
         const std::string p = "downs." + std::to_string(i);
@@ -317,8 +321,12 @@ int run_forward(Ctx& c, const float* x, int Cx, const float* cond, int Cc, const
     Tensor xin = c.keep(16, H, W);
     c.begin(PC_MISC, 0, 0);
     RUN(k_pack_input(x, Cx, cond, cond ? Cc : 0, xin.p, B, H, W, c.s));
-    RUN(k_time_mlp(t, u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"), u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), temb, temb_silu, B, dim, c.s));
-    RUN(k_block_mlp(temb_silu, u->d_mlp, (int)u->resblocks.size(), c.ss, B, dim * 4, u->ss_stride, c.s));
+    if (!u->cfg.no_time) {
+        RUN(k_time_mlp(t, u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"), u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), temb, temb_silu, B, dim, c.s));
+        RUN(k_block_mlp(temb_silu, u->d_mlp, (int)u->resblocks.size(), c.ss, B, dim * 4, u->ss_stride, c.s));
+    } else {
+        c.ss = nullptr;          // GroupNorm of block1 folds no scale/shift (DD:205-208 with scale_shift = None)
+    }
     c.end();
     Tensor r = c.keep(dim, H, W);
     { SrcSpec s; s.t = xin; plain_conv(c, "init_conv", {s}, r); }
@@ -444,6 +452,7 @@ size_t small_bytes(const ofd_unet* u, int B) {
 static void drop_graphs(ofd_unet* u);
 
 static void upload_mlp_descs(ofd_unet* u) {
+    if (u->cfg.no_time) return;
     std::vector<MlpDesc> descs;
     for (auto& name : u->resblocks) {
         MlpDesc d;
@@ -477,6 +486,7 @@ extern "C" int ofd_unet_create(const ofd_unet_config* cfg, ofd_unet** out) {
     OFD_CHECK_ARG(cfg->channels >= 1 && cfg->channels <= 16, "unet_create: channels=%d (1..16)", cfg->channels);
     OFD_CHECK_ARG(cfg->out_dim >= 1 && cfg->out_dim <= 4, "unet_create: out_dim=%d (1..4)", cfg->out_dim);
     OFD_CHECK_ARG(cfg->eps_mode == 0 || cfg->eps_mode == 1, "unet_create: eps_mode=%d", cfg->eps_mode);
+    OFD_CHECK_ARG(cfg->no_time == 0 || cfg->no_time == 1, "unet_create: no_time=%d", cfg->no_time);
     ofd_unet* u = new ofd_unet();
     u->cfg = *cfg;
     build_registry(u);
@@ -587,7 +597,7 @@ extern "C" int ofd_unet_set_graph(ofd_unet* u, int enabled) {
 
 extern "C" int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float* cond, int Cc, const int64_t* t, float* out,
                                 int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
-    OFD_CHECK_ARG(u && x && t && out && workspace, "unet_forward: null argument");
+    OFD_CHECK_ARG(u && x && (t || u->cfg.no_time) && out && workspace, "unet_forward: null argument");
     OFD_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "unet_forward: H=%d W=%d must be positive multiples of 8 (three 2x down-samplings, DD:95-99)", H, W);
     OFD_CHECK_ARG(Cx + (cond ? Cc : 0) == u->cfg.channels, "unet_forward: %d + %d input channels, UNet has %d", Cx, cond ? Cc : 0, u->cfg.channels);
     if (!u->prepared) { set_error("unet_forward: call ofd_unet_prepare after setting parameters"); return OFD_ERR_STATE; }
@@ -623,7 +633,7 @@ extern "C" int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float
     hipStream_t s_ = (hipStream_t)stream;
     OFD_HIP(hipMemcpyAsync(sx, x, (size_t)B * Cx * plane, hipMemcpyDeviceToDevice, s_));
     if (cond) OFD_HIP(hipMemcpyAsync(sc, cond, (size_t)B * Cc * plane, hipMemcpyDeviceToDevice, s_));
-    OFD_HIP(hipMemcpyAsync(st, t, (size_t)B * 8, hipMemcpyDeviceToDevice, s_));
+    if (t) OFD_HIP(hipMemcpyAsync(st, t, (size_t)B * 8, hipMemcpyDeviceToDevice, s_));
     ofd_unet::GraphEntry* e = nullptr;
     for (auto& g : u->graphs)
         if (g.workspace == workspace && g.B == B && g.H == H && g.W == W && g.Cx == Cx && g.Cc == (cond ? Cc : 0) && g.stream == s_) e = &g;

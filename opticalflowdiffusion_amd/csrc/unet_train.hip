@@ -168,11 +168,14 @@ static void resblock_backward(Bwd& b, const TapeRec& r, float* dss, float* dts) 
     SrcSpec sa; sa.t = act1;
     Tensor dact1 = conv_backward(b, name + ".block2.proj", {sa}, r.h2.g, H, W, true, nullptr, true);
     c.begin(PC_GNBWD, 0, ew * 5, name + ".block1 gn-silu bwd");
-    RUN(k_gn_silu_backward(dact1.p, r.h1.p, r.a1, r.s1, r.st1, u->P(name + ".block1.norm.weight"), u->P(name + ".block1.norm.bias"), c.ss,
-                           u->ss_stride, u->ss_offset.at(name), r.h1.g, u->G(name + ".block1.norm.weight"), u->G(name + ".block1.norm.bias"), dss,
+    const bool timed = !u->cfg.no_time;       // Unet(time_in=False): block1 has no scale/shift and no time projection
+    RUN(k_gn_silu_backward(dact1.p, r.h1.p, r.a1, r.s1, r.st1, u->P(name + ".block1.norm.weight"), u->P(name + ".block1.norm.bias"),
+                           timed ? c.ss : nullptr, timed ? u->ss_stride : 0, timed ? u->ss_offset.at(name) : 0, r.h1.g,
+                           u->G(name + ".block1.norm.weight"), u->G(name + ".block1.norm.bias"), timed ? dss : nullptr,
                            ws, B, H, W, Cout, c.s, u->G(name + ".block1.proj.bias")));
-    RUN(k_block_mlp_bwd(dss, u->ts.temb_silu, u->P(name + ".mlp.1.weight"), 2 * Cout, u->ss_offset.at(name), u->G(name + ".mlp.1.weight"),
-                        u->G(name + ".mlp.1.bias"), dts, B, u->cfg.dim * 4, u->ss_stride, c.s));
+    if (timed)
+        RUN(k_block_mlp_bwd(dss, u->ts.temb_silu, u->P(name + ".mlp.1.weight"), 2 * Cout, u->ss_offset.at(name), u->G(name + ".mlp.1.weight"),
+                            u->G(name + ".mlp.1.bias"), dts, B, u->cfg.dim * 4, u->ss_stride, c.s));
     c.end();
     Tensor D;
     if (cin == Cout) {
@@ -303,6 +306,7 @@ static int run_backward(Ctx& c, const float* dout, const TrainLayout& L, float* 
         }
         notify(r.name);
     }
+    if (u->cfg.no_time) return c.rc;
     c.begin(PC_MISC, 0, 0, "time_mlp bwd");
     RUN(k_time_mlp_bwd(u->ts.t, u->ts.temb, dts, u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"), u->P("time_mlp.3.weight"),
                        u->G("time_mlp.1.weight"), u->G("time_mlp.1.bias"), u->G("time_mlp.3.weight"), u->G("time_mlp.3.bias"), tm, B, dim, c.s));
@@ -368,7 +372,8 @@ static int prepare_train(ofd_unet* u, hipStream_t s) {
     if (u->prange.empty()) {
         // parameter range of every op prefix the backward reports: the longest registered op name that
         // prefixes the parameter name ("downs.0.0" resblock, "downs.0.2" attention, "downs.0.3.1" conv ...)
-        std::vector<std::string> ops = {"init_conv", "time_mlp", "final_conv", "mid_attn"};
+        std::vector<std::string> ops = {"init_conv", "final_conv", "mid_attn"};
+        if (!u->cfg.no_time) ops.push_back("time_mlp");
         for (auto& n : u->resblocks) ops.push_back(n);
         for (auto& kv : u->cindex) {
             const std::string& p = kv.first;
@@ -404,7 +409,7 @@ static int prepare_train(ofd_unet* u, hipStream_t s) {
 
 extern "C" int ofd_unet_train_forward(ofd_unet* u, const float* x, int Cx, const float* cond, int Cc, const int64_t* t, float* out, int B, int H,
                                       int W, void* workspace, size_t workspace_bytes, void* stream) {
-    OFD_CHECK_ARG(u && x && t && out && workspace, "unet_train_forward: null argument");
+    OFD_CHECK_ARG(u && x && (t || u->cfg.no_time) && out && workspace, "unet_train_forward: null argument");
     OFD_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "unet_train_forward: H=%d W=%d must be positive multiples of 8", H, W);
     OFD_CHECK_ARG(Cx + (cond ? Cc : 0) == u->cfg.channels, "unet_train_forward: %d + %d input channels, UNet has %d", Cx, cond ? Cc : 0, u->cfg.channels);
     OFD_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "unet_train_forward: workspace must be 256-byte aligned");

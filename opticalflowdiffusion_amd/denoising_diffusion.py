@@ -39,10 +39,10 @@ class _Node(nn.Module):
     """Parameter container that reproduces the reference's module tree in state-dict keys."""
 
 
-def _registry(dim, channels, out_dim, eps_mode):
+def _registry(dim, channels, out_dim, eps_mode, no_time=0):
     """(handle, [(name, shape)]) from the C library, which owns the layer table."""
     lib = L.lib()
-    cfg = L.UnetConfig(dim, channels, out_dim, eps_mode)
+    cfg = L.UnetConfig(dim, channels, out_dim, eps_mode, no_time)
     h = ctypes.c_void_p()
     L.check(lib.ofd_unet_create(ctypes.byref(cfg), ctypes.byref(h)))
     names = []
@@ -71,25 +71,25 @@ class _UnetTrain(torch.autograd.Function):
 
 
 class Unet(nn.Module):
-    """DD:272-417.  Supported: dim=64, dim_mults=(1,2,4,8), time_in=True, no self-conditioning --
-    the UNet FlowDiffuser instantiates (FD:106-111)."""
+    """DD:272-417.  Supported: dim=64, dim_mults=(1,2,4,8), no self-conditioning -- the UNet FlowDiffuser instantiates
+    (FD:106-111), with time_in=True (diffusion) or time_in=False (is_diffusion=False, and FlowLearner's regression UNet)."""
 
     def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=3, self_condition=False,
                  resnet_block_groups=8, learned_variance=False, learned_sinusoidal_cond=False,
                  random_fourier_features=False, learned_sinusoidal_dim=16, time_in=True, precision="bf16"):
         super().__init__()
         if (dim != 64 or tuple(dim_mults) != (1, 2, 4, 8) or self_condition or learned_variance or learned_sinusoidal_cond
-                or random_fourier_features or not time_in or resnet_block_groups != 8 or init_dim not in (None, dim)):
-            raise NotImplementedError("the HIP engine implements the FlowDiffuser UNet: Unet(64, channels=, out_dim=, time_in=True)")
+                or random_fourier_features or resnet_block_groups != 8 or init_dim not in (None, dim)):
+            raise NotImplementedError("the HIP engine implements the FlowDiffuser UNet: Unet(64, channels=, out_dim=, time_in=)")
         self.channels = channels
         self.self_condition = False
-        self.time_in = True
+        self.time_in = bool(time_in)
         self.random_or_learned_sinusoidal_cond = False
         self.out_dim = default(out_dim, channels)
         self.dim = dim
         # eps_mode 1: per-site eps of the reference under bf16 autocast (DD:107,122); 0: fp32 rule
         self.eps_mode = 1 if precision == "bf16" else 0
-        self._handle, reg = _registry(dim, channels, self.out_dim, self.eps_mode)
+        self._handle, reg = _registry(dim, channels, self.out_dim, self.eps_mode, 0 if self.time_in else 1)
         self._names = [n for n, _ in reg]
         gen = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
         fan_in = 1
@@ -182,18 +182,21 @@ class Unet(nn.Module):
     def forward(self, x, external_cond=None, time=None, x_self_cond=None, additional_out=False):
         if additional_out:
             raise ValueError("additional tgt not supported for non warp Unet")             # DD:364-365
-        if time is None:
+        if self.time_in and time is None:
             raise ValueError("when Unet takes time arg, time argument must be passed in")  # DD:378-379
+        if not self.time_in and time is not None:
+            raise ValueError("this Unet does not take time arg")                           # DD:382-383
         L.require_gpu(x, external_cond, time)
         if x.requires_grad or (external_cond is not None and external_cond.requires_grad):
             raise L.OfdError("Unet.forward: gradients w.r.t. the inputs are not produced (the training step never needs them)")
         x = L.f32c(x)
         cond = L.f32c(external_cond) if external_cond is not None else None
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return _UnetTrain.apply(self, x, cond, time.to(torch.int64).contiguous(), *[self._param(n) for n in self._names])
+            return _UnetTrain.apply(self, x, cond, time.to(torch.int64).contiguous() if self.time_in else None,
+                                    *[self._param(n) for n in self._names])
         B, Cx, H, W = x.shape
         Cc = cond.shape[1] if cond is not None else 0
-        t = time.to(torch.int64).contiguous()
+        t = time.to(torch.int64).contiguous() if self.time_in else None
         self._sync_params(x.device)
         ws = self._workspace(x.device, B, H, W)
         out = torch.empty(B, self.out_dim, H, W, dtype=torch.float32, device=x.device)

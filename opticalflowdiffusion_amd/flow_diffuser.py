@@ -120,8 +120,6 @@ class FlowDiffuser(_Base):
         self.target = cfg.target
         if self.latent:
             raise NotImplementedError("latent=True needs the reference's W&B autoencoder checkpoint (FD:84-90): network fetch")
-        if not self.is_diffusion:
-            raise NotImplementedError("is_diffusion=False (plain regression UNet, time_in=False) is outside the hot path")
         self.dim = 3
         if self.target == "target":                                         # FD:98-104
             unet_dims = self.dim + 1
@@ -129,11 +127,15 @@ class FlowDiffuser(_Base):
             unet_dims = self.dim + 3
         else:
             unet_dims = 2
-        self.unet = Unet(64, channels=self.dim + unet_dims, out_dim=2, time_in=True, precision=cfg.precision)   # FD:106-111
+        self.unet = Unet(64, channels=self.dim + unet_dims * int(self.is_diffusion), out_dim=2, time_in=bool(self.is_diffusion),
+                         precision=cfg.precision)                           # FD:106-111
         if cfg.target in ["target", "joint"]:
             self._model = UnetWithWarp(cfg, self.unet, full_output=cfg.target == "joint")
         else:
             self._model = self.unet
+        if not self.is_diffusion:                                           # FD:128-129: plain regression cond -> flow
+            self.model = self._model
+            return
         self.model = ConditionalDiffusion(                                  # FD:118-127
             self._model, cfg.image_size, objective="pred_x0",
             channels=2 + 1 * int(cfg.target == "target") + 3 * int(cfg.target == "joint"),
@@ -167,7 +169,15 @@ class FlowDiffuser(_Base):
         ret.append(flow)
         return tuple(ret)
 
-    def loss(self, tgt, cond, flow, override=None):                         # FD:170-175
+    def loss(self, tgt, cond, flow, override=None):                         # FD:170-187
+        if not self.is_diffusion:
+            # FD:176-186.  (The reference tests `override is not None` the wrong way round, FD:177-180: it calls the model when an
+            # override IS given and uses None otherwise; the evident intent is implemented.)
+            out = override if override is not None else self.model(cond, additional_out=self.cfg.target == "target")
+            mse = torch.nn.functional.mse_loss
+            if self.cfg.target in ["target", "joint"]:
+                return mse(out[:, :self.dim], tgt) + self.cfg.flow_weight * mse(out[:, self.dim:], flow)
+            return mse(out, flow)
         if self.cfg.target == "target":
             return self.model(tgt, external_cond=cond, additional_tgt=flow, additional_weight=self.cfg.flow_weight,
                               model_out_override=override)
@@ -175,6 +185,12 @@ class FlowDiffuser(_Base):
 
     def sample(self, cond, flow):                                           # FD:189-215
         bsz = flow.shape[0]
+        if not self.is_diffusion:                                           # FD:204-213
+            if self.cfg.target in ["target", "joint"]:
+                samples = self.model(cond, additional_out=True) if self.cfg.target == "target" else self.model(cond)
+                return samples[:, :self.dim], samples[:, -2:]
+            flow = self.model(cond)
+            return warp(cond[:, :self.dim], None, flow, mode="forward"), flow
         if self.cfg.target == "target":
             samples, flow = self.model.sample(batch_size=bsz, external_cond=cond, additional_tgt=flow, return_all_timesteps=True)
         elif self.cfg.target == "joint":

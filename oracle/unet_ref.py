@@ -125,13 +125,15 @@ def resnet_block(P, pre, x, temb, eps, q, groups=8):
     x arrives already stored (q'd).  Rounding points of the engine: conv outputs, the
     conv2 input SiLU(GN(h1)), and the block output.
     """
-    ss = F.linear(F.silu(temb), P[f"{pre}.mlp.1.weight"], P[f"{pre}.mlp.1.bias"])  # DD:205-208
-    scale, shift = ss[:, :, None, None].chunk(2, dim=1)
+    timed = temb is not None and f"{pre}.mlp.1.weight" in P                        # DD:204 exists(self.mlp) and exists(time_emb)
+    if timed:
+        ss = F.linear(F.silu(temb), P[f"{pre}.mlp.1.weight"], P[f"{pre}.mlp.1.bias"])  # DD:205-208
+        scale, shift = ss[:, :, None, None].chunk(2, dim=1)
 
     w1 = q(standardize_weight(P[f"{pre}.block1.proj.weight"], eps(f"{pre}.block1.proj", x)))
     h = q(F.conv2d(x, w1, P[f"{pre}.block1.proj.bias"], padding=1))
     h = F.group_norm(h, groups, P[f"{pre}.block1.norm.weight"], P[f"{pre}.block1.norm.bias"], eps=1e-5)
-    h = q(F.silu(h * (scale + 1) + shift))                                         # DD:183-187
+    h = q(F.silu(h * (scale + 1) + shift if timed else h))                         # DD:183-187
 
     w2 = q(standardize_weight(P[f"{pre}.block2.proj.weight"], eps(f"{pre}.block2.proj", h)))
     h = q(F.conv2d(h, w2, P[f"{pre}.block2.proj.bias"], padding=1))
@@ -214,8 +216,10 @@ def unet_forward(P, x, cond, t, dim=64, dim_mults=(1, 2, 4, 8), mode="fp32", tap
     x = q(F.conv2d(x, q(P["init_conv.weight"]), P["init_conv.bias"], padding=3))   # DD:374
     r = x
     tap("init_conv", x)
-    temb = time_mlp(P, t, dim)                                                     # DD:381
-    tap("temb", temb)
+    temb = None                                                                    # DD:376-385: time_in=False takes no time
+    if "time_mlp.1.weight" in P:
+        temb = time_mlp(P, t, dim)                                                 # DD:381
+        tap("temb", temb)
 
     hs = []
     for i in range(n):                                                             # DD:390-398
@@ -261,8 +265,8 @@ def unet_forward(P, x, cond, t, dim=64, dim_mults=(1, 2, 4, 8), mode="fp32", tap
 
 
 # --------------------------------------------------------------------------- weights
-def unet_param_shapes(dim=64, channels=5, out_dim=2, dim_mults=(1, 2, 4, 8)):
-    """Ordered {name: shape} of the reference ``Unet(dim, channels=, out_dim=)`` state dict (DD:272-361)."""
+def unet_param_shapes(dim=64, channels=5, out_dim=2, dim_mults=(1, 2, 4, 8), time_in=True):
+    """Ordered {name: shape} of the reference ``Unet(dim, channels=, out_dim=, time_in=)`` state dict (DD:272-361)."""
     S = {}
     tdim = dim * 4
     dims = [dim] + [dim * m for m in dim_mults]
@@ -275,8 +279,9 @@ def unet_param_shapes(dim=64, channels=5, out_dim=2, dim_mults=(1, 2, 4, 8)):
             S[f"{name}.bias"] = (co,)
 
     def resblock(name, ci, co):
-        S[f"{name}.mlp.1.weight"] = (co * 2, tdim)
-        S[f"{name}.mlp.1.bias"] = (co * 2,)
+        if time_in:                                                            # DD:193-196
+            S[f"{name}.mlp.1.weight"] = (co * 2, tdim)
+            S[f"{name}.mlp.1.bias"] = (co * 2,)
         for blk, cin in (("block1", ci), ("block2", co)):
             conv(f"{name}.{blk}.proj", co, cin, 3)
             S[f"{name}.{blk}.norm.weight"] = (co,)
@@ -291,10 +296,11 @@ def unet_param_shapes(dim=64, channels=5, out_dim=2, dim_mults=(1, 2, 4, 8)):
         S[f"{name}.fn.norm.g"] = (1, c, 1, 1)
 
     conv("init_conv", dim, channels, 7)
-    S["time_mlp.1.weight"] = (tdim, dim)
-    S["time_mlp.1.bias"] = (tdim,)
-    S["time_mlp.3.weight"] = (tdim, tdim)
-    S["time_mlp.3.bias"] = (tdim,)
+    if time_in:                                                                # DD:308-324
+        S["time_mlp.1.weight"] = (tdim, dim)
+        S["time_mlp.1.bias"] = (tdim,)
+        S["time_mlp.3.weight"] = (tdim, tdim)
+        S["time_mlp.3.bias"] = (tdim,)
     for i, (ci, co) in enumerate(in_out):
         resblock(f"downs.{i}.0", ci, ci)
         resblock(f"downs.{i}.1", ci, ci)

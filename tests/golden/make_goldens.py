@@ -254,5 +254,41 @@ def main():
     save("warp_backward", **arrays)
 
 
+def regression_unet():
+    """(6) Unet(time_in=False): FlowDiffuser with is_diffusion=False (FD:106-111) and FlowLearner's flow+weight regressor
+    (flow_learner.py:93-98): Unet(64, channels=6, out_dim=3, time_in=False), forward, bf16-autocast forward and the gradient
+    of a fixed linear functional with respect to a few parameters."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    dd, _ = import_reference()
+    u = dd.Unet(64, channels=6, out_dim=3, time_in=False)
+    fill(u)
+    u.eval()
+    B, hw = 2, (32, 40)
+    x = sin_tensor((B, 6, *hw), 41, 1.0)
+    gy = sin_tensor((B, 3, *hw), 42, 1.0)
+    y = u(x)
+    (y * gy).sum().backward()
+    arrays = dict(x=x, gy=gy, y=y.detach())
+    P = dict(u.named_parameters())
+    for name in ("final_conv.weight", "final_conv.bias", "final_res_block.block1.norm.weight", "ups.3.0.res_conv.weight",
+                 "mid_block1.block2.proj.bias", "downs.0.0.block1.proj.weight", "init_conv.bias"):
+        arrays[f"grad.{name}"] = P[name].grad
+    arrays["n_params"] = np.int64(len(u.state_dict()))
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        yb = u(x)
+    arrays["y_autocast"] = yb.float()
+    try:
+        u(x, None, torch.tensor([1, 2]))
+        arrays["time_rejected"] = np.int64(0)
+    except ValueError:
+        arrays["time_rejected"] = np.int64(1)           # DD:382-383
+    save("unet_notime_c6_32x40", **arrays)
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-regression-unet" in sys.argv:
+        regression_unet()
+    else:
+        main()
+        regression_unet()

@@ -328,3 +328,38 @@ def test_unet_training_step_gradients(L, B, H, W):
     g2 = torch.cat([P[n].grad.flatten() for n, _ in net.named_parameters()])
     cos = torch.dot(g1, g2) / (g1.norm() * g2.norm())
     assert cos > 0.999, cos
+
+
+def test_regression_unet_time_in_false_forward_and_gradients(L):
+    """Unet(64, channels=6, out_dim=3, time_in=False): no time MLP, ResnetBlocks without scale/shift (DD:192-208).  Forward on the
+    oracle in the engine's bf16c contract and every parameter gradient against oracle autograd (the oracle itself is pinned to the
+    reference module in fp32 by tests/test_oracle_unet.py::test_regression_unet_time_in_false; with the goldens' closed-form
+    weights this network is chaotic in bf16 -- the reference's own autocast output differs from its fp32 output by 0.46 rel-L2 --
+    so default-init weights are used here); passing a time raises like DD:382-383."""
+    from conftest import load_golden
+    from opticalflowdiffusion_amd import Unet
+    g = load_golden("unet_notime_c6_32x40")
+    net = Unet(64, channels=6, out_dim=3, time_in=False).cuda()
+    names = [n for n, _ in net.named_parameters()]
+    assert len(names) == int(g["n_params"]) and not any(".mlp." in n or n.startswith("time_mlp") for n in names)
+    shapes = R.unet_param_shapes(64, 6, 3, time_in=False)
+    assert list(shapes) == names
+    with pytest.raises(ValueError):
+        net(g["x"].cuda(), None, torch.tensor([1, 2]).cuda())
+    # default-init weights (O(1) activations): forward + all gradients vs the oracle in the engine's contract
+    torch.manual_seed(9)
+    x = torch.randn(2, 6, 32, 40)
+    gy = torch.randn(2, 3, 32, 40)
+    out = net(x.cuda())
+    (out * gy.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    P = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in net.named_parameters()}
+    ref = R.unet_forward(P, x, None, None, mode="bf16c")
+    assert rel_l2(out.detach().cpu(), ref.detach()) < 2e-2
+    (ref * gy).sum().backward()
+    worst = sorted(((rel_l2(p.grad.cpu(), P[n].grad), n) for n, p in net.named_parameters()), reverse=True)
+    print("worst parameter-gradient errors:", [(f"{e:.3e}", n) for e, n in worst[:6]])
+    assert worst[0][0] < 5e-2, worst[:4]
+    with torch.no_grad():
+        out_inf = net(x.cuda())
+    assert rel_l2(out_inf.cpu(), ref.detach()) < 2e-2

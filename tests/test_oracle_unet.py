@@ -118,3 +118,22 @@ def test_engine_contract_vs_reference_autocast(tag, ch):
     err_ref = rel_l2(y, ga["y"])
     print(f"bf16c vs reference autocast rel-L2 = {err_ref:.3e}; autocast vs fp32 = {rel_l2(ga['y'], g['y']):.3e}")
     assert err_ref < 0.1   # informative: closed-form weights amplify bf16 rounding ~10x vs default init
+
+
+def test_regression_unet_time_in_false():
+    """Unet(64, channels=6, out_dim=3, time_in=False) (FlowDiffuser with is_diffusion=False, FD:106-111; FlowLearner's
+    regressor): parameter set, forward and autograd gradients of the restatement against the reference module."""
+    g = load_golden("unet_notime_c6_32x40")
+    shapes = R.unet_param_shapes(64, 6, 3, time_in=False)
+    assert len(shapes) == int(g["n_params"]) and not any(".mlp." in k or k.startswith("time_mlp") for k in shapes)
+    assert int(g["time_rejected"]) == 1
+    P = {k: v.requires_grad_(True) for k, v in R.closed_form_params(shapes).items()}
+    y = R.unet_forward(P, g["x"], None, None, mode="fp32")
+    assert rel_l2(y.detach(), g["y"]) < 1e-5
+    (y * g["gy"]).sum().backward()
+    for k in g:
+        if k.startswith("grad."):
+            assert rel_l2(P[k[5:]].grad, g[k]) < 2e-4, k
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        yb = R.unet_forward(P, g["x"], None, None, mode="autocast")
+    assert rel_l2(yb.float(), g["y_autocast"]) < 2e-2

@@ -171,6 +171,40 @@ def test_flow_diffuser_training_steps_reduce_the_loss():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in fd.unet.parameters())
 
 
+def test_flow_diffuser_regression_mode_is_diffusion_false():
+    """FD:106-111 / 128-129 / 176-186 / 204-213 with is_diffusion=False, target=flow: Unet(64, channels=3, out_dim=2, time_in=False)
+    regresses the flow from the condition image, loss = mse; training reduces it; sample = forward splat of the condition."""
+    from opticalflowdiffusion_amd import FlowDiffuser, Unet, warp
+    torch.manual_seed(0)
+    H, W, B = 32, 64, 4
+    fd = FlowDiffuser(dict(target="flow", is_diffusion=False, image_size=[H, W], flow_max=20, zero_init=False, lr=2e-4, weight_decay=0.0)).cuda()
+    assert isinstance(fd.model, Unet) and fd.model is fd.unet and not fd.unet.time_in and fd.unet.channels == 3
+    assert not any(n.startswith("time_mlp") or ".mlp." in n for n, _ in fd.named_parameters())
+    fd.log_dict = lambda *a, **k: None
+    opt = fd.configure_optimizers()
+    img = torch.rand(B, 3, H, W, device="cuda")
+    flow = torch.clamp(torch.randn(B, 2, H, W, device="cuda") * 8, -20, 20)
+    tgt_, cond, flow_ = fd.preprocess((img, img, flow), aug=False)
+    with torch.no_grad():
+        direct = torch.nn.functional.mse_loss(fd.unet(cond), flow_)
+        assert float(fd.loss(tgt_, cond, flow_)) == pytest.approx(float(direct), rel=1e-6)
+        assert float(fd.loss(tgt_, cond, flow_, override=flow_)) == 0.0
+    losses = []
+    for it in range(12):
+        loss = fd.training_step((img, img, flow), it)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.8 * losses[0], losses
+    with torch.no_grad():
+        samples, f = fd.sample(cond, flow_)
+        assert f.shape == (B, 2, H, W) and samples.shape == (B, 3, H, W)
+        again = warp(cond[:, :3], None, f, mode="forward")
+        assert torch.equal(torch.isnan(samples), torch.isnan(again)) and torch.allclose(torch.nan_to_num(samples), torch.nan_to_num(again))
+        fd.validation_step((img, img, flow), 0)
+
+
 def test_backward_reports_every_gradient_range_once():
     """the ranges handed to the data-parallel hook cover the flat gradient buffer exactly once, last layers first"""
     from opticalflowdiffusion_amd import Unet
