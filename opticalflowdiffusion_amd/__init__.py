@@ -4,3 +4,4 @@ from .warp import warp, nan_mse, scale, warp_forward_flow, warp_backward_flow  #
 from .softsplat import softsplat  # noqa: F401
 from .denoising_diffusion import Unet, ConditionalDiffusion  # noqa: F401,E402
 from .flow_diffuser import FlowDiffuser, UnetWithWarp  # noqa: F401,E402
+from .flow_learner import FlowLearner  # noqa: F401,E402

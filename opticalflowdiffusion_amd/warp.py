@@ -218,3 +218,33 @@ def scale(img, up=None, down=None):
         p = img.reshape(b, c, h // down, down, w // down, down)
         return torch.mean(torch.mean(p, dim=-1), dim=-2)
     return img
+
+
+# ---- photometric-loss helpers of the FlowLearner path (WP:273-303) ---------------------------------------------------
+def fill_holes_nan(img, weights):
+    """WP:273-276: NaN wherever nothing was splatted (weight <= 0)."""
+    return torch.where(weights > 0, img, torch.full_like(img, float("nan")))
+
+
+def charbonnier(x, alpha=0.5, eps=1e-3):
+    """WP:278-279."""
+    return torch.pow(torch.square(x) + eps ** 2, alpha)
+
+
+def nan_charbonnier(pred, target):
+    """WP:281-287: mean Charbonnier penalty over the positions where neither side is NaN."""
+    pred, target = pred.flatten(), target.flatten()
+    ok = torch.logical_not(torch.logical_or(torch.isnan(target), torch.isnan(pred)))
+    return torch.mean(charbonnier(pred[ok] - target[ok]))
+
+
+def edgeaware_smoothness1(image, flow, edge_weight=30):
+    """WP:289-303: first-order flow smoothness, down-weighted across image edges."""
+    image_grad_y = image[:, :, 1:, :] - image[:, :, :-1, :]
+    image_grad_x = image[:, :, :, 1:] - image[:, :, :, :-1]
+    flow_grad_y = flow[:, :, 1:, :] - flow[:, :, :-1, :]
+    flow_grad_x = flow[:, :, :, 1:] - flow[:, :, :, :-1]
+    y_weights = torch.exp(-edge_weight * torch.mean(image_grad_y ** 2, dim=1, keepdim=True))
+    x_weights = torch.exp(-edge_weight * torch.mean(image_grad_x ** 2, dim=1, keepdim=True))
+    loss = torch.mean(x_weights * charbonnier(flow_grad_x)) + torch.mean(y_weights * charbonnier(flow_grad_y))
+    return loss / 2

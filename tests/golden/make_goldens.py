@@ -286,9 +286,26 @@ def regression_unet():
     save("unet_notime_c6_32x40", **arrays)
 
 
+def loss_helpers():
+    """(7) the photometric-loss helpers of the FlowLearner path (WP:273-303), run from the reference's warp module."""
+    _, wp = import_reference()
+    img = sin_tensor((2, 3, 12, 20), 51)
+    flow = sin_tensor((2, 2, 12, 20), 52, 4.0)
+    a = sin_tensor((2, 3, 12, 20), 53)
+    b = sin_tensor((2, 3, 12, 20), 54)
+    a[0, 1, 2, 3] = float("nan")
+    b[1, 0, 5, 5] = float("nan")
+    w = sin_tensor((2, 1, 12, 20), 55)
+    save("loss_helpers", img=img, flow=flow, a=a, b=b, w=w, charbonnier=wp.charbonnier(a), nan_charbonnier=wp.nan_charbonnier(a, b),
+         fill_holes_nan=wp.fill_holes_nan(img, w), edgeaware_smoothness1=wp.edgeaware_smoothness1(img, flow))
+
+
 if __name__ == "__main__":
-    if "--only-regression-unet" in sys.argv:
+    if "--only-loss-helpers" in sys.argv:
+        loss_helpers()
+    elif "--only-regression-unet" in sys.argv:
         regression_unet()
     else:
         main()
         regression_unet()
+        loss_helpers()

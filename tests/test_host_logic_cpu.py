@@ -74,3 +74,16 @@ def test_batch_sharding_and_rates():
         assert max(sizes) - min(sizes) <= 1
     assert len({P.rank_seed(0, r) for r in range(8)}) == 8
     assert P.whole_job_rate(10, 8, 2.0) == 40.0
+
+
+def test_photometric_loss_helpers_match_reference_goldens():
+    """WP:273-303 (host-side torch functions of the FlowLearner loss): values captured from the reference's warp module."""
+    from conftest import load_golden
+    from opticalflowdiffusion_amd.warp import charbonnier, edgeaware_smoothness1, fill_holes_nan, nan_charbonnier
+    g = load_golden("loss_helpers")
+    c = charbonnier(g["a"])
+    assert torch.equal(torch.isnan(c), torch.isnan(g["charbonnier"])) and torch.allclose(torch.nan_to_num(c), torch.nan_to_num(g["charbonnier"]), rtol=1e-6)
+    assert float(nan_charbonnier(g["a"], g["b"])) == pytest.approx(float(g["nan_charbonnier"]), rel=1e-6)
+    f = fill_holes_nan(g["img"], g["w"])
+    assert torch.equal(torch.isnan(f), torch.isnan(g["fill_holes_nan"])) and torch.equal(torch.nan_to_num(f), torch.nan_to_num(g["fill_holes_nan"]))
+    assert float(edgeaware_smoothness1(g["img"], g["flow"])) == pytest.approx(float(g["edgeaware_smoothness1"]), rel=1e-6)
