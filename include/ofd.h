@@ -60,6 +60,19 @@ int ofd_splat_bwd_in(const float* flow, const float* outgrad, float* ingrad, int
 int ofd_splat_bwd_flow(const float* in, const float* flow, const float* outgrad, float* flowgrad,
                        int B, int C, int H, int W, int scale, int offset_x, int offset_y, void* stream);
 
+/* All L*L offsets of a scale-L splat at once (the photometric pyramid of flow_learner.py:159-206 evaluates every offset of 10
+ * levels on the same image and flow).  T: (B, C, L*(H/L), L*(W/L)) with
+ *     T[n, c, L*cy + b, L*cx + a] = ofd_splat_fwd(..., scale = L, offset_x = a, offset_y = b)[n, c, cy, cx].
+ * One scale-1 splat of the pixels whose targets avoid the reference's border branches for every offset + one separable
+ * tent filter of half-width L + a scatter of the remaining pixels with the reference's own remap; L in 1..16.
+ * bwd: ingrad (B,C,H,W) and / or flowgrad (B,2,H,W) (either may be NULL) = the sums over (a, b) of ofd_splat_bwd_in /
+ * ofd_splat_bwd_flow with the matching slices of dT.  Workspace: ofd_splat_pyramid_workspace_bytes. */
+size_t ofd_splat_pyramid_workspace_bytes(int B, int C, int H, int W);
+int ofd_splat_pyramid_fwd(const float* in, const float* flow, float* T, int B, int C, int H, int W, int L, int radius,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int ofd_splat_pyramid_bwd(const float* in, const float* flow, const float* dT, float* ingrad, float* flowgrad,
+                          int B, int C, int H, int W, int L, void* workspace, size_t workspace_bytes, void* stream);
+
 /* warp_forward_flow pieces (WP:121-156).
  * prep : first (B,C,H,W) -> ten_in (B,C+1,H,W) = cat(nan_to_zero(first) * w, w), w = 0 where any
  *        channel of the pixel is NaN else 1.  square != 0 squares the values (get_variance).

@@ -27,7 +27,15 @@ namespace ofd {
 struct SplatGeom {
     int B, C, H, W, Ho, Wo, scale, ox, oy, radius, ntx, nty;
     int grid;     // 1: targets are grid_sample's un-normalised coordinates (adjoint of warp_backward_flow), scale 1
+    int pyr_L;    // > 0: only the source pixels that are "plain" for every offset of pyramid level pyr_L take part (splat_pyramid)
 };
+
+// Pyramid level L (splat_pyramid below): a source pixel is PLAIN when for every offset (a, b) in [0, L)^2 the reference's
+// remap takes its ordinary branch on both axes (SS:379-381): L - 1 <= x + flow_x < W - 1 and L - 1 <= y + flow_y < H - 1.
+// (x + flow_x - a is exact in fp32 for these magnitudes, so `fltX - fox < 0` is the comparison fltX < a.)
+__device__ __forceinline__ bool pyr_plain(float fltX, float fltY, int L, int H, int W) {
+    return fltX >= (float)(L - 1) && fltX < (float)W - 1.0f && fltY >= (float)(L - 1) && fltY < (float)H - 1.0f;
+}
 
 constexpr int S_TH = 64, S_TW = 64, S_CG = 4, S_NT = 1024;
 constexpr int SKIPPED = -(1 << 30);
@@ -57,6 +65,7 @@ __device__ __forceinline__ bool splat_remap(float flow_x, float flow_y, int x, i
     float fltX = (float)x + flow_x;
     float fltY = (float)y + flow_y;
     if (!isfinite(fltX) || !isfinite(fltY)) return false;
+    if (g.pyr_L > 0 && !pyr_plain(fltX, fltY, g.pyr_L, g.H, g.W)) return false;
     const bool guard = (VARIANT == 0) ? (g.scale > 1) : true;
     const float fW = (float)g.W, fH = (float)g.H, fs = (float)g.scale, fox = (float)g.ox, foy = (float)g.oy;
 
@@ -766,12 +775,174 @@ __global__ void grid_warp_corners_kernel(const float* __restrict__ flow, int32_t
     }
 }
 
+
+// ================================================================================================
+// splat_pyramid: ALL L*L offsets of a scale-L splat in one result.  T (B, C, L*Ho, L*Wo) with
+//     T[n, c, L*cy + b, L*cx + a] = softsplat_out(in, flow, scale = L, offset = (a, b))[n, c, cy, cx]      (SS:352-423)
+// flow_learner.py:159-206 evaluates its photometric loss on every offset of 10 levels: 1052 splats of the same image with the
+// same flow.  For a plain pixel (pyr_plain) the scale-L bilinear weight of output cell (cx, a) is 1 - |L cx + a - fx| / L: the
+// offsets sample one tent of half-width L on the full-resolution grid, and that tent is the scale-1 bilinear pair convolved with
+// the discrete tent t(k) = 1 - |k| / L.  So
+//     T = tent_L (*) splat_scale1(plain pixels)   +   the remaining (border) pixels, scattered with the reference's branches,
+// one scale-1 splat + one separable 2L-1 tap filter per level instead of L*L splats.  The backward is the same identity
+// transposed: G = tent_L (*) dT (zero-extended), then the scale-1 gradient kernels on the plain pixels; border pixels gather
+// with the reference's own backward remaps (SS:515-533, 628-647) per offset.  Plain pixels differ from the reference only in
+// summation order (and it rounds (fx - a) / L before forming the weights): ~1e-6 relative.
+constexpr int PT_W = 64, PT_H = 16, PT_MAXL = 16, PT_HALO = PT_MAXL - 1;
+constexpr int PT_IW = PT_W + 2 * PT_HALO, PT_IH = PT_H + 2 * PT_HALO;
+
+// out (planes, Ho_, Wo_) = tent_L (*) in (planes, Hi, Wi), zero outside the input; out index (y, x) reads in (y - ky, x - kx)
+__global__ void __launch_bounds__(256) tent2d_kernel(const float* __restrict__ in, float* __restrict__ out, int Hi, int Wi, int Ho_, int Wo_, int L) {
+    __shared__ float tile[PT_IH][PT_IW + 1];
+    __shared__ float hrow[PT_IH][PT_W + 1];
+    const size_t plane_i = (size_t)Hi * Wi, plane_o = (size_t)Ho_ * Wo_;
+    const float* ip = in + (size_t)blockIdx.z * plane_i;
+    float* op = out + (size_t)blockIdx.z * plane_o;
+    const int X0 = blockIdx.x * PT_W, Y0 = blockIdx.y * PT_H, h = L - 1;
+    const int iw = PT_W + 2 * h, ih = PT_H + 2 * h;
+    for (int i = threadIdx.x; i < ih * iw; i += 256) {
+        const int r = i / iw, c = i - r * iw;
+        const int y = Y0 - h + r, x = X0 - h + c;
+        tile[r][c] = (y >= 0 && y < Hi && x >= 0 && x < Wi) ? ip[(size_t)y * Wi + x] : 0.0f;
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)L;
+    for (int i = threadIdx.x; i < ih * PT_W; i += 256) {         // horizontal pass
+        const int r = i / PT_W, c = i - r * PT_W;
+        float acc = tile[r][c + h];
+        for (int k = 1; k < L; ++k) acc += (1.0f - (float)k * inv) * (tile[r][c + h - k] + tile[r][c + h + k]);
+        hrow[r][c] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PT_H * PT_W; i += 256) {       // vertical pass
+        const int r = i / PT_W, c = i - r * PT_W;
+        const int y = Y0 + r, x = X0 + c;
+        if (y >= Ho_ || x >= Wo_) continue;
+        float acc = hrow[r + h][c];
+        for (int k = 1; k < L; ++k) acc += (1.0f - (float)k * inv) * (hrow[r + h - k][c] + hrow[r + h + k][c]);
+        op[(size_t)y * Wo_ + x] = acc;
+    }
+}
+
+// compact list of the border pixels of level L (finite target, not plain): one atomic per wave
+__global__ void __launch_bounds__(256) pyramid_border_list_kernel(const float* __restrict__ flow, unsigned int* __restrict__ list,
+                                                                  unsigned int* __restrict__ count, int B, int H, int W, int L) {
+    const size_t plane = (size_t)H * W, total = (size_t)B * plane;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < total; i0 += stride) {      // whole waves stay in the loop (ballot)
+        const size_t i = i0 + threadIdx.x;
+        bool border = false;
+        if (i < total) {
+            const size_t n = i / plane, pix = i % plane;
+            const int y = (int)(pix / W), x = (int)(pix % W);
+            const float fltX = (float)x + flow[n * 2 * plane + pix], fltY = (float)y + flow[n * 2 * plane + plane + pix];
+            border = isfinite(fltX) && isfinite(fltY) && !pyr_plain(fltX, fltY, L, H, W);
+        }
+        const unsigned long long m = __ballot(border);
+        const int lane = threadIdx.x & 63;
+        unsigned base = 0;
+        if (lane == 0 && m) base = atomicAdd(count, (unsigned)__popcll(m));
+        base = __shfl(base, 0, 64);
+        if (border) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i;
+    }
+}
+
+// border pixels of level g.scale, one work item per (pixel, offset): the reference's forward remap, scattered into T
+__global__ void __launch_bounds__(256) pyramid_border_fwd_kernel(const float* __restrict__ in, const float* __restrict__ flow, float* __restrict__ T,
+                                                                 const unsigned int* __restrict__ list, const unsigned int* __restrict__ count,
+                                                                 SplatGeom g) {
+    const size_t plane = (size_t)g.H * g.W;
+    const int L = g.scale, L2 = L * L, Wt = L * g.Wo;
+    const size_t tplane = (size_t)(L * g.Ho) * Wt;
+    const size_t items = (size_t)(*count) * L2;
+    for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = list[it / L2];
+        const int o = (int)(it % L2), a = o % L, b = o / L;
+        const int n = (int)(i / plane);
+        const size_t pix = i % plane;
+        const int y = (int)(pix / g.W), x = (int)(pix % g.W);
+        SplatGeom go = g;
+        go.ox = a; go.oy = b;
+        float fx, fy, d0, d1;
+        if (!splat_remap<0>(flow[(size_t)n * 2 * plane + pix], flow[(size_t)n * 2 * plane + plane + pix], x, y, go, fx, fy, d0, d1)) continue;
+        const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
+        float w[4];
+        corner_weights(fx, fy, x0, y0, w);
+        for (int k = 0; k < 4; ++k) {
+            const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+            if (cx < 0 || cx >= g.Wo || cy < 0 || cy >= g.Ho) continue;
+            const size_t t = (size_t)(L * cy + b) * Wt + (L * cx + a);
+            for (int c = 0; c < g.C; ++c)
+                atomicAdd(&T[((size_t)n * g.C + c) * tplane + t], in[((size_t)n * g.C + c) * plane + pix] * w[k]);
+        }
+    }
+}
+
+// border pixels, backward, one work item per (pixel, offset row b): the reference's ingrad (SS:489-565) and flowgrad (SS:600-700)
+// over the offsets a of that row, added to the zeros the scale-1 kernels wrote for these pixels
+__global__ void __launch_bounds__(256) pyramid_border_bwd_kernel(const float* __restrict__ in, const float* __restrict__ flow, const float* __restrict__ dT,
+                                                                 float* __restrict__ ingrad, float* __restrict__ flowgrad,
+                                                                 const unsigned int* __restrict__ list, const unsigned int* __restrict__ count, SplatGeom g) {
+    const size_t plane = (size_t)g.H * g.W;
+    const int L = g.scale, Wt = L * g.Wo;
+    const size_t tplane = (size_t)(L * g.Ho) * Wt;
+    const size_t items = (size_t)(*count) * L;
+    for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = list[it / L];
+        const int b = (int)(it % L);
+        const int n = (int)(i / plane);
+        const size_t pix = i % plane;
+        const int y = (int)(pix / g.W), x = (int)(pix % g.W);
+        const float f0 = flow[(size_t)n * 2 * plane + pix], f1 = flow[(size_t)n * 2 * plane + plane + pix];
+        SplatGeom go = g;
+        go.oy = b;
+        float gx = 0.0f, gy = 0.0f;
+        for (int c = 0; c < g.C; ++c) {
+            const float v = in ? in[((size_t)n * g.C + c) * plane + pix] : 0.0f;
+            const float* gp = dT + ((size_t)n * g.C + c) * tplane;
+            float acc = 0.0f;
+            for (int a = 0; a < L; ++a) {
+                go.ox = a;
+                float fx, fy, dxx, dyy;
+                if (ingrad && splat_remap<1>(f0, f1, x, y, go, fx, fy, dxx, dyy)) {
+                    const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
+                    float w[4];
+                    corner_weights(fx, fy, x0, y0, w);
+                    for (int k = 0; k < 4; ++k) {
+                        const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+                        if (cx >= 0 && cx < g.Wo && cy >= 0 && cy < g.Ho) acc += gp[(size_t)(L * cy + b) * Wt + (L * cx + a)] * w[k];
+                    }
+                }
+                if (flowgrad && splat_remap<2>(f0, f1, x, y, go, fx, fy, dxx, dyy)) {
+                    const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
+                    const float x1 = (float)(x0 + 1), y1 = (float)(y0 + 1);
+                    const float wx[4] = {-1.0f * (y1 - fy), +1.0f * (y1 - fy), -1.0f * (fy - (float)y0), +1.0f * (fy - (float)y0)};
+                    const float wy[4] = {(x1 - fx) * -1.0f, (fx - (float)x0) * -1.0f, (x1 - fx) * +1.0f, (fx - (float)x0) * +1.0f};
+                    for (int k = 0; k < 4; ++k) {
+                        const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+                        if (cx >= 0 && cx < g.Wo && cy >= 0 && cy < g.Ho) {
+                            const float go_ = gp[(size_t)(L * cy + b) * Wt + (L * cx + a)];
+                            gx += go_ * v * wx[k] * dyy;
+                            gy += go_ * v * wy[k] * dxx;
+                        }
+                    }
+                }
+            }
+            if (ingrad && acc != 0.0f) atomicAdd(&ingrad[((size_t)n * g.C + c) * plane + pix], acc);
+        }
+        if (flowgrad) {
+            if (gx != 0.0f) atomicAdd(&flowgrad[(size_t)n * 2 * plane + pix], gx);
+            if (gy != 0.0f) atomicAdd(&flowgrad[(size_t)n * 2 * plane + plane + pix], gy);
+        }
+    }
+}
+
 static int make_geom(SplatGeom& g, int B, int C, int H, int W, int scale, int ox, int oy, int radius) {
     OFD_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0, "splat: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
     OFD_CHECK_ARG(scale >= 1 && H / scale > 0 && W / scale > 0, "splat: bad scale %d for %dx%d", scale, H, W);
     OFD_CHECK_ARG(ox >= 0 && oy >= 0 && ox < scale && oy < scale, "splat: offset (%d,%d) must be in [0,scale)", ox, oy);
     OFD_CHECK_ARG((size_t)B * H * W < (1ull << 31), "splat: B*H*W must be < 2^31");
-    g = SplatGeom{B, C, H, W, H / scale, W / scale, scale, ox, oy, radius < 0 ? 0 : radius, 0, 0, 0};
+    g = SplatGeom{B, C, H, W, H / scale, W / scale, scale, ox, oy, radius < 0 ? 0 : radius, 0, 0, 0, 0};
     g.ntx = cdiv(g.Wo, S_TW);
     g.nty = cdiv(g.Ho, S_TH);
     return OFD_OK;
@@ -829,6 +1000,80 @@ static int splat_launch(const float* in, const float* flow, float* out, const Sp
         splat_tile_kernel<<<dim3(g.ntx, g.nty, B), S_NT, S_LDS_BYTES, s>>>(in, flow, out, list, count, cap, absmax, g, c0, cg);
     }
     splat_far_kernel<<<256, 256, 0, s>>>(in, flow, out, list, count, cap, g);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" size_t ofd_splat_pyramid_workspace_bytes(int B, int C, int H, int W) {
+    // the splat's own workspace | one (B, C, H, W) fp32 image (scale-1 splat of the plain pixels / filtered gradient)
+    return (ofd_splat_workspace_bytes(B, H, W) + 255) / 256 * 256 + (size_t)B * C * H * W * 4;
+}
+
+extern "C" int ofd_splat_pyramid_fwd(const float* in, const float* flow, float* T, int B, int C, int H, int W, int L, int radius,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    OFD_CHECK_ARG(in && flow && T && workspace, "splat_pyramid_fwd: null pointer");
+    OFD_CHECK_ARG(L >= 1 && L <= PT_MAXL, "splat_pyramid_fwd: level %d (1..%d)", L, PT_MAXL);
+    if (workspace_bytes < ofd_splat_pyramid_workspace_bytes(B, C, H, W)) {
+        set_error("splat_pyramid_fwd: workspace %zu < %zu", workspace_bytes, ofd_splat_pyramid_workspace_bytes(B, C, H, W));
+        return OFD_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SplatGeom g1, gL;
+    int rc = make_geom(g1, B, C, H, W, 1, 0, 0, radius);
+    if (rc) return rc;
+    rc = make_geom(gL, B, C, H, W, L, 0, 0, 0);
+    if (rc) return rc;
+    OFD_CHECK_ARG(g1.nty <= 65535 && B <= 65535 && C <= S_MAXC && (size_t)B * C <= 65535, "splat_pyramid_fwd: grid too large");
+    if (L == 1) return splat_launch(in, flow, T, g1, workspace, s);
+    float* S = (float*)((char*)workspace + (ofd_splat_workspace_bytes(B, H, W) + 255) / 256 * 256);
+    g1.pyr_L = L;
+    rc = splat_launch(in, flow, S, g1, workspace, s);
+    if (rc) return rc;
+    const int Ht = L * gL.Ho, Wt = L * gL.Wo;
+    tent2d_kernel<<<dim3(cdiv(Wt, PT_W), cdiv(Ht, PT_H), B * C), 256, 0, s>>>(S, T, H, W, Ht, Wt, L);
+    // border pixels: compact list in the (now idle) far-corner list area of the splat workspace, counter in its header
+    unsigned int* bcount = (unsigned int*)workspace + 2;
+    unsigned int* blist = (unsigned int*)((char*)workspace + 16 + (size_t)B * S_MAXC * 4);
+    OFD_HIP(hipMemsetAsync(bcount, 0, 4, s));
+    pyramid_border_list_kernel<<<stream_grid((size_t)B * H * W, 256), 256, 0, s>>>(flow, blist, bcount, B, H, W, L);
+    pyramid_border_fwd_kernel<<<4096, 256, 0, s>>>(in, flow, T, blist, bcount, gL);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" int ofd_splat_pyramid_bwd(const float* in, const float* flow, const float* dT, float* ingrad, float* flowgrad, int B, int C, int H,
+                                     int W, int L, void* workspace, size_t workspace_bytes, void* stream) {
+    OFD_CHECK_ARG(flow && dT && (ingrad || flowgrad) && workspace, "splat_pyramid_bwd: null pointer");
+    OFD_CHECK_ARG(!flowgrad || in, "splat_pyramid_bwd: the flow gradient needs the input");
+    OFD_CHECK_ARG(L >= 1 && L <= PT_MAXL, "splat_pyramid_bwd: level %d (1..%d)", L, PT_MAXL);
+    if (workspace_bytes < ofd_splat_pyramid_workspace_bytes(B, C, H, W)) {
+        set_error("splat_pyramid_bwd: workspace %zu < %zu", workspace_bytes, ofd_splat_pyramid_workspace_bytes(B, C, H, W));
+        return OFD_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SplatGeom g1, gL;
+    int rc = make_geom(g1, B, C, H, W, 1, 0, 0, 0);
+    if (rc) return rc;
+    rc = make_geom(gL, B, C, H, W, L, 0, 0, 0);
+    if (rc) return rc;
+    OFD_CHECK_ARG((size_t)B * C <= 65535, "splat_pyramid_bwd: grid too large");
+    const float* G = dT;
+    if (L > 1) {
+        float* Gb = (float*)((char*)workspace + (ofd_splat_workspace_bytes(B, H, W) + 255) / 256 * 256);
+        tent2d_kernel<<<dim3(cdiv(W, PT_W), cdiv(H, PT_H), B * C), 256, 0, s>>>(dT, Gb, L * gL.Ho, L * gL.Wo, H, W, L);
+        G = Gb;
+        g1.pyr_L = L;
+    }
+    const int grid = stream_grid((size_t)B * H * W, 256);
+    if (ingrad) splat_ingrad_kernel<<<grid, 256, 0, s>>>(flow, G, ingrad, g1);
+    if (flowgrad) splat_flowgrad_kernel<<<grid, 256, 0, s>>>(in, flow, G, flowgrad, g1);
+    if (L > 1) {
+        unsigned int* bcount = (unsigned int*)workspace + 2;
+        unsigned int* blist = (unsigned int*)((char*)workspace + 16 + (size_t)B * S_MAXC * 4);
+        OFD_HIP(hipMemsetAsync(bcount, 0, 4, s));
+        pyramid_border_list_kernel<<<grid, 256, 0, s>>>(flow, blist, bcount, B, H, W, L);
+        pyramid_border_bwd_kernel<<<4096, 256, 0, s>>>(in, flow, dT, ingrad, flowgrad, blist, bcount, gL);
+    }
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

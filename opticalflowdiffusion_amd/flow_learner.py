@@ -11,8 +11,8 @@ import torch
 
 from .denoising_diffusion import Unet
 from .flow_diffuser import UnetWithWarp, _Base, _Cfg
-from .softsplat import softsplat
-from .warp import edgeaware_smoothness1, fill_holes_nan, nan_charbonnier
+from .softsplat import pyramid_offsets, softsplat, softsplat_pyramid
+from .warp import charbonnier, edgeaware_smoothness1, fill_holes_nan, nan_charbonnier
 
 LEVELS = (1, 2, 4, 5, 7, 8, 10, 11, 14, 16)          # FL:163
 
@@ -40,6 +40,24 @@ def photometric_pyramid_loss(input_img, flow_pred, warp_weights, tgt, levels=LEV
     return sum(photo) / len(photo)
 
 
+def photometric_pyramid_loss_fused(input_img, flow_pred, warp_weights, tgt, levels=LEVELS):
+    """The same loss with ONE pyramid splat per level and image (softsplat.splat_pyramid: scale-1 splat + tent filter + border
+    scatter) instead of L*L splats, and the per-offset Charbonnier means as batched reductions over the (a, b) axes."""
+    zero_flow = torch.zeros_like(flow_pred)
+    ones = torch.ones_like(warp_weights)
+    photo = []
+    for level in levels:
+        sw = pyramid_offsets(softsplat_pyramid(input_img, flow_pred, warp_weights, "soft", level), level)      # (a, b, B, 4, Ho, Wo)
+        filled = fill_holes_nan(sw[:, :, :, :-1], sw[:, :, :, -1:])
+        dt = pyramid_offsets(softsplat_pyramid(tgt, zero_flow, ones, "soft", level), level)[:, :, :, :-1]
+        ok = torch.logical_not(torch.logical_or(torch.isnan(dt), torch.isnan(filled)))
+        diff = torch.where(ok, dt - filled, torch.zeros_like(dt))
+        pen = torch.where(ok, charbonnier(diff), torch.zeros_like(dt))
+        per_offset = pen.sum(dim=(2, 3, 4, 5)) / ok.sum(dim=(2, 3, 4, 5))        # nan_charbonnier of every (a, b)
+        photo.append(per_offset.mean())
+    return sum(photo) / len(photo)
+
+
 class FlowLearner(_Base):
     """FL:62-424, flow representation."""
 
@@ -53,6 +71,8 @@ class FlowLearner(_Base):
         self.flow_max = cfg.flow_max
         self.rep = "flow"
         self.levels = tuple(cfg.levels) if "levels" in cfg else LEVELS
+        # pyramid: "fused" (one pyramid splat per level) or "loop" (the reference's L*L splats per level)
+        self.pyramid = cfg.pyramid if "pyramid" in cfg else "fused"
         # 3 outputs: optical flow + the splat weight map (FL:93-98)
         self.unet = UnetWithWarp(cfg, Unet(64, channels=6, out_dim=3, time_in=False, precision=cfg.precision), False, nan_safe=False)
         self.model = self.unet
@@ -81,7 +101,8 @@ class FlowLearner(_Base):
             flow_pred = override_flow * self.flow_max
             warp_weights = torch.ones_like(flow_pred[:, :1])
         input_img = cond[:, :3]
-        loss = photometric_pyramid_loss(input_img, flow_pred, warp_weights, tgt, self.levels)
+        pyr = photometric_pyramid_loss_fused if self.pyramid == "fused" else photometric_pyramid_loss
+        loss = pyr(input_img, flow_pred, warp_weights, tgt, self.levels)
         return loss + edgeaware_smoothness1(input_img, flow_pred) * 0.01    # FL:208-209
 
     def sample(self, cond, flo, log_additional=False):                      # FL:235-248

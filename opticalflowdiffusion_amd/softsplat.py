@@ -8,6 +8,9 @@ import torch
 
 from . import _lib as L
 
+L_mod = L
+_lib_f32 = L.f32c
+
 # scan radius (source pixels) of an output tile; FlowDiffuser clamps flow to +-flow_max = 20 px
 # (flow_diffuser.py:141). Larger displacements stay correct through the far-corner list.
 DEFAULT_RADIUS = 24
@@ -95,6 +98,82 @@ def softsplat(tenIn, tenFlow, tenMetric, strMode, scale=1, offset=(0, 0)):
 
     tenOut = softsplat_func.apply(tenIn, tenFlow, scale, offset[0], offset[1])
 
+    if base in ["avg", "linear", "soft"]:
+        tenNormalize = tenOut[:, -1:, :, :]
+        parts = strMode.split("-")
+        if len(parts) == 1 or parts[1] == "addeps":
+            tenNormalize = tenNormalize + 0.0000001
+        elif parts[1] == "zeroeps":
+            tenNormalize = tenNormalize.clone()
+            tenNormalize[tenNormalize == 0.0] = 1.0
+        elif parts[1] == "clipeps":
+            tenNormalize = tenNormalize.clip(0.0000001, None)
+        return torch.cat((tenOut[:, :-1, :, :] / tenNormalize, tenOut[:, -1, None, :, :]), dim=1)
+    return tenOut
+
+
+# ---- all L*L offsets of a scale-L splat in one call (the FlowLearner pyramid, flow_learner.py:159-206) -------------------------
+class _PyramidSplat(torch.autograd.Function):
+    """T[n, c, L*cy + b, L*cx + a] = softsplat_func(tenIn, tenFlow, L, a, b)[n, c, cy, cx] for every offset (a, b)."""
+
+    @staticmethod
+    def forward(ctx, tenIn, tenFlow, L):
+        L_ = int(L)
+        tenIn, tenFlow = _lib_f32(tenIn), _lib_f32(tenFlow)
+        B, C, H, W = tenIn.shape
+        out = torch.empty(B, C, L_ * (H // L_), L_ * (W // L_), dtype=torch.float32, device=tenIn.device)
+        lib = L_mod.lib()
+        ws = _workspace(tenIn.device, lib.ofd_splat_pyramid_workspace_bytes(B, C, H, W))
+        L_mod.check(lib.ofd_splat_pyramid_fwd(L_mod.ptr(tenIn), L_mod.ptr(tenFlow), L_mod.ptr(out), B, C, H, W, L_, DEFAULT_RADIUS,
+                                              L_mod.ptr(ws), ws.numel(), L_mod.stream()))
+        ctx.save_for_backward(tenIn, tenFlow)
+        ctx.level = L_
+        return out
+
+    @staticmethod
+    def backward(ctx, dT):
+        tenIn, tenFlow = ctx.saved_tensors
+        B, C, H, W = tenIn.shape
+        dT = _lib_f32(dT)
+        need_in, need_flow = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        ingrad = torch.empty_like(tenIn) if need_in else None
+        flowgrad = torch.empty_like(tenFlow) if need_flow else None
+        if need_in or need_flow:
+            lib = L_mod.lib()
+            ws = _workspace(tenIn.device, lib.ofd_splat_pyramid_workspace_bytes(B, C, H, W))
+            L_mod.check(lib.ofd_splat_pyramid_bwd(L_mod.ptr(tenIn), L_mod.ptr(tenFlow), L_mod.ptr(dT), L_mod.ptr(ingrad), L_mod.ptr(flowgrad),
+                                                  B, C, H, W, ctx.level, L_mod.ptr(ws), ws.numel(), L_mod.stream()))
+        return ingrad, flowgrad, None
+
+
+def splat_pyramid(tenIn, tenFlow, level):
+    """(B, C, L*(H//L), L*(W//L)): every offset of the scale-`level` splat, interleaved (see `pyramid_offsets`)."""
+    L_mod.require_gpu(tenIn, tenFlow)
+    return _PyramidSplat.apply(tenIn, tenFlow, level)
+
+
+def pyramid_offsets(T, level):
+    """view of splat_pyramid's result as (a, b, B, C, H//L, W//L): [a, b] is the splat with offset=[a, b]."""
+    B, C, Ht, Wt = T.shape
+    return T.view(B, C, Ht // level, level, Wt // level, level).permute(5, 3, 0, 1, 2, 4)
+
+
+def softsplat_pyramid(tenIn, tenFlow, tenMetric, strMode, scale):
+    """`softsplat(tenIn, tenFlow, tenMetric, strMode, scale, offset=[a, b])` for ALL offsets at once, interleaved as
+    splat_pyramid does (softsplat_new.py:278-333: same modes and normalisation)."""
+    base = strMode.split("-")[0]
+    assert base in ["sum", "avg", "linear", "soft", "linear_unn"]
+    if strMode in ("sum", "avg"):
+        assert tenMetric is None
+    if base in ("linear", "linear_unn", "soft"):
+        assert tenMetric is not None
+    if strMode == "avg":
+        tenIn = torch.cat([tenIn, tenIn.new_ones([tenIn.shape[0], 1, tenIn.shape[2], tenIn.shape[3]])], 1)
+    elif base in ("linear", "linear_unn"):
+        tenIn = torch.cat([tenIn * tenMetric, tenMetric], 1)
+    elif base == "soft":
+        tenIn = torch.cat([tenIn * tenMetric.exp(), tenMetric.exp()], 1)
+    tenOut = splat_pyramid(tenIn, tenFlow, scale)
     if base in ["avg", "linear", "soft"]:
         tenNormalize = tenOut[:, -1:, :, :]
         parts = strMode.split("-")
