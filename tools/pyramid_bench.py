@@ -23,7 +23,10 @@ def timed(fn, n):
 
 def main():
     from opticalflowdiffusion_amd.flow_learner import LEVELS, photometric_pyramid_loss, photometric_pyramid_loss_fused
-    for (B, H, W, n_loop) in [(16, 128, 128, 1), (16, 440, 1024, 0)]:
+    cases = [(16, 128, 128, 1), (16, 440, 1024, 0)]
+    if "--full-only" in sys.argv:
+        cases = cases[1:]
+    for (B, H, W, n_loop) in cases:
         torch.manual_seed(0)
         img = torch.rand(B, 3, H, W, device="cuda") * 2 - 1
         tgt = torch.rand(B, 3, H, W, device="cuda") * 2 - 1
