@@ -364,3 +364,23 @@ def test_exported_building_blocks(L):
     assert rel_l2(got, F.group_norm(h, 8, gamma, beta, 1e-5)) < 1e-4
     hg = h.view(B, 8, -1)
     assert torch.allclose(st.cpu()[..., 0], hg.mean(-1), atol=1e-4) and torch.allclose(st.cpu()[..., 1], (hg.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-3)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 8, 8), (2, 8, 40), (3, 40, 8), (1, 104, 200)])
+def test_unet_awkward_shapes_inference_and_training_forward(L, B, H, W):
+    """smallest legal image (one pixel at the coarsest level), single tile rows/columns, sizes that leave partial tiles at every
+    level: both executors follow the bf16c oracle and every gradient is finite (tools/shape_sweep.py runs a longer list)."""
+    from opticalflowdiffusion_amd import Unet
+    torch.manual_seed(12)
+    net = Unet(64, channels=5, out_dim=2).cuda()
+    P = {n: p.detach().cpu().clone() for n, p in net.named_parameters()}
+    x = torch.randn(B, 2, H, W)
+    cond = torch.rand(B, 3, H, W) * 2 - 1
+    t = torch.randint(0, 1000, (B,))
+    with torch.no_grad():
+        ref = R.unet_forward(P, x, cond, t, mode="bf16c")
+        out = net(x.cuda(), cond.cuda(), t.cuda()).cpu()
+    out_t = net(x.cuda(), external_cond=cond.cuda(), time=t.cuda())
+    out_t.sum().backward()
+    assert rel_l2(out, ref) < 2e-2 and rel_l2(out_t.detach().cpu(), ref) < 2e-2
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
