@@ -148,6 +148,10 @@ def broadcast_parameters(module, src=0, group=None):
 
 def attach_grad_sync(flow_diffuser_or_unet, bucket_bytes=32 << 20, group=None):
     """data-parallel training: average the UNet's gradients across ranks inside every backward."""
-    unet = getattr(flow_diffuser_or_unet, "unet", flow_diffuser_or_unet)
-    unet.grad_sync = BucketedAllReduce(bucket_bytes, group)
-    return unet.grad_sync
+    from .denoising_diffusion import Unet
+    root = flow_diffuser_or_unet
+    unets = [m for m in root.modules() if isinstance(m, Unet)] if isinstance(root, torch.nn.Module) else []
+    if len(unets) != 1:        # FlowDiffuser.unet, FlowLearner.unet.model (inside UnetWithWarp), or a bare Unet
+        raise ValueError(f"attach_grad_sync: expected exactly one engine Unet under the module, found {len(unets)}")
+    unets[0].grad_sync = BucketedAllReduce(bucket_bytes, group)
+    return unets[0].grad_sync

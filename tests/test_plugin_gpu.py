@@ -166,7 +166,7 @@ def test_flow_diffuser_training_steps_reduce_the_loss():
         opt.zero_grad()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < 0.7 * losses[0] and max(losses) < 1.5 * losses[0], losses
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in fd.unet.parameters())
 

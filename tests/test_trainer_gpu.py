@@ -44,6 +44,24 @@ def test_checkpoint_layout_and_resume(tmp_path, capsys):
     assert all(json.loads(ln)["world"] == 1 for ln in out.strip().splitlines())
 
 
+def test_trainer_runs_flow_learner_and_grad_sync_attaches_to_its_unet(tmp_path):
+    """`algorithm.name=flow_learner` (exp_99.py:22-28): the regression UNet + photometric pyramid through the same trainer; the
+    checkpoint carries the reference's key prefixes (unet.model.* / model.model.*, FL:93-99); attach_grad_sync finds the engine
+    UNet inside UnetWithWarp."""
+    import train
+    from opticalflowdiffusion_amd import FlowLearner, Unet, parallel
+    d = str(tmp_path / "ck")
+    fl, logs = train.main(["--steps", "3", "--log-every", "1", "--ckpt-dir", d, "--set", "algorithm.name=flow_learner",
+                           "algorithm.image_size=[32,48]", "algorithm.levels=[1,2,4]", "algorithm.zero_init=false",
+                           "experiment.training.data.batch_size=2"])
+    assert isinstance(fl, FlowLearner) and len(logs) == 3 and all(r["loss"] == r["loss"] for r in logs)
+    ck = torch.load(os.path.join(d, "last.ckpt"), map_location="cpu", weights_only=False)
+    keys = set(ck["state_dict"])
+    assert "unet.model.final_conv.weight" in keys and "model.model.final_conv.weight" in keys and not any("time_mlp" in k for k in keys)
+    sync = parallel.attach_grad_sync(fl)
+    assert isinstance(fl.unet.model, Unet) and fl.unet.model.grad_sync is sync
+
+
 def _dp_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       OFD_DIST_BACKEND="gloo")

@@ -20,7 +20,7 @@ import time
 import torch
 import yaml
 
-from opticalflowdiffusion_amd import FlowDiffuser, parallel
+from opticalflowdiffusion_amd import FlowDiffuser, FlowLearner, parallel
 from opticalflowdiffusion_amd.data import SyntheticFlowPairs
 
 DEFAULTS = {
@@ -34,6 +34,10 @@ DEFAULTS = {
                   "target": "joint", "ae": "px8q8g0m", "noiser": "image", "zero_init": True},
     "dataset": {"name": "synthetic", "length": 1 << 20, "seed": 0},
 }
+# configurations/algorithm/flow_learner.yaml; selected with --set algorithm.name=flow_learner (experiments/exp_99.py:22-28)
+FLOW_LEARNER = {"name": "flow_learner", "image_size": [128, 128], "flow_max": 20, "latent": False, "zero_init": True, "c2f": False, "lr": 8e-5,
+                "weight_decay": 1e-6, "sparsity_weight": 0.0, "occlusion_mask": True, "train_aug": True}
+ALGORITHMS = {"flow_diffuser": FlowDiffuser, "flow_learner": FlowLearner}
 
 
 def deep_update(d, u):
@@ -84,6 +88,8 @@ def main(argv=None):
     cfg = json.loads(json.dumps(DEFAULTS))
     if a.config:
         deep_update(cfg, yaml.safe_load(open(a.config)) or {})
+    if any(kv.replace(" ", "") == "algorithm.name=flow_learner" for kv in a.set):
+        cfg["algorithm"] = dict(FLOW_LEARNER)
     for kv in a.set:
         k, v = kv.split("=", 1)
         set_path(cfg, k, v)
@@ -98,7 +104,7 @@ def main(argv=None):
     parallel.init(device=dev)
     torch.manual_seed(parallel.rank_seed(a.seed, rank))
 
-    fd = FlowDiffuser(alg).to(dev)
+    fd = ALGORITHMS[alg.get("name", "flow_diffuser")](alg).to(dev)
     parallel.broadcast_parameters(fd)
     if world > 1:
         parallel.attach_grad_sync(fd)
