@@ -41,9 +41,11 @@ def cpu_baseline(H, W, batch):
     t = torch.tensor([999])
     with torch.no_grad():
         R.unet_forward(P, x[:, :, :64, :64], cond[:, :, :64, :64], t, mode="fp32")   # warm-up of the op set
+        reps = int(os.environ.get("OFD_CPU_REPS", 3))       # >= 3 timed forwards; ~20 s of CPU work in all
         t0 = time.time()
-        R.unet_forward(P, x, cond, t, mode="fp32")
-        dt = time.time() - t0
+        for _ in range(reps):
+            R.unet_forward(P, x, cond, t, mode="fp32")
+        dt = (time.time() - t0) / reps
     model = "unknown"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -53,7 +55,7 @@ def cpu_baseline(H, W, batch):
     except OSError:
         pass
     return {"value": 1.0 / (dt * batch), "unit": "denoise_steps/s", "cores": torch.get_num_threads(), "cpu_model": model, "kind": "port",
-            "sample": f"1 of {batch} samples: one fp32 UNet forward at 1x5x{H}x{W} in {dt:.1f} s, scaled x{batch}"}
+            "sample": f"1 of {batch} samples: fp32 UNet forward at 1x5x{H}x{W}, mean of {reps} runs = {dt:.1f} s, scaled x{batch}"}
 
 
 TRAIN_TFLOP_PER_SAMPLE = 4.8917       # fwd + bwd = 2.99 x fwd (ch=5 @ 440x1024)
