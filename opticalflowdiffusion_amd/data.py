@@ -81,3 +81,64 @@ class SyntheticFlowPairs(torch.utils.data.Dataset):
         """`count` consecutive samples (wrapping around) stacked on `device` -- the input pipeline of train.py: generating on
         the GPU keeps the host out of the step (the CPU box filters cost 50 ms per sample)."""
         return tuple(torch.stack(x) for x in zip(*(self.sample((first + k) % self.length, device) for k in range(count))))
+
+
+class SintelPairs(torch.utils.data.Dataset):
+    """MPI-Sintel frame pairs in the reference's batch contract.  Directory layout of the public archive:
+    `<root>/training/<render>/<scene>/frame_NNNN.png` and `<root>/training/flow/<scene>/frame_NNNN.flo` (flow of frame N -> N+1).
+    Item i = (frame N, frame N+1, flow N) as `(img in [0,1] (3,H,W), tgt (3,H,W), flow px (2,H,W), channel 0 = x)` -- the
+    `(frame2, frame3, flow)` triple the reference's loader builds (datasets/animation/sintel.py:22-50, 68-104), without its
+    hard-coded paths and ImageNet normalisation (FlowDiffuser.preprocess expects [0,1], FD:150).  `image_size=(H, W)` resizes
+    bilinearly and rescales the flow vectors (flo_to_tensor); `pad_to=8` pads H, W up to multiples of 8 by edge replication for the
+    images and zeros for the flow (436 -> 440: three 2x down-samplings in the UNet, DD:95-99)."""
+
+    def __init__(self, root, render="clean", scenes=None, image_size=None, pad_to=8):
+        import os
+        self.image_size, self.pad_to = (tuple(image_size) if image_size else None), int(pad_to)
+        frames_root = os.path.join(root, "training", render)
+        flow_root = os.path.join(root, "training", "flow")
+        if not os.path.isdir(frames_root) or not os.path.isdir(flow_root):
+            raise FileNotFoundError(f"{root}: expected training/{render}/<scene>/frame_NNNN.png and training/flow/<scene>/frame_NNNN.flo")
+        self.items = []
+        for scene in sorted(os.listdir(flow_root)):
+            if scenes is not None and scene not in scenes:
+                continue
+            for fn in sorted(os.listdir(os.path.join(flow_root, scene))):
+                if not fn.endswith(".flo"):
+                    continue
+                n = int(fn[len("frame_"):-len(".flo")])
+                a = os.path.join(frames_root, scene, f"frame_{n:04d}.png")
+                b = os.path.join(frames_root, scene, f"frame_{n + 1:04d}.png")
+                if os.path.exists(a) and os.path.exists(b):
+                    self.items.append((a, b, os.path.join(flow_root, scene, fn)))
+        if not self.items:
+            raise FileNotFoundError(f"{root}: no (frame, next frame, flow) triples found")
+
+    def __len__(self):
+        return len(self.items)
+
+    @staticmethod
+    def _png(path):
+        from PIL import Image
+        with Image.open(path) as im:
+            a = np.asarray(im.convert("RGB"), dtype=np.float32) / 255.0
+        return torch.from_numpy(a).permute(2, 0, 1).contiguous()
+
+    def __getitem__(self, i):
+        pa, pb, pf = self.items[i]
+        img, tgt = self._png(pa), self._png(pb)
+        flow_hw2 = read_flo(pf)
+        if tuple(flow_hw2.shape[:2]) != tuple(img.shape[-2:]):
+            raise ValueError(f"{pf}: flow {flow_hw2.shape[:2]} does not match frame {tuple(img.shape[-2:])}")
+        if self.image_size is not None:
+            img = torch.nn.functional.interpolate(img[None], size=self.image_size, mode="bilinear", align_corners=False)[0]
+            tgt = torch.nn.functional.interpolate(tgt[None], size=self.image_size, mode="bilinear", align_corners=False)[0]
+        flow = flo_to_tensor(flow_hw2, self.image_size)
+        if self.pad_to > 1:
+            h, w = img.shape[-2:]
+            ph, pw = (-h) % self.pad_to, (-w) % self.pad_to
+            if ph or pw:
+                img = torch.nn.functional.pad(img[None], (0, pw, 0, ph), mode="replicate")[0]
+                tgt = torch.nn.functional.pad(tgt[None], (0, pw, 0, ph), mode="replicate")[0]
+                flow = torch.nn.functional.pad(flow, (0, pw, 0, ph))
+        return img, tgt, flow

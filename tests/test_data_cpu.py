@@ -57,3 +57,36 @@ def test_synthetic_pairs_contract():
     assert not torch.equal(flow, ds[5][2])
     with pytest.raises(IndexError):
         ds[10]
+
+
+def test_sintel_pairs_adapter(tmp_path):
+    """a miniature MPI-Sintel tree: (frame N, frame N+1, flow N) triples in the reference's batch contract, padded 436 -> 440
+    style (here 10 -> 16), resized with rescaled vectors on request"""
+    from PIL import Image
+    from opticalflowdiffusion_amd.data import SintelPairs, write_flo
+    root = tmp_path / "MPI_Sintel"
+    rng = np.random.default_rng(3)
+    frames = {}
+    for scene, n in (("alley_1", 3), ("bamboo_2", 2)):
+        (root / "training" / "clean" / scene).mkdir(parents=True)
+        (root / "training" / "flow" / scene).mkdir(parents=True)
+        for k in range(1, n + 1):
+            a = rng.integers(0, 256, size=(10, 12, 3), dtype=np.uint8)
+            frames[(scene, k)] = a
+            Image.fromarray(a).save(root / "training" / "clean" / scene / f"frame_{k:04d}.png")
+        for k in range(1, n):
+            write_flo(root / "training" / "flow" / scene / f"frame_{k:04d}.flo", np.full((10, 12, 2), [k, -k], np.float32))
+    ds = SintelPairs(str(root))
+    assert len(ds) == 3                                           # alley_1: frames (1,2), (2,3); bamboo_2: (1,2)
+    img, tgt, flow = ds[1]
+    assert img.shape == tgt.shape == (3, 16, 16) and flow.shape == (2, 16, 16)
+    assert torch.equal(img[:, :10, :12], torch.from_numpy(frames[("alley_1", 2)]).permute(2, 0, 1).float() / 255.0)
+    assert torch.equal(tgt[:, :10, :12], torch.from_numpy(frames[("alley_1", 3)]).permute(2, 0, 1).float() / 255.0)
+    assert torch.equal(img[:, 10:, :12], img[:, 9:10, :12].expand(-1, 6, -1))          # edge replication
+    assert float(flow[0, 0, 0]) == 2.0 and float(flow[1, 0, 0]) == -2.0 and float(flow[:, 10:].abs().max()) == 0.0
+    small = SintelPairs(str(root), scenes=["bamboo_2"], image_size=(20, 24), pad_to=1)
+    i2, _, f2 = small[0]
+    assert len(small) == 1 and i2.shape == (3, 20, 24) and f2.shape == (2, 20, 24)
+    assert float(f2[0, 5, 5]) == pytest.approx(2.0) and float(f2[1, 5, 5]) == pytest.approx(-2.0)   # vectors rescaled by 24/12, 20/10
+    with pytest.raises(FileNotFoundError):
+        SintelPairs(str(tmp_path / "nothing"))
