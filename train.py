@@ -21,7 +21,7 @@ import torch
 import yaml
 
 from opticalflowdiffusion_amd import FlowDiffuser, FlowLearner, parallel
-from opticalflowdiffusion_amd.data import SyntheticFlowPairs
+from opticalflowdiffusion_amd.data import SintelPairs, SyntheticFlowPairs
 
 DEFAULTS = {
     # configurations/experiment/base.yaml + matrix_flow.yaml
@@ -113,6 +113,14 @@ def main(argv=None):
 
     B = int(tr["data"]["batch_size"])
     ds = SyntheticFlowPairs(cfg["dataset"].get("length", 1 << 20), H, W, flow_max=float(alg["flow_max"]), seed=cfg["dataset"].get("seed", 0))
+    if cfg["dataset"].get("name") == "sintel":        # --set dataset.name=sintel dataset.root=/path/to/MPI_Sintel
+        files = SintelPairs(cfg["dataset"]["root"], render=cfg["dataset"].get("render", "clean"), image_size=(H, W))
+
+        class _Batches:
+            def batch(self, first, count, device):
+                items = [files[(first + k) % len(files)] for k in range(count)]
+                return tuple(torch.stack(t).to(device, non_blocking=True) for t in zip(*items))
+        ds = _Batches()
     accum = int(tr["optim"].get("accumulate_grad_batches", 1))
     every = int((tr.get("checkpointing") or {}).get("every_n_train_steps", 0) or 0)
     t_last, logs = time.perf_counter(), []
