@@ -37,6 +37,10 @@ struct WgradParams {
     const bf16_t* dy;
     float* dw;           // [taps][Cin_total][Cout] fp32, accumulated with atomics (zeroed by the caller)
     float* dbias;        // optional [Cout]: += column sums of dY (workgroups of the first ci block add them)
+    // 3x3 only: X = SiLU(x * in_scale[b][c] + in_shift[b][c]) applied while the halo tile is staged (the forward conv's
+    // GroupNorm-affine + SiLU prologue): the weight gradient of a block's second conv reads h1 instead of a materialised act1
+    const float* in_scale;
+    const float* in_shift;
 };
 
 // column sums of a staged dY tile [256 pixels][64 co] (128-byte rows): thread -> (co, quarter of the pixels)
@@ -152,6 +156,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams P) {
 // (ci block, co block): 248 flop per byte, against 83 for one kernel row per workgroup.  The halo rows are
 // walked once; a halo row rr feeds output rows rr, rr-1, rr-2 (ky = 0, 1, 2), whose dY fragments stay in a
 // three-row register window: 8 fragment reads per 18 MFMAs.
+template <bool PRO>      // PRO: SiLU(affine) prologue on the staged input (its own instantiation: the plain one keeps its register budget)
 __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P) {
     constexpr int IWK = 34, XROWS = 10, XPIX = XROWS * IWK, YPIX = 256;
     constexpr int XPT = (XPIX * 8 + 255) / 256, YPT = YPIX * 8 / 256;
@@ -198,10 +203,26 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
             xr[i] = *(const u32x4*)(xbase + ((size_t)sy * S.SW + sx) * S.src_channels);
         }
         __syncthreads();     // previous tile's operand reads are complete
+        float ps[8], pb[8];
+        if constexpr (PRO) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ps[j] = P.in_scale[(size_t)b * P.Cin_total + kc * 64 + c8 * 8 + j];
+                pb[j] = P.in_shift[(size_t)b * P.Cin_total + kc * 64 + c8 * 8 + j];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
             const int p = (tid >> 3) + i * 32;
             u32x4 v = xr[i];
+            if constexpr (PRO) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float z0 = bf2f((bf16_t)(v[j] & 0xffffu)) * ps[2 * j] + pb[2 * j];
+                    const float z1 = bf2f((bf16_t)(v[j] >> 16)) * ps[2 * j + 1] + pb[2 * j + 1];
+                    v[j] = f2bf2(z0 * __builtin_amdgcn_rcpf(1.0f + __expf(-z0)), z1 * __builtin_amdgcn_rcpf(1.0f + __expf(-z1)));
+                }
+            }
             const bool ok = (xok >> i) & 1u;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
@@ -505,6 +526,8 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
         cin += s_.channels;
     }
     P.Cin_total = cin; P.dy = dy; P.dw = dw; P.dbias = dbias;
+    OFD_CHECK_ARG(!a->in_scale || (a->in_shift && a->ksize == 3), "conv_wgrad: the input prologue is a 3x3 feature");
+    P.in_scale = a->in_scale; P.in_shift = a->in_shift;
     const int ntiles = P.tiles_x * P.tiles_y * P.B, combos = (cin / 64) * (a->Cout / 64);
     int gx = cdiv(1024, combos * a->ksize);     // ~4 workgroups per CU in total; each walks ntiles / gx pixel tiles
     if (gx < 1) gx = 1;
@@ -513,11 +536,16 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
     if (a->ksize == 3) {
         constexpr int LDS = 10 * 34 * 128 + 256 * 128;
         static bool attr = false;
-        if (!attr) { OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+        if (!attr) {
+            OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            attr = true;
+        }
         gx = cdiv(512, combos);                  // two workgroups per CU fit (75.5 KB LDS each)
         if (gx < 1) gx = 1;
         if (gx > ntiles) gx = ntiles;
-        conv_wgrad3_kernel<<<dim3(gx, combos), 256, LDS, s>>>(P);
+        if (P.in_scale) conv_wgrad3_kernel<true><<<dim3(gx, combos), 256, LDS, s>>>(P);
+        else conv_wgrad3_kernel<false><<<dim3(gx, combos), 256, LDS, s>>>(P);
     } else {
         constexpr int LDS = 8 * 32 * 128 + 256 * 128;
         static bool attr = false;
