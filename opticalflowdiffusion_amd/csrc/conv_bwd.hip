@@ -151,6 +151,84 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams P) {
     }
 }
 
+
+// 1x1, Cout = 384 (LinearAttention / Attention to_qkv, DD:222,252): dW[ci][co] = sum_p X[p][ci] dY[p][co] is a reduction over
+// millions of pixels into a 64..512 x 384 matrix.  The generic kernel above gives a workgroup one 64 x 64 block of it, so dY
+// (5.5 GB at full resolution) is re-read per ci block and X per co block, with 16 MFMAs per wave for 64 KB of staged operands.
+// Here a workgroup owns one ci block and ALL 384 output channels (wave -> 64 ci x 96 co = 6 accumulator tiles): every pixel's
+// dY row is read once per ci block, X once; 5 fragment reads per 6 MFMAs.  Pixels are walked as a flat [npix][C] array in
+// tiles of 64.
+constexpr int WQ_PX = 64, WQ_CO = 384, WQ_YP = WQ_CO * 2 + 64;      // dY row pitch: 16 dwords (mod 64 banks) apart
+__global__ void __launch_bounds__(256, 2) conv_wgrad1_qkv_kernel(const bf16_t* __restrict__ x, int x_stride, const bf16_t* __restrict__ dy,
+                                                                 float* __restrict__ dw, size_t npix, int Cin_total) {
+    __shared__ __attribute__((aligned(16))) unsigned char xs[WQ_PX * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char ys[WQ_PX * WQ_YP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int kc = blockIdx.y;
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.0f;
+    const size_t ntiles = (npix + WQ_PX - 1) / WQ_PX;
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const size_t p0 = t * WQ_PX;
+        u32x4 xr[2], yr[12];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                     // X tile: 64 pixels x 8 units
+            const int u = tid + i * 256, p = u >> 3, c8 = u & 7;
+            const size_t gp = min(p0 + p, npix - 1);
+            xr[i] = *(const u32x4*)(x + gp * x_stride + kc * 64 + c8 * 8);
+            if (p0 + p >= npix) xr[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {                    // dY tile: 64 pixels x 48 units
+            const int u = tid + i * 256, p = u / 48, c8 = u - p * 48;
+            const size_t gp = min(p0 + p, npix - 1);
+            yr[i] = *(const u32x4*)(dy + gp * WQ_CO + c8 * 8);
+            if (p0 + p >= npix) yr[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+        __syncthreads();                                  // previous tile's fragment reads are complete
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = tid + i * 256;
+            *(u32x4*)(xs + (u >> 3) * 128 + (u & 7) * 16) = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int u = tid + i * 256, p = u / 48, c8 = u - p * 48;
+            *(u32x4*)(ys + p * WQ_YP + c8 * 16) = yr[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < WQ_PX / 16; ++ks) {
+            bf16x8 xf[2], yf[3];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) xf[a] = tr_frag(xs + (ks * 16) * 128 + a * 64, 128, lane);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) yf[j] = tr_frag(ys + (ks * 16) * WQ_YP + (wave * 96 + j * 32) * 2, WQ_YP, lane);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[a][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a], yf[j], acc[a][j], 0, 0, 0);   // rows = ci, cols = co
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float* d = dw + ((size_t)kc * 64 + a * 32) * WQ_CO + wave * 96 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
+                atomicAdd(d + (size_t)ci * WQ_CO, acc[a][j][r]);
+            }
+        }
+}
+
 // 3x3: all nine taps in one workgroup.  grid (pixel-tile groups, (Cin/64)*(Cout/64)); 4 waves, wave -> 32 ci x 32 co x 9 taps
 // (144 accumulator registers).  The 10 x 34 halo tile and the 8 x 32 dY tile are read from HBM once per
 // (ci block, co block): 248 flop per byte, against 83 for one kernel row per workgroup.  The halo rows are
@@ -533,6 +611,17 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     OFD_CHECK_ARG(combos <= 65535, "conv_wgrad: too many channel blocks");
+    static const bool no_wq = getenv("OFD_NO_WGRAD_QKV") && atoi(getenv("OFD_NO_WGRAD_QKV"));
+    if (a->ksize == 1 && a->Cout == WQ_CO && a->n_src == 1 && P.src[0].mode == 0 && !dbias && !no_wq) {
+        const size_t npix = (size_t)a->B * a->H * a->W;
+        const int ncib = cin / 64;
+        int g = cdiv(512, ncib);                                 // two workgroups per CU
+        const size_t nt = (npix + WQ_PX - 1) / WQ_PX;
+        if ((size_t)g > nt) g = (int)nt;
+        conv_wgrad1_qkv_kernel<<<dim3(g, ncib), 256, 0, s>>>(P.src[0].ptr + P.src[0].ch_offset, P.src[0].src_channels, dy, dw, npix, cin);
+        OFD_LAUNCH_CHECK();
+        return OFD_OK;
+    }
     if (a->ksize == 3) {
         constexpr int LDS = 10 * 34 * 128 + 256 * 128;
         static bool attr = false;
