@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libofd_hip.so")
+LIB_PATH = os.environ.get("OFD_LIB") or os.path.join(_HERE, "lib", "libofd_hip.so")      # OFD_LIB: A/B runs of alternative builds
 
 c_void_p, c_int, c_size_t, c_float, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float, ctypes.c_char_p
 
