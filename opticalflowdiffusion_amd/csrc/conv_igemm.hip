@@ -280,11 +280,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
                 for (int nt = 0; nt < C::NTN; ++nt)
                     wf[nt] = *(const bf16x8*)(wbuf + ((ks * 2 + half) * BN + nt * 32 + l31) * 16);
                 if (!(dbg & 4)) {
+                    // the MFMA issue of this wave goes ahead of the other resident workgroup's staging / epilogue instructions on the
+                    // same SIMD (same-box A/B: <3,128> 12.41 -> 11.82 ms per denoise step, <3,64> 4.13 -> 3.90)
+                    if (!(dbg & 128)) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                     for (int nt = 0; nt < C::NTN; ++nt)
 #pragma unroll
                         for (int pt = 0; pt < 2; ++pt)
                             acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[pt], acc[nt][pt], 0, 0, 0);
+                    if (!(dbg & 128)) __builtin_amdgcn_s_setprio(0);
                 } else {
 #pragma unroll
                     for (int nt = 0; nt < C::NTN; ++nt) asm volatile("" ::"v"(wf[nt]));
@@ -529,7 +533,8 @@ __device__ __forceinline__ void pp_write_x(const PPX& xr, const ConvParams& P, c
     }
 }
 
-__device__ __forceinline__ void pp_mfma(f32x16 (&acc)[2][2], const unsigned char* lds_w, const unsigned char* xbuf, int wv, int l31, int half) {
+__device__ __forceinline__ void pp_mfma(f32x16 (&acc)[2][2], const unsigned char* lds_w, const unsigned char* xbuf, int wv, int l31, int half,
+                                        bool prio) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -551,6 +556,7 @@ __device__ __forceinline__ void pp_mfma(f32x16 (&acc)[2][2], const unsigned char
     };
     read_frags(0, xf[0], wf[0]);
     read_frags(1, xf[1], wf[1]);
+    if (prio) __builtin_amdgcn_s_setprio(2);      // ahead of the other group's VALU phase on the same SIMD
 #pragma unroll
     for (int step = 0; step < 36; ++step) {
         if (step + 2 < 36) read_frags(step + 2, xf[(step + 2) % 3], wf[(step + 2) % 3]);
@@ -561,6 +567,7 @@ __device__ __forceinline__ void pp_mfma(f32x16 (&acc)[2][2], const unsigned char
             for (int pt = 0; pt < 2; ++pt)
                 acc[nt][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[step % 3][nt], xf[step % 3][pt], acc[nt][pt], 0, 0, 0);
     }
+    if (prio) __builtin_amdgcn_s_setprio(0);
 }
 
 // Epilogue with 16-byte stores: a lane holds 4 consecutive channels (8 B) per register quad; one
@@ -663,7 +670,7 @@ __global__ void __launch_bounds__(PP_THREADS, 1) conv3x3_c64_pingpong_kernel(con
         const PPTile nxt = my_tile(i + 1);        // (clamped to a valid tile past the end; never stored)
         if (group == 0) {
             if (!(P.dbg & 1)) pp_load_x(xr, P, nxt, gt);
-            if (!(P.dbg & 4)) pp_mfma(acc, lds_w, xbuf, wv, l31, half);
+            if (!(P.dbg & 4)) pp_mfma(acc, lds_w, xbuf, wv, l31, half, !(P.dbg & 256));
         } else if (i > 0) {
             if (prev.valid && !(P.dbg & 16)) pp_epilogue(acc, P, prev, s_bias, wv, lane, xbuf);
             if (!(P.dbg & 32)) pp_write_x(xr, P, cur, xbuf, gt);
@@ -674,7 +681,7 @@ __global__ void __launch_bounds__(PP_THREADS, 1) conv3x3_c64_pingpong_kernel(con
             if (!(P.dbg & 32)) pp_write_x(xr, P, nxt, xbuf, gt);
         } else {
             if (!(P.dbg & 1)) pp_load_x(xr, P, nxt, gt);
-            if (!(P.dbg & 4)) pp_mfma(acc, lds_w, xbuf, wv, l31, half);
+            if (!(P.dbg & 4)) pp_mfma(acc, lds_w, xbuf, wv, l31, half, !(P.dbg & 256));
         }
         pp_barrier();
         prev = cur;
