@@ -364,6 +364,10 @@ class ConditionalDiffusion(nn.Module):
         self.num_timesteps = int(timesteps)
         self.sampling_timesteps = default(sampling_timesteps, timesteps)
         assert self.sampling_timesteps <= timesteps
+        # optional: with return_all_timesteps keep x_T, every `trajectory_stride`-th step and the final sample instead of all T+1
+        # frames (1001 x 57.7 MB = 57.8 GB at B=16, 440x1024; the reference's logging only looks at samples[:, ::50], FD:246).
+        # None = the reference's behaviour (every frame).
+        self.trajectory_stride = None
         self.is_ddim_sampling = self.sampling_timesteps < timesteps
         self.ddim_sampling_eta = ddim_sampling_eta
 
@@ -463,9 +467,10 @@ class ConditionalDiffusion(nn.Module):
         img = torch.randn(shape, device=self.device)
         imgs = [img]
         additionals = [None]
-        for t in reversed(range(0, self.num_timesteps)):
+        stride = self.trajectory_stride
+        for i, t in enumerate(reversed(range(0, self.num_timesteps))):
             img, x_start, additional_out = self.p_sample(img, t, None, external_cond=external_cond, additional_tgt=additional_tgt)
-            if return_all_timesteps:
+            if return_all_timesteps and (stride is None or (i + 1) % stride == 0 or t == 0):
                 imgs.append(img)
             additionals.append(additional_out)
         ret = img if not return_all_timesteps else torch.stack(imgs, dim=1)
@@ -485,7 +490,8 @@ class ConditionalDiffusion(nn.Module):
         imgs = [img]
         n = img[0].numel()
         ac = self.alphas_cumprod
-        for time, time_next in time_pairs:
+        stride = self.trajectory_stride
+        for i, (time, time_next) in enumerate(time_pairs):
             tc = torch.full((batch,), time, device=device, dtype=torch.long)
             out = self.model_with_condition(img, tc, None, external_cond=external_cond)
             sr = self.sqrt_recip_alphas_cumprod[tc].contiguous()
@@ -505,7 +511,7 @@ class ConditionalDiffusion(nn.Module):
             L.check(L.lib().ofd_ddim_update(L.ptr(img), L.ptr(out), L.ptr(noise), L.ptr(sr), L.ptr(srm1), L.ptr(san), L.ptr(cc),
                                             L.ptr(sg), int(last), L.ptr(nxt), None, batch, n, L.stream()))
             img = nxt
-            if return_all_timesteps:
+            if return_all_timesteps and (stride is None or (i + 1) % stride == 0 or last):
                 imgs.append(img)
         return img if not return_all_timesteps else torch.stack(imgs, dim=1)
 

@@ -141,6 +141,8 @@ class FlowDiffuser(_Base):
             channels=2 + 1 * int(cfg.target == "target") + 3 * int(cfg.target == "joint"),
             auto_normalize=False, noise_space="image" if cfg.noiser == "image" else "flow",
             timesteps=cfg.timesteps, sampling_timesteps=cfg.sampling_timesteps, min_snr_loss_weight=True)
+        if "trajectory_stride" in cfg:                                      # optional key, default = every frame as the reference
+            self.model.trajectory_stride = cfg.trajectory_stride
 
     def configure_optimizers(self):                                         # FD:131-134
         """Adam(lr, weight_decay) as the reference; the HIP multi-tensor step (optim.FusedAdam) has

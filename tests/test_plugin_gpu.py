@@ -171,6 +171,23 @@ def test_flow_diffuser_training_steps_reduce_the_loss():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in fd.unet.parameters())
 
 
+def test_trajectory_stride_keeps_strided_frames_only():
+    """optional `trajectory_stride`: x_T, every k-th step and the final sample; the kept frames equal those of the full trajectory"""
+    from opticalflowdiffusion_amd import FlowDiffuser
+    H, W, B = 16, 24, 2
+    fd = FlowDiffuser(dict(target="flow", image_size=[H, W], timesteps=10, flow_max=20, zero_init=False)).cuda()
+    cond = torch.rand(B, 3, H, W, device="cuda") * 2 - 1
+    torch.manual_seed(5)
+    full = fd.model.sample(batch_size=B, external_cond=cond, return_all_timesteps=True)
+    fd.model.trajectory_stride = 4
+    torch.manual_seed(5)
+    part = fd.model.sample(batch_size=B, external_cond=cond, return_all_timesteps=True)
+    assert full.shape[1] == 11 and part.shape[1] == 4                       # x_T, after steps 4 and 8, final
+    assert torch.equal(part, full[:, [0, 4, 8, 10]])
+    fd2 = FlowDiffuser(dict(target="flow", image_size=[H, W], timesteps=10, trajectory_stride=5)).cuda()
+    assert fd2.model.trajectory_stride == 5
+
+
 def test_flow_diffuser_regression_mode_is_diffusion_false():
     """FD:106-111 / 128-129 / 176-186 / 204-213 with is_diffusion=False, target=flow: Unet(64, channels=3, out_dim=2, time_in=False)
     regresses the flow from the condition image, loss = mse; training reduces it; sample = forward splat of the condition."""
