@@ -791,26 +791,29 @@ __global__ void grid_warp_corners_kernel(const float* __restrict__ flow, int32_t
 constexpr int PT_W = 64, PT_H = 16, PT_MAXL = 16, PT_HALO = PT_MAXL - 1;
 constexpr int PT_IW = PT_W + 2 * PT_HALO, PT_IH = PT_H + 2 * PT_HALO;
 
-// out (planes, Ho_, Wo_) = tent_L (*) in (planes, Hi, Wi), zero outside the input; out index (y, x) reads in (y - ky, x - kx)
-__global__ void __launch_bounds__(256) tent2d_kernel(const float* __restrict__ in, float* __restrict__ out, int Hi, int Wi, int Ho_, int Wo_, int L) {
+// out (planes, Ho_, Wo_) (+)= tent_L (*) in (planes, Hi, Wi) along x (DX), y (DY) or both; zero outside the input; out index (y, x)
+// reads in (y - ky, x - kx)
+template <bool DX, bool DY, bool ACC>
+__global__ void __launch_bounds__(256) tent_kernel(const float* __restrict__ in, float* __restrict__ out, int Hi, int Wi, int Ho_, int Wo_, int L) {
     __shared__ float tile[PT_IH][PT_IW + 1];
     __shared__ float hrow[PT_IH][PT_W + 1];
     const size_t plane_i = (size_t)Hi * Wi, plane_o = (size_t)Ho_ * Wo_;
     const float* ip = in + (size_t)blockIdx.z * plane_i;
     float* op = out + (size_t)blockIdx.z * plane_o;
-    const int X0 = blockIdx.x * PT_W, Y0 = blockIdx.y * PT_H, h = L - 1;
-    const int iw = PT_W + 2 * h, ih = PT_H + 2 * h;
+    const int X0 = blockIdx.x * PT_W, Y0 = blockIdx.y * PT_H, hx = DX ? L - 1 : 0, hy = DY ? L - 1 : 0;
+    const int iw = PT_W + 2 * hx, ih = PT_H + 2 * hy;
     for (int i = threadIdx.x; i < ih * iw; i += 256) {
         const int r = i / iw, c = i - r * iw;
-        const int y = Y0 - h + r, x = X0 - h + c;
+        const int y = Y0 - hy + r, x = X0 - hx + c;
         tile[r][c] = (y >= 0 && y < Hi && x >= 0 && x < Wi) ? ip[(size_t)y * Wi + x] : 0.0f;
     }
     __syncthreads();
     const float inv = 1.0f / (float)L;
     for (int i = threadIdx.x; i < ih * PT_W; i += 256) {         // horizontal pass
         const int r = i / PT_W, c = i - r * PT_W;
-        float acc = tile[r][c + h];
-        for (int k = 1; k < L; ++k) acc += (1.0f - (float)k * inv) * (tile[r][c + h - k] + tile[r][c + h + k]);
+        float acc = tile[r][c + hx];
+        if (DX)
+            for (int k = 1; k < L; ++k) acc += (1.0f - (float)k * inv) * (tile[r][c + hx - k] + tile[r][c + hx + k]);
         hrow[r][c] = acc;
     }
     __syncthreads();
@@ -818,11 +821,20 @@ __global__ void __launch_bounds__(256) tent2d_kernel(const float* __restrict__ i
         const int r = i / PT_W, c = i - r * PT_W;
         const int y = Y0 + r, x = X0 + c;
         if (y >= Ho_ || x >= Wo_) continue;
-        float acc = hrow[r + h][c];
-        for (int k = 1; k < L; ++k) acc += (1.0f - (float)k * inv) * (hrow[r + h - k][c] + hrow[r + h + k][c]);
-        op[(size_t)y * Wo_ + x] = acc;
+        float acc = hrow[r + hy][c];
+        if (DY)
+            for (int k = 1; k < L; ++k) acc += (1.0f - (float)k * inv) * (hrow[r + hy - k][c] + hrow[r + hy + k][c]);
+        if (ACC) op[(size_t)y * Wo_ + x] += acc;
+        else op[(size_t)y * Wo_ + x] = acc;
     }
 }
+
+// Border classes of a level (class code in the top two bits of a list entry): a pixel whose target is plain along one axis
+// still takes the tent path ALONG THAT AXIS -- its contribution factorises into (per-offset reference weights on the border axis)
+// x (scale-1 bilinear pair on the plain axis, tent-filtered afterwards) -- so it costs O(L) scattered values instead of O(L^2).
+constexpr unsigned PYR_IDX = 0x3fffffffu;       // class 0: both axes border; 1: x border, y plain; 2: x plain, y border
+__device__ __forceinline__ bool pyr_plain_x(float fltX, int L, int W) { return fltX >= (float)(L - 1) && fltX < (float)W - 1.0f; }
+__device__ __forceinline__ bool pyr_plain_y(float fltY, int L, int H) { return fltY >= (float)(L - 1) && fltY < (float)H - 1.0f; }
 
 // compact list of the border pixels of level L (finite target, not plain): one atomic per wave
 __global__ void __launch_bounds__(256) pyramid_border_list_kernel(const float* __restrict__ flow, unsigned int* __restrict__ list,
@@ -832,31 +844,35 @@ __global__ void __launch_bounds__(256) pyramid_border_list_kernel(const float* _
     for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < total; i0 += stride) {      // whole waves stay in the loop (ballot)
         const size_t i = i0 + threadIdx.x;
         bool border = false;
+        unsigned cls = 0;
         if (i < total) {
             const size_t n = i / plane, pix = i % plane;
             const int y = (int)(pix / W), x = (int)(pix % W);
             const float fltX = (float)x + flow[n * 2 * plane + pix], fltY = (float)y + flow[n * 2 * plane + plane + pix];
             border = isfinite(fltX) && isfinite(fltY) && !pyr_plain(fltX, fltY, L, H, W);
+            cls = pyr_plain_y(fltY, L, H) ? 1u : (pyr_plain_x(fltX, L, W) ? 2u : 0u);
         }
         const unsigned long long m = __ballot(border);
         const int lane = threadIdx.x & 63;
         unsigned base = 0;
         if (lane == 0 && m) base = atomicAdd(count, (unsigned)__popcll(m));
         base = __shfl(base, 0, 64);
-        if (border) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i;
+        if (border) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)i | (cls << 30);
     }
 }
 
 // border pixels of level g.scale, one work item per (pixel, offset): the reference's forward remap, scattered into T
 __global__ void __launch_bounds__(256) pyramid_border_fwd_kernel(const float* __restrict__ in, const float* __restrict__ flow, float* __restrict__ T,
                                                                  const unsigned int* __restrict__ list, const unsigned int* __restrict__ count,
-                                                                 SplatGeom g) {
+                                                                 SplatGeom g, int all_classes) {
     const size_t plane = (size_t)g.H * g.W;
     const int L = g.scale, L2 = L * L, Wt = L * g.Wo;
     const size_t tplane = (size_t)(L * g.Ho) * Wt;
     const size_t items = (size_t)(*count) * L2;
     for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
-        const size_t i = list[it / L2];
+        const unsigned e = list[it / L2];
+        if (!all_classes && (e >> 30) != 0u) continue;          // strip pixels go through pyramid_strip_fwd_kernel
+        const size_t i = e & PYR_IDX;
         const int o = (int)(it % L2), a = o % L, b = o / L;
         const int n = (int)(i / plane);
         const size_t pix = i % plane;
@@ -878,6 +894,52 @@ __global__ void __launch_bounds__(256) pyramid_border_fwd_kernel(const float* __
     }
 }
 
+// strip pixels (border along ONE axis), forward.  AX = 0: x border, y plain -> scatter into U (planes, H, L*Wo) whose columns are
+// full-resolution offset positions X = L cx + a and whose rows are scale-1 rows (the y tent filter runs afterwards);
+// AX = 1: x plain, y border -> into Bm (planes, L*Ho, W), filtered along x afterwards.  One work item per (pixel, offset).
+template <int AX>
+__global__ void __launch_bounds__(256) pyramid_strip_fwd_kernel(const float* __restrict__ in, const float* __restrict__ flow, float* __restrict__ dst,
+                                                                const unsigned int* __restrict__ list, const unsigned int* __restrict__ count,
+                                                                SplatGeom g) {
+    const size_t plane = (size_t)g.H * g.W;
+    const int L = g.scale, Wt = L * g.Wo, Ht = L * g.Ho;
+    const size_t dplane = AX == 0 ? (size_t)g.H * Wt : (size_t)Ht * g.W;
+    const size_t items = (size_t)(*count) * L;
+    for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
+        const unsigned e = list[it / L];
+        if ((e >> 30) != (AX == 0 ? 1u : 2u)) continue;
+        const size_t i = e & PYR_IDX;
+        const int o = (int)(it % L);
+        const int n = (int)(i / plane);
+        const size_t pix = i % plane;
+        const int y = (int)(pix / g.W), x = (int)(pix % g.W);
+        const float f0 = flow[(size_t)n * 2 * plane + pix], f1 = flow[(size_t)n * 2 * plane + plane + pix];
+        SplatGeom go = g;
+        go.ox = AX == 0 ? o : 0; go.oy = AX == 0 ? 0 : o;
+        float fx, fy, d0, d1;
+        if (!splat_remap<0>(f0, f1, x, y, go, fx, fy, d0, d1)) continue;
+        // border axis: the reference's cells and weights at this offset; plain axis: the scale-1 bilinear pair of the raw target
+        const float fb = AX == 0 ? fx : fy;
+        const int c0 = floor_to_int(fb);
+        const float wb[2] = {(float)(c0 + 1) - fb, fb - (float)c0};
+        const float fp = AX == 0 ? (float)y + f1 : (float)x + f0;
+        const int p0 = (int)floorf(fp);
+        const float wp[2] = {(float)(p0 + 1) - fp, fp - (float)p0};
+        const int nb = AX == 0 ? g.Wo : g.Ho;
+        for (int k = 0; k < 2; ++k) {
+            const int cb = c0 + k;
+            if (cb < 0 || cb >= nb) continue;
+            const int full = L * cb + o;                            // full-resolution position along the border axis
+            for (int j = 0; j < 2; ++j) {
+                const size_t t = AX == 0 ? (size_t)(p0 + j) * Wt + full : (size_t)full * g.W + (p0 + j);
+                const float w = AX == 0 ? wb[k] * wp[j] : wp[j] * wb[k];
+                for (int c = 0; c < g.C; ++c)
+                    atomicAdd(&dst[((size_t)n * g.C + c) * dplane + t], in[((size_t)n * g.C + c) * plane + pix] * w);
+            }
+        }
+    }
+}
+
 // border pixels, backward, one work item per (pixel, offset row b): the reference's ingrad (SS:489-565) and flowgrad (SS:600-700)
 // over the offsets a of that row, added to the zeros the scale-1 kernels wrote for these pixels
 __global__ void __launch_bounds__(256) pyramid_border_bwd_kernel(const float* __restrict__ in, const float* __restrict__ flow, const float* __restrict__ dT,
@@ -888,7 +950,7 @@ __global__ void __launch_bounds__(256) pyramid_border_bwd_kernel(const float* __
     const size_t tplane = (size_t)(L * g.Ho) * Wt;
     const size_t items = (size_t)(*count) * L;
     for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
-        const size_t i = list[it / L];
+        const size_t i = list[it / L] & PYR_IDX;
         const int b = (int)(it % L);
         const int n = (int)(i / plane);
         const size_t pix = i % plane;
@@ -1005,8 +1067,9 @@ static int splat_launch(const float* in, const float* flow, float* out, const Sp
 }
 
 extern "C" size_t ofd_splat_pyramid_workspace_bytes(int B, int C, int H, int W) {
-    // the splat's own workspace | one (B, C, H, W) fp32 image (scale-1 splat of the plain pixels / filtered gradient)
-    return (ofd_splat_workspace_bytes(B, H, W) + 255) / 256 * 256 + (size_t)B * C * H * W * 4;
+    // the splat's own workspace | three (B, C, H, W) fp32 images (forward: scale-1 splat of the plain pixels, the two strip
+    // buffers; backward: the filtered gradient)
+    return (ofd_splat_workspace_bytes(B, H, W) + 255) / 256 * 256 + 3 * (((size_t)B * C * H * W * 4 + 255) / 256 * 256);
 }
 
 extern "C" int ofd_splat_pyramid_fwd(const float* in, const float* flow, float* T, int B, int C, int H, int W, int L, int radius,
@@ -1030,13 +1093,29 @@ extern "C" int ofd_splat_pyramid_fwd(const float* in, const float* flow, float* 
     rc = splat_launch(in, flow, S, g1, workspace, s);
     if (rc) return rc;
     const int Ht = L * gL.Ho, Wt = L * gL.Wo;
-    tent2d_kernel<<<dim3(cdiv(Wt, PT_W), cdiv(Ht, PT_H), B * C), 256, 0, s>>>(S, T, H, W, Ht, Wt, L);
+    OFD_CHECK_ARG((size_t)B * H * W < (1u << 30), "splat_pyramid_fwd: B*H*W must be < 2^30");
+    const size_t img = ((size_t)B * C * H * W * 4 + 255) / 256 * 256;
+    float* U = (float*)((char*)S + img);            // (planes, H, Wt): x-filtered plain pixels + x-border strip pixels
+    float* Bm = (float*)((char*)S + 2 * img);       // (planes, Ht, W): y-border strip pixels, to be filtered along x
     // border pixels: compact list in the (now idle) far-corner list area of the splat workspace, counter in its header
     unsigned int* bcount = (unsigned int*)workspace + 2;
     unsigned int* blist = (unsigned int*)((char*)workspace + 16 + (size_t)B * S_MAXC * 4);
     OFD_HIP(hipMemsetAsync(bcount, 0, 4, s));
     pyramid_border_list_kernel<<<stream_grid((size_t)B * H * W, 256), 256, 0, s>>>(flow, blist, bcount, B, H, W, L);
-    pyramid_border_fwd_kernel<<<4096, 256, 0, s>>>(in, flow, T, blist, bcount, gL);
+    static const bool direct = getenv("OFD_PYR_DIRECT_BORDER") && atoi(getenv("OFD_PYR_DIRECT_BORDER"));     // A/B: L*L scatter for every class
+    if (direct) {
+        tent_kernel<true, true, false><<<dim3(cdiv(Wt, PT_W), cdiv(Ht, PT_H), B * C), 256, 0, s>>>(S, T, H, W, Ht, Wt, L);
+        pyramid_border_fwd_kernel<<<4096, 256, 0, s>>>(in, flow, T, blist, bcount, gL, 1);
+    } else {
+        // T = tent_y( tent_x(S) + [x-border strips] ) + tent_x( [y-border strips] ) + [corner pixels]
+        OFD_HIP(hipMemsetAsync(Bm, 0, (size_t)B * C * Ht * W * 4, s));
+        pyramid_strip_fwd_kernel<1><<<2048, 256, 0, s>>>(in, flow, Bm, blist, bcount, gL);
+        tent_kernel<true, false, false><<<dim3(cdiv(Wt, PT_W), cdiv(Ht, PT_H), B * C), 256, 0, s>>>(Bm, T, Ht, W, Ht, Wt, L);
+        tent_kernel<true, false, false><<<dim3(cdiv(Wt, PT_W), cdiv(H, PT_H), B * C), 256, 0, s>>>(S, U, H, W, H, Wt, L);
+        pyramid_strip_fwd_kernel<0><<<2048, 256, 0, s>>>(in, flow, U, blist, bcount, gL);
+        tent_kernel<false, true, true><<<dim3(cdiv(Wt, PT_W), cdiv(Ht, PT_H), B * C), 256, 0, s>>>(U, T, H, Wt, Ht, Wt, L);
+        pyramid_border_fwd_kernel<<<4096, 256, 0, s>>>(in, flow, T, blist, bcount, gL, 0);
+    }
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -1060,7 +1139,7 @@ extern "C" int ofd_splat_pyramid_bwd(const float* in, const float* flow, const f
     const float* G = dT;
     if (L > 1) {
         float* Gb = (float*)((char*)workspace + (ofd_splat_workspace_bytes(B, H, W) + 255) / 256 * 256);
-        tent2d_kernel<<<dim3(cdiv(W, PT_W), cdiv(H, PT_H), B * C), 256, 0, s>>>(dT, Gb, L * gL.Ho, L * gL.Wo, H, W, L);
+        tent_kernel<true, true, false><<<dim3(cdiv(W, PT_W), cdiv(H, PT_H), B * C), 256, 0, s>>>(dT, Gb, L * gL.Ho, L * gL.Wo, H, W, L);
         G = Gb;
         g1.pyr_L = L;
     }

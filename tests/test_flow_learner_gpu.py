@@ -107,7 +107,7 @@ def test_splat_pyramid_equals_the_per_offset_splats(B, C, H, W, L, amp):
         for b in range(L):
             ref = splat_forward(x.cuda(), f.cuda(), L, a, b)
             scale = float(ref.abs().max()) + 1e-6
-            worst = max(worst, float((off[a, b] - ref).abs().max()) / scale)
+            worst = max(worst, float((off[a, b].detach() - ref).abs().max()) / scale)
     assert worst < 2e-5, worst
     for (a, b) in {(0, 0), (L - 1, L // 2), (L // 3, L - 1)}:
         cpu = WR.splat_out(x, f, L, a, b)
