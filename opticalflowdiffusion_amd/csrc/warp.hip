@@ -940,16 +940,96 @@ __global__ void __launch_bounds__(256) pyramid_strip_fwd_kernel(const float* __r
     }
 }
 
+// strip pixels, backward (the transposed per-axis identity).  With dP = dT filtered along the PLAIN axis (AX = 0: dU = tent_y dT,
+// (planes, H, L*Wo); AX = 1: dBm = tent_x dT, (planes, L*Ho, W)), sums over the plain axis' offsets collapse:
+//   sum_o sum_cells W_cell(o) dT[cell, o]   = sum_j w_j dP[p0 + j]          (bilinear pair w of the raw target)
+//   sum_o sum_cells s_cell    dT[cell, o]   = L sum_j s_j dP[p0 + j]        (s = -1, +1: the derivative of that pair)
+// and the reference's ingrad (SS:489-565) / flowgrad (SS:600-700) keep their own remaps (variants 1 and 2) on the border axis.  The
+// flow gradient of channel 0 multiplies by the Y branch factor and that of channel 1 by the X one (SS:664-672): the plain axis'
+// factor is 1 / L.  One work item per (pixel, offset of the border axis); results are added to the zeros the scale-1 kernels wrote.
+template <int AX>
+__global__ void __launch_bounds__(256) pyramid_strip_bwd_kernel(const float* __restrict__ in, const float* __restrict__ flow, const float* __restrict__ dP,
+                                                                float* __restrict__ ingrad, float* __restrict__ flowgrad,
+                                                                const unsigned int* __restrict__ list, const unsigned int* __restrict__ count, SplatGeom g) {
+    const size_t plane = (size_t)g.H * g.W;
+    const int L = g.scale, Wt = L * g.Wo, Ht = L * g.Ho;
+    const size_t dplane = AX == 0 ? (size_t)g.H * Wt : (size_t)Ht * g.W;
+    const size_t items = (size_t)(*count) * L;
+    const int nb = AX == 0 ? g.Wo : g.Ho;
+    for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
+        const unsigned e = list[it / L];
+        if ((e >> 30) != (AX == 0 ? 1u : 2u)) continue;
+        const size_t i = e & PYR_IDX;
+        const int o = (int)(it % L);
+        const int n = (int)(i / plane);
+        const size_t pix = i % plane;
+        const int y = (int)(pix / g.W), x = (int)(pix % g.W);
+        const float f0 = flow[(size_t)n * 2 * plane + pix], f1 = flow[(size_t)n * 2 * plane + plane + pix];
+        SplatGeom go = g;
+        go.ox = AX == 0 ? o : 0; go.oy = AX == 0 ? 0 : o;
+        float fx, fy, dxx, dyy;
+        // border axis, variant 1 (ingrad) and variant 2 (flowgrad)
+        const bool ok1 = splat_remap<1>(f0, f1, x, y, go, fx, fy, dxx, dyy);
+        const float b1 = AX == 0 ? fx : fy;
+        const bool ok2 = splat_remap<2>(f0, f1, x, y, go, fx, fy, dxx, dyy);
+        const float b2 = AX == 0 ? fx : fy, dfl = AX == 0 ? dxx : dyy;
+        const int c1 = floor_to_int(b1), c2 = floor_to_int(b2);
+        const float W1[2] = {(float)(c1 + 1) - b1, b1 - (float)c1}, W2[2] = {(float)(c2 + 1) - b2, b2 - (float)c2};
+        // plain axis: the raw target's bilinear pair
+        const float fp = AX == 0 ? (float)y + f1 : (float)x + f0;
+        const int p0 = (int)floorf(fp);
+        const float wp[2] = {(float)(p0 + 1) - fp, fp - (float)p0};
+        auto at = [&](const float* base, int cell, int j) {       // dP at (border cell of this offset, plain position p0 + j)
+            const int full = L * cell + o;
+            return base[AX == 0 ? (size_t)(p0 + j) * Wt + full : (size_t)full * g.W + (p0 + j)];
+        };
+        float g_border = 0.0f, g_plain = 0.0f;     // d / d(flow of the border axis), d / d(flow of the plain axis)
+        for (int c = 0; c < g.C; ++c) {
+            const float* dp = dP + ((size_t)n * g.C + c) * dplane;
+            const float v = in ? in[((size_t)n * g.C + c) * plane + pix] : 0.0f;
+            if (ingrad && ok1) {
+                float acc = 0.0f;
+                for (int k = 0; k < 2; ++k)
+                    if (c1 + k >= 0 && c1 + k < nb) acc += W1[k] * (wp[0] * at(dp, c1 + k, 0) + wp[1] * at(dp, c1 + k, 1));
+                if (acc != 0.0f) atomicAdd(&ingrad[((size_t)n * g.C + c) * plane + pix], acc);
+            }
+            if (flowgrad && ok2) {
+                for (int k = 0; k < 2; ++k)
+                    if (c2 + k >= 0 && c2 + k < nb) {
+                        const float d0 = at(dp, c2 + k, 0), d1 = at(dp, c2 + k, 1);
+                        const float sgn = k == 0 ? -1.0f : 1.0f;
+                        // border-axis flow: sign of the border cell x plain weights, times the PLAIN axis' branch factor 1 / L
+                        g_border += v * sgn * (wp[0] * d0 + wp[1] * d1) * (1.0f / (float)L);
+                        // plain-axis flow: border weights x plain derivative (L x the pair difference), times the BORDER axis' factor
+                        g_plain += v * W2[k] * (d1 - d0) * (float)L * dfl;
+                    }
+            }
+        }
+        if (flowgrad) {
+            float* gxp = flowgrad + (size_t)n * 2 * plane + pix;
+            if (AX == 0) {
+                if (g_border != 0.0f) atomicAdd(gxp, g_border);
+                if (g_plain != 0.0f) atomicAdd(gxp + plane, g_plain);
+            } else {
+                if (g_plain != 0.0f) atomicAdd(gxp, g_plain);
+                if (g_border != 0.0f) atomicAdd(gxp + plane, g_border);
+            }
+        }
+    }
+}
+
 // border pixels, backward, one work item per (pixel, offset row b): the reference's ingrad (SS:489-565) and flowgrad (SS:600-700)
 // over the offsets a of that row, added to the zeros the scale-1 kernels wrote for these pixels
 __global__ void __launch_bounds__(256) pyramid_border_bwd_kernel(const float* __restrict__ in, const float* __restrict__ flow, const float* __restrict__ dT,
                                                                  float* __restrict__ ingrad, float* __restrict__ flowgrad,
-                                                                 const unsigned int* __restrict__ list, const unsigned int* __restrict__ count, SplatGeom g) {
+                                                                 const unsigned int* __restrict__ list, const unsigned int* __restrict__ count, SplatGeom g,
+                                                                 int all_classes) {
     const size_t plane = (size_t)g.H * g.W;
     const int L = g.scale, Wt = L * g.Wo;
     const size_t tplane = (size_t)(L * g.Ho) * Wt;
     const size_t items = (size_t)(*count) * L;
     for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
+        if (!all_classes && (list[it / L] >> 30) != 0u) continue;          // strip pixels: pyramid_strip_bwd_kernel
         const size_t i = list[it / L] & PYR_IDX;
         const int b = (int)(it % L);
         const int n = (int)(i / plane);
@@ -1151,7 +1231,20 @@ extern "C" int ofd_splat_pyramid_bwd(const float* in, const float* flow, const f
         unsigned int* blist = (unsigned int*)((char*)workspace + 16 + (size_t)B * S_MAXC * 4);
         OFD_HIP(hipMemsetAsync(bcount, 0, 4, s));
         pyramid_border_list_kernel<<<grid, 256, 0, s>>>(flow, blist, bcount, B, H, W, L);
-        pyramid_border_bwd_kernel<<<4096, 256, 0, s>>>(in, flow, dT, ingrad, flowgrad, blist, bcount, gL);
+        static const bool direct = getenv("OFD_PYR_DIRECT_BORDER") && atoi(getenv("OFD_PYR_DIRECT_BORDER"));
+        if (direct) {
+            pyramid_border_bwd_kernel<<<4096, 256, 0, s>>>(in, flow, dT, ingrad, flowgrad, blist, bcount, gL, 1);
+        } else {
+            const int Ht = L * gL.Ho, Wt = L * gL.Wo;
+            const size_t img = ((size_t)B * C * H * W * 4 + 255) / 256 * 256;
+            float* dU = (float*)((char*)G + img);          // tent_y dT: (planes, H, Wt)
+            float* dBm = (float*)((char*)G + 2 * img);     // tent_x dT: (planes, Ht, W)
+            tent_kernel<false, true, false><<<dim3(cdiv(Wt, PT_W), cdiv(H, PT_H), B * C), 256, 0, s>>>(dT, dU, Ht, Wt, H, Wt, L);
+            tent_kernel<true, false, false><<<dim3(cdiv(W, PT_W), cdiv(Ht, PT_H), B * C), 256, 0, s>>>(dT, dBm, Ht, Wt, Ht, W, L);
+            pyramid_strip_bwd_kernel<0><<<2048, 256, 0, s>>>(in, flow, dU, ingrad, flowgrad, blist, bcount, gL);
+            pyramid_strip_bwd_kernel<1><<<2048, 256, 0, s>>>(in, flow, dBm, ingrad, flowgrad, blist, bcount, gL);
+            pyramid_border_bwd_kernel<<<4096, 256, 0, s>>>(in, flow, dT, ingrad, flowgrad, blist, bcount, gL, 0);
+        }
     }
     OFD_LAUNCH_CHECK();
     return OFD_OK;
