@@ -73,6 +73,16 @@ int ofd_splat_pyramid_fwd(const float* in, const float* flow, float* T, int B, i
 int ofd_splat_pyramid_bwd(const float* in, const float* flow, const float* dT, float* ingrad, float* flowgrad,
                           int B, int C, int H, int W, int L, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Photometric loss of one pyramid level on two ofd_splat_pyramid_fwd results in "soft" form (flow_learner.py:176-190):
+ * Tin, Ttg: (B, C+1, Ht, Wt), last channel = splatted weight.  filled = Tin_c / (w + 1e-7) where w > 0, NaN elsewhere
+ * (fill_holes_nan, WP:273-276); tgt = Ttg_c / (w_t + 1e-7); Charbonnier sqrt(d^2 + 1e-6) (WP:278-287) over the pairs without NaN,
+ * per offset: sums / counts [L][L] (row = offset_y, col = offset_x), fp64.  The level loss is mean(sums / counts).
+ * bwd: dTin = d(level loss)/dTin x gscale[0] (device scalar). */
+int ofd_pyramid_charbonnier_fwd(const float* Tin, const float* Ttg, double* sums, double* counts, int B, int C, int Ht, int Wt,
+                                int L, void* stream);
+int ofd_pyramid_charbonnier_bwd(const float* Tin, const float* Ttg, const double* counts, const float* gscale, float* dTin,
+                                int B, int C, int Ht, int Wt, int L, void* stream);
+
 /* warp_forward_flow pieces (WP:121-156).
  * prep : first (B,C,H,W) -> ten_in (B,C+1,H,W) = cat(nan_to_zero(first) * w, w), w = 0 where any
  *        channel of the pixel is NaN else 1.  square != 0 squares the values (get_variance).

@@ -53,6 +53,8 @@ SIGNATURES = {
     "ofd_splat_pyramid_workspace_bytes": (c_size_t, [c_int] * 4),
     "ofd_splat_pyramid_fwd": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
     "ofd_splat_pyramid_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
+    "ofd_pyramid_charbonnier_fwd": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "ofd_pyramid_charbonnier_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "ofd_grid_warp_bwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_size_t, c_void_p]),
     "ofd_grid_warp_corners": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p]),
     "ofd_q_sample": (c_int, [c_void_p] * 5 + [c_int, c_size_t, c_void_p]),

@@ -1079,6 +1079,87 @@ __global__ void __launch_bounds__(256) pyramid_border_bwd_kernel(const float* __
     }
 }
 
+// ---- photometric loss of one pyramid level on the interleaved splats (flow_learner.py:176-190, WP:273-287) -------------------
+// Tin, Ttg: (B, C+1, Ht, Wt) = splat_pyramid of cat(img e^m, e^m) with the predicted flow, and of cat(tgt e, e) with zero flow.
+// Per position: filled = Tin_c / (w + 1e-7) where w > 0 else NaN (fill_holes_nan), tgt = Ttg_c / (w_t + 1e-7) (soft mode's
+// normalisation), Charbonnier penalty sqrt(d^2 + 1e-6) over the pairs without NaN, accumulated per offset (a, b) = (X mod L,
+// Y mod L): sums / counts -> nan_charbonnier of every offset.  One kernel instead of ~20 elementwise passes per level.
+__global__ void __launch_bounds__(256) pyr_charb_reduce_kernel(const float* __restrict__ Tin, const float* __restrict__ Ttg, double* __restrict__ sums,
+                                                               double* __restrict__ counts, int B, int C, int Ht, int Wt, int L) {
+    __shared__ float bs[PT_MAXL], bc[PT_MAXL];
+    const size_t tplane = (size_t)Ht * Wt;
+    const int xchunks = (Wt + 255) / 256;
+    const size_t nrows = (size_t)B * Ht * xchunks;
+    for (size_t rw = blockIdx.x; rw < nrows; rw += gridDim.x) {
+        const int xc = (int)(rw % xchunks);
+        const size_t ny = rw / xchunks;
+        const int Y = (int)(ny % Ht), n = (int)(ny / Ht);
+        const int X = xc * 256 + threadIdx.x;
+        if (threadIdx.x < L) { bs[threadIdx.x] = 0.0f; bc[threadIdx.x] = 0.0f; }
+        __syncthreads();
+        if (X < Wt) {
+            const size_t pos = (size_t)Y * Wt + X;
+            const float* pi = Tin + (size_t)n * (C + 1) * tplane + pos;
+            const float* pt = Ttg + (size_t)n * (C + 1) * tplane + pos;
+            const float wi = pi[(size_t)C * tplane], wt = pt[(size_t)C * tplane];
+            float s_ = 0.0f, c_ = 0.0f;
+            for (int c = 0; c < C; ++c) {
+                const float filled = wi > 0.0f ? pi[(size_t)c * tplane] / (wi + 0.0000001f) : __builtin_nanf("");
+                const float tg = pt[(size_t)c * tplane] / (wt + 0.0000001f);
+                if (filled == filled && tg == tg) {
+                    const float d = tg - filled;
+                    s_ += sqrtf(d * d + 1.0e-6f);
+                    c_ += 1.0f;
+                }
+            }
+            if (c_ > 0.0f) { atomicAdd(&bs[X % L], s_); atomicAdd(&bc[X % L], c_); }
+        }
+        __syncthreads();
+        if (threadIdx.x < L && bc[threadIdx.x] > 0.0f) {
+            const int o = (Y % L) * L + threadIdx.x;            // [b][a]
+            atomicAdd(&sums[o], (double)bs[threadIdx.x]);
+            atomicAdd(&counts[o], (double)bc[threadIdx.x]);
+        }
+        __syncthreads();
+    }
+}
+
+// d(level loss) / dTin, level loss = mean over offsets of sums / counts; gscale[0] = the incoming gradient of the level loss
+__global__ void __launch_bounds__(256) pyr_charb_grad_kernel(const float* __restrict__ Tin, const float* __restrict__ Ttg, const double* __restrict__ counts,
+                                                             const float* __restrict__ gscale, float* __restrict__ dTin, int B, int C, int Ht, int Wt,
+                                                             int L) {
+    const size_t tplane = (size_t)Ht * Wt, total = (size_t)B * tplane;
+    const float gs = gscale[0] / (float)(L * L);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / tplane);
+        const size_t pos = i % tplane;
+        const int Y = (int)(pos / Wt), X = (int)(pos % Wt);
+        const float* pi = Tin + (size_t)n * (C + 1) * tplane + pos;
+        const float* pt = Ttg + (size_t)n * (C + 1) * tplane + pos;
+        float* po = dTin + (size_t)n * (C + 1) * tplane + pos;
+        const float wi = pi[(size_t)C * tplane], wt = pt[(size_t)C * tplane];
+        const double cnt = counts[(Y % L) * L + (X % L)];
+        const float k = cnt > 0.0 ? gs / (float)cnt : 0.0f;
+        const float inv = 1.0f / (wi + 0.0000001f);
+        float dw = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            float g = 0.0f;
+            if (wi > 0.0f) {
+                const float ti = pi[(size_t)c * tplane];
+                const float filled = ti * inv, tg = pt[(size_t)c * tplane] / (wt + 0.0000001f);
+                if (filled == filled && tg == tg) {
+                    const float d = filled - tg;
+                    const float df = k * d / sqrtf(d * d + 1.0e-6f);       // d loss / d filled
+                    g = df * inv;
+                    dw -= df * ti * inv * inv;
+                }
+            }
+            po[(size_t)c * tplane] = g;
+        }
+        po[(size_t)C * tplane] = dw;
+    }
+}
+
 static int make_geom(SplatGeom& g, int B, int C, int H, int W, int scale, int ox, int oy, int radius) {
     OFD_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0, "splat: bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
     OFD_CHECK_ARG(scale >= 1 && H / scale > 0 && W / scale > 0, "splat: bad scale %d for %dx%d", scale, H, W);
@@ -1246,6 +1327,26 @@ extern "C" int ofd_splat_pyramid_bwd(const float* in, const float* flow, const f
             pyramid_border_bwd_kernel<<<4096, 256, 0, s>>>(in, flow, dT, ingrad, flowgrad, blist, bcount, gL, 0);
         }
     }
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" int ofd_pyramid_charbonnier_fwd(const float* Tin, const float* Ttg, double* sums, double* counts, int B, int C, int Ht, int Wt, int L,
+                                           void* stream) {
+    OFD_CHECK_ARG(Tin && Ttg && sums && counts && B > 0 && C > 0 && Ht > 0 && Wt > 0 && L >= 1 && L <= PT_MAXL, "pyramid_charbonnier_fwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    OFD_HIP(hipMemsetAsync(sums, 0, (size_t)L * L * sizeof(double), s));
+    OFD_HIP(hipMemsetAsync(counts, 0, (size_t)L * L * sizeof(double), s));
+    const size_t nrows = (size_t)B * Ht * cdiv(Wt, 256);
+    pyr_charb_reduce_kernel<<<(unsigned)(nrows < 8192 ? nrows : 8192), 256, 0, s>>>(Tin, Ttg, sums, counts, B, C, Ht, Wt, L);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" int ofd_pyramid_charbonnier_bwd(const float* Tin, const float* Ttg, const double* counts, const float* gscale, float* dTin, int B, int C,
+                                           int Ht, int Wt, int L, void* stream) {
+    OFD_CHECK_ARG(Tin && Ttg && counts && gscale && dTin && B > 0 && C > 0 && L >= 1 && L <= PT_MAXL, "pyramid_charbonnier_bwd: bad argument");
+    pyr_charb_grad_kernel<<<stream_grid((size_t)B * Ht * Wt, 256), 256, 0, (hipStream_t)stream>>>(Tin, Ttg, counts, gscale, dTin, B, C, Ht, Wt, L);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

@@ -11,7 +11,7 @@ import torch
 
 from .denoising_diffusion import Unet
 from .flow_diffuser import UnetWithWarp, _Base, _Cfg
-from .softsplat import pyramid_offsets, softsplat, softsplat_pyramid
+from .softsplat import pyramid_charbonnier, pyramid_offsets, softsplat, softsplat_pyramid, splat_pyramid
 from .warp import charbonnier, edgeaware_smoothness1, fill_holes_nan, nan_charbonnier
 
 LEVELS = (1, 2, 4, 5, 7, 8, 10, 11, 14, 16)          # FL:163
@@ -41,8 +41,21 @@ def photometric_pyramid_loss(input_img, flow_pred, warp_weights, tgt, levels=LEV
 
 
 def photometric_pyramid_loss_fused(input_img, flow_pred, warp_weights, tgt, levels=LEVELS):
-    """The same loss with ONE pyramid splat per level and image (softsplat.splat_pyramid: scale-1 splat + tent filter + border
-    scatter) instead of L*L splats, and the per-offset Charbonnier means as batched reductions over the (a, b) axes."""
+    """The same loss with ONE pyramid splat per level and image (softsplat.splat_pyramid: scale-1 splat + tent filters + border
+    scatter) instead of L*L splats, and ONE reduction kernel per level (softsplat.pyramid_charbonnier: soft-mode normalisation,
+    hole filling, Charbonnier penalty and the per-offset means)."""
+    zero_flow = torch.zeros_like(flow_pred)
+    e_in = warp_weights.exp()
+    in4 = torch.cat([input_img * e_in, e_in], 1)                               # softsplat "soft": cat(x e^m, e^m)
+    e_tg = torch.ones_like(warp_weights).exp()
+    tg4 = torch.cat([tgt * e_tg, e_tg], 1)
+    photo = [pyramid_charbonnier(splat_pyramid(in4, flow_pred, level), splat_pyramid(tg4, zero_flow, level), level) for level in levels]
+    return sum(photo) / len(photo)
+
+
+def photometric_pyramid_loss_fused_torch(input_img, flow_pred, warp_weights, tgt, levels=LEVELS):
+    """photometric_pyramid_loss_fused with the per-level loss spelled out in torch ops on the interleaved layout (test reference
+    of the reduction kernel)."""
     zero_flow = torch.zeros_like(flow_pred)
     ones = torch.ones_like(warp_weights)
     photo = []

@@ -186,3 +186,36 @@ def softsplat_pyramid(tenIn, tenFlow, tenMetric, strMode, scale):
             tenNormalize = tenNormalize.clip(0.0000001, None)
         return torch.cat((tenOut[:, :-1, :, :] / tenNormalize, tenOut[:, -1, None, :, :]), dim=1)
     return tenOut
+
+
+class _PyramidCharbonnier(torch.autograd.Function):
+    """mean over the L*L offsets of nan_charbonnier(target slice, filled input slice) on two un-normalised "soft" pyramid splats
+    (B, C+1, Ht, Wt): one reduction kernel forward, one elementwise kernel backward (gradient w.r.t. the input pyramid only)."""
+
+    @staticmethod
+    def forward(ctx, Tin, Ttg, L):
+        L_ = int(L)
+        Tin, Ttg = _lib_f32(Tin), _lib_f32(Ttg)
+        B, C1, Ht, Wt = Tin.shape
+        acc = torch.empty(2, L_, L_, dtype=torch.float64, device=Tin.device)
+        L_mod.check(L_mod.lib().ofd_pyramid_charbonnier_fwd(L_mod.ptr(Tin), L_mod.ptr(Ttg), L_mod.ptr(acc[0]), L_mod.ptr(acc[1]), B, C1 - 1, Ht, Wt,
+                                                            L_, L_mod.stream()))
+        ctx.save_for_backward(Tin, Ttg, acc)
+        ctx.level = L_
+        return (acc[0] / acc[1]).mean().to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        Tin, Ttg, acc = ctx.saved_tensors
+        B, C1, Ht, Wt = Tin.shape
+        dT = torch.empty_like(Tin)
+        gs = g.reshape(1).to(torch.float32).contiguous()
+        L_mod.check(L_mod.lib().ofd_pyramid_charbonnier_bwd(L_mod.ptr(Tin), L_mod.ptr(Ttg), L_mod.ptr(acc[1]), L_mod.ptr(gs), L_mod.ptr(dT), B, C1 - 1,
+                                                            Ht, Wt, ctx.level, L_mod.stream()))
+        return dT, None, None
+
+
+def pyramid_charbonnier(Tin, Ttg, level):
+    """level loss of flow_learner.py:176-191 from the raw (un-normalised) soft pyramid splats of input and target"""
+    L_mod.require_gpu(Tin, Ttg)
+    return _PyramidCharbonnier.apply(Tin, Ttg, level)

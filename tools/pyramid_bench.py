@@ -45,5 +45,25 @@ def main():
         print(json.dumps(row), flush=True)
 
 
+def learner_step():
+    """whole FlowLearner training step (regression UNet forward + backward, pyramid loss, fused Adam) at the reference's default size"""
+    from opticalflowdiffusion_amd import FlowLearner
+    from opticalflowdiffusion_amd.data import SyntheticFlowPairs
+    for (B, H, W) in [(16, 128, 128)]:
+        fl = FlowLearner(dict(image_size=[H, W], flow_max=20, zero_init=False)).cuda()
+        fl.log_dict = lambda *a, **k: None
+        fl.log = lambda *a, **k: None
+        opt = fl.configure_optimizers()
+        batch = SyntheticFlowPairs(64, H, W).batch(0, B, torch.device("cuda"))
+
+        def step():
+            opt.zero_grad()
+            fl.training_step(batch, 0).backward()
+            opt.step()
+        print(json.dumps({"workload": f"FlowLearner training step, B={B} {H}x{W}, 10 levels, fused pyramid", "ms_per_step": timed(step, 5)}), flush=True)
+
+
 if __name__ == "__main__":
     main()
+    if "--full-only" not in sys.argv:
+        learner_step()
