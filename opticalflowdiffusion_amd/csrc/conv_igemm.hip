@@ -1119,7 +1119,11 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
         P.pad_y = 1 - py; P.pad_x = 1 - px; P.out_oy = py; P.out_ox = px;
     }
     { static int dbg_env = -1; if (dbg_env < 0) { const char* e = getenv("OFD_CONV_DBG"); dbg_env = e ? atoi(e) : 0; } P.dbg = dbg_env; }
-    const bool wide = (a->Cout % 128 == 0);
+    // 128 output channels per workgroup unless that leaves CUs without work: small images (the reference's default 128 x 128 reaches
+    // 16 x 16 at the coarsest level: 32 pixel tiles x 4 channel blocks for 256 CUs) take the 64-channel instantiation: twice the
+    // workgroups
+    static const int small_grid = getenv("OFD_CONV_SMALL_GRID") ? atoi(getenv("OFD_CONV_SMALL_GRID")) : 256;
+    const bool wide = (a->Cout % 128 == 0) && (long)P.tiles_x * P.tiles_y * P.B * (a->Cout / 128) >= small_grid;
     static int no_pp = -1;
     if (no_pp < 0) { const char* e = getenv("OFD_NO_PINGPONG"); no_pp = (e && atoi(e)) ? 1 : 0; }
     static int use_rw = -1;
