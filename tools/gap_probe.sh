@@ -18,5 +18,11 @@ import collections
 by = collections.Counter()
 for r, e in zip(rows, ex): by[r['Kernel_Name'][:50]] += e
 for k, v in by.most_common(8): print(f"  {k:50s} {v/1e6:.2f} ms")
+bg = collections.defaultdict(lambda: [0, 0])
+for r, e in zip(rows, ex):
+    if 'conv_igemm_kernel<3' in r['Kernel_Name'] or 'pingpong' in r['Kernel_Name']:
+        k = (r['Kernel_Name'][:44], r.get('Grid_Size_X', r.get('Grid_Size', '?')), r.get('Grid_Size_Y', ''))
+        bg[k][0] += 1; bg[k][1] += e
+for k, (n, t) in sorted(bg.items(), key=lambda kv: -kv[1][1])[:12]: print(f"  {k} n={n} avg={t/n/1e3:.1f} us total={t/1e6:.2f} ms")
 PY
 rm -rf gpurun_out/gap
