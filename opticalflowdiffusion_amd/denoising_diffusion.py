@@ -462,9 +462,10 @@ class ConditionalDiffusion(nn.Module):
         return pred, x_start, additional_out
 
     @torch.no_grad()
-    def p_sample_loop(self, shape, return_all_timesteps=False, external_cond=None, additional_tgt=None, verbose=False):
-        """DD:700-729 (no per-step print / host sync)."""
-        img = torch.randn(shape, device=self.device)
+    def p_sample_loop(self, shape, return_all_timesteps=False, external_cond=None, additional_tgt=None, verbose=False, x_T=None):
+        """DD:700-729 (no per-step print / host sync).  `x_T` (optional, not in the reference): the start of the chains (DD:705)."""
+        img = torch.randn(shape, device=self.device) if x_T is None else L.f32c(x_T)
+        assert tuple(img.shape) == tuple(shape)
         imgs = [img]
         additionals = [None]
         stride = self.trajectory_stride
@@ -480,13 +481,15 @@ class ConditionalDiffusion(nn.Module):
 
     # -- DDIM --------------------------------------------------------------------------------
     @torch.no_grad()
-    def ddim_sample(self, shape, return_all_timesteps=False, external_cond=None, additional_tgt=None):
-        """DD:731-774; accepts (and ignores) additional_tgt so that sample() can reach it."""
+    def ddim_sample(self, shape, return_all_timesteps=False, external_cond=None, additional_tgt=None, x_T=None):
+        """DD:731-774; accepts (and ignores) additional_tgt so that sample() can reach it.  `x_T` (optional, not in
+        the reference) starts the chains from a given tensor instead of a fresh draw (DD:741)."""
         batch, device, T, S, eta = shape[0], self.device, self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
         times = torch.linspace(-1, T - 1, steps=S + 1)
         times = list(reversed(times.int().tolist()))
         time_pairs = list(zip(times[:-1], times[1:]))
-        img = torch.randn(shape, device=device)
+        img = torch.randn(shape, device=device) if x_T is None else L.f32c(x_T)
+        assert tuple(img.shape) == tuple(shape)
         imgs = [img]
         n = img[0].numel()
         ac = self.alphas_cumprod

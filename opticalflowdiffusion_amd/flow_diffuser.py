@@ -106,8 +106,8 @@ class UnetWithWarp(torch.nn.Module):
 
 
 class FlowDiffuser(_Base):
-    """FD:65-388 (latent=False).  Training-mode `training_step` needs the HIP backward pass,
-    which this build does not contain yet; `validation_step`-style loss/sampling run."""
+    """FD:65-388 (latent=False): `training_step` is differentiable through the HIP training executor
+    (`ofd_unet_train_forward` / `ofd_unet_backward` behind `denoising_diffusion._UnetTrain`)."""
 
     def __init__(self, cfg):
         super().__init__()

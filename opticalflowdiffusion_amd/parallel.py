@@ -4,8 +4,8 @@
 Sampling (the benchmarked path) shards BY SAMPLE: every rank runs independent chains on its own
 slice of the global batch, so there is no data-path collective -- only a barrier around the timed
 region and a MAX-reduction of the elapsed time.  The reference's only parallelism is
-Lightning DDP (experiments/exp_base.py:198); its gradient all-reduce belongs to the training
-path, which needs the backward kernels.
+Lightning DDP (experiments/exp_base.py:198): its gradient all-reduce is `BucketedAllReduce` below, fed by the
+range callback of `ofd_unet_backward` and overlapped with the remaining backward launches.
 """
 import os
 
@@ -55,6 +55,15 @@ def max_over_ranks(seconds, device=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def describe_grad_sync(world, bucket_bytes=32 << 20):
+    """what actually synchronises the gradients in this process group (for benchmark records)"""
+    if world <= 1 or not (dist.is_available() and dist.is_initialized()):
+        return "none"
+    be = dist.get_backend()
+    name = {"nccl": "RCCL (torch backend nccl)", "gloo": "gloo (host transport: rehearsal, not xGMI)"}.get(be, be)
+    return f"bucketed all-reduce over {name}, {bucket_bytes >> 20} MiB buckets, side stream, overlapped with backward"
 
 
 def whole_job_rate(units_per_rank, world, seconds):

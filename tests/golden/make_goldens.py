@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 
-from oracle.unet_ref import closed_form_params  # noqa: E402  (weight fill shared with tests)
+from oracle.unet_ref import closed_form_params, random_params  # noqa: E402  (weight fills shared with tests)
 
 
 def import_reference():
@@ -300,12 +300,56 @@ def loss_helpers():
          fill_holes_nan=wp.fill_holes_nan(img, w), edgeaware_smoothness1=wp.edgeaware_smoothness1(img, flow))
 
 
+TAPS = (["init_conv"] + [f"downs.{i}.{j}" for i in range(4) for j in (0, 2, 3)] + ["mid_block1", "mid_attn", "mid_block2"] +
+        [f"ups.{i}.{j}" for i in range(4) for j in (2, 3)] + ["final_res_block"])
+
+
+def random_weight_unet():
+    """(8) the reference Unet under WELL-CONDITIONED weights (oracle.unet_ref.random_params: default-init-like statistics, the
+    two dtype-dependent eps sites made immaterial), in fp32 AND under bf16 autocast, output and 19 taps each.  Under these
+    weights the reference's own bf16-vs-fp32 distance is rounding noise (~1.5e-2), so it is the floor the HIP engine's bf16
+    output is asserted against DIRECTLY (tests/test_unet_gpu.py::test_hip_unet_against_the_reference_module_outputs)."""
+    torch.set_num_threads(8)
+    dd, _ = import_reference()
+    for tag, ch, hw in (("c5_64x96", 5, (64, 96)), ("c9_32x48", 9, (32, 48))):
+        u = dd.Unet(64, channels=ch, out_dim=2)
+        P = random_params({k: tuple(v.shape) for k, v in u.state_dict().items()}, seed=1)
+        u.load_state_dict(P)
+        u.eval()
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(2, ch - 3, *hw, generator=g)
+        cond = torch.rand(2, 3, *hw, generator=g) * 2 - 1
+        t = torch.tensor([3, 700])
+        arrays = dict(x=x, cond=cond, t=t, seed=np.int64(1))
+        for mode in ("fp32", "autocast"):
+            rec = {}
+            hooks = [mod.register_forward_hook(lambda m, i, o, name=name: rec.__setitem__(name, o.detach().float().clone()))
+                     for name, mod in u.named_modules() if name in TAPS]
+            with torch.no_grad():
+                if mode == "fp32":
+                    y = u(x, cond, t)
+                else:
+                    with torch.autocast("cpu", dtype=torch.bfloat16):
+                        y = u(x, cond, t)
+            for h in hooks:
+                h.remove()
+            arrays[f"y.{mode}"] = y.float()
+            for name, v in rec.items():
+                arrays[f"tap.{name}.{mode}"] = v[:, :8, :8, :8]
+                arrays[f"tapstat.{name}.{mode}"] = torch.stack((v.mean(), v.std()))
+                arrays[f"tapshape.{name}"] = np.asarray(v.shape, dtype=np.int64)
+        save(f"unet_rand_{tag}", **arrays)
+
+
 if __name__ == "__main__":
     if "--only-loss-helpers" in sys.argv:
         loss_helpers()
     elif "--only-regression-unet" in sys.argv:
         regression_unet()
+    elif "--only-random-unet" in sys.argv:
+        random_weight_unet()
     else:
         main()
         regression_unet()
         loss_helpers()
+        random_weight_unet()

@@ -128,3 +128,89 @@ def test_splat_flowgrad_frozen_outside_and_crossed():
     fg = W.splat_flowgrad(img, flow, gout)
     assert (fg[0, 1, :, 3] == 0).all()      # channel 1 is scaled by dfltXX (crossed, SS:671-672)
     assert (fg[0, 0, :3, 3] != 0).any()     # channel 0 is scaled by dfltYY, still live
+
+
+# ---- splat: an executable third-party pin ---------------------------------------------------
+def _aten_grid(flow, dtype=torch.float64):
+    """Normalised sampling grid whose ATen un-normalisation ((g+1)/2*(size-1), align_corners=True) lands on x + flow."""
+    B, _, H, Wd = flow.shape
+    # SS:368-369: fltOutputX = x + flow[:, 0] in the flow's own precision (fp32 in the reference), everything after in `dtype`
+    xs = (torch.arange(Wd, dtype=flow.dtype).view(1, 1, Wd) + flow[:, 0]).to(dtype)
+    ys = (torch.arange(H, dtype=flow.dtype).view(1, H, 1) + flow[:, 1]).to(dtype)
+    return torch.stack((2 * xs / (Wd - 1) - 1, 2 * ys / (H - 1) - 1), dim=-1)
+
+
+@pytest.mark.parametrize("shape,mag", [((2, 3, 17, 23), 3.0), ((1, 4, 40, 56), 12.0), ((1, 1, 9, 64), 30.0), ((1, 2, 100, 120), 20.0)])
+def test_splat_scale1_is_the_adjoint_of_aten_grid_sample(shape, mag):
+    """At scale 1 the reference's splat (SS:352-423) is the exact transpose of ATen's bilinear grid_sample
+    (align_corners=True, zeros padding) evaluated at the un-normalised coordinates x + flow: torch's CPU autograd of
+    that op yields the splat, its input gradient and (for targets inside the plain branch, SS:626-647) its flow gradient
+    without going through oracle/splat_ref.c.  This is the third-party pin of the C restatement."""
+    B, C, H, Wd = shape
+    g = torch.Generator().manual_seed(41)
+    img = torch.rand(B, C, H, Wd, generator=g)
+    flow = (torch.rand(B, 2, H, Wd, generator=g) * 2 - 1) * mag
+    flow[0, :, 1, 1] = 0.0                                                 # an exact integer target
+    flow[0, 0, 2, 2] = 1.0
+    gout = torch.rand(B, C, H, Wd, generator=g)
+
+    # forward: d/dG <grid_sample(G, grid), img> = splat(img)
+    G = torch.zeros(B, C, H, Wd, dtype=torch.float64, requires_grad=True)
+    grid = _aten_grid(flow)
+    (torch.nn.functional.grid_sample(G, grid, mode="bilinear", padding_mode="zeros", align_corners=True) * img.double()).sum().backward()
+    ref = W.splat_out(img, flow)
+    assert float((ref.double() - G.grad).abs().max()) <= 1e-6 * max(1.0, float(G.grad.abs().max()))
+    assert rel_l2(ref, G.grad) < 2e-7
+
+    # ingrad (SS:489-565) is the gather itself
+    gather = torch.nn.functional.grid_sample(gout.double(), grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    ing = W.splat_ingrad(flow, gout, img.shape)
+    assert float((ing.double() - gather).abs().max()) <= 2e-6
+
+    # flowgrad (SS:600-700): ATen's grid gradient chained through x + flow, for targets in the plain branch on both axes
+    fl = flow.clone().requires_grad_(True)
+    s = (torch.nn.functional.grid_sample(gout.double(), _aten_grid(fl), mode="bilinear", padding_mode="zeros",
+                                         align_corners=True) * img.double()).sum()
+    s.backward()
+    fg = W.splat_flowgrad(img, flow, gout)
+    xs = torch.arange(Wd).view(1, 1, Wd) + flow[:, 0]
+    ys = torch.arange(H).view(1, H, 1) + flow[:, 1]
+    frac = lambda v: (v - v.floor())
+    plain = ((xs >= 0) & (xs < Wd - 1) & (ys >= 0) & (ys < H - 1) &
+             (frac(xs) > 1e-3) & (frac(xs) < 1 - 1e-3) & (frac(ys) > 1e-3) & (frac(ys) < 1 - 1e-3))   # off the kinks
+    plain = plain.unsqueeze(1).expand_as(fg)
+    assert int(plain.sum()) > 0.3 * plain.numel() / max(1.0, mag / 6)
+    assert float((fg.double() - fl.grad)[plain].abs().max()) <= 2e-5 * max(1.0, float(fl.grad.abs().max()))
+
+
+def test_splat_property_p2_direct_and_two_stage_values_and_gradients():
+    """warp_test.py:77-102 (`are_they_equal`): method_a = warp(src, flow, scale=L, offset)/L^2 against
+    method_b = warp(warp(src, flow, set_nans=True), 0, scale=L, offset, set_nans=False)/L^2 -- values and the gradient of an
+    MSE against a random image, here carried on to `src` through the restated backward kernels (the reference compares
+    the gradient at the method output, which is equal iff the values are)."""
+    g = torch.Generator().manual_seed(42)
+    L = 2
+    B, C, H, Wd = 1, 1, 64, 64
+    src = torch.rand(B, C, H, Wd, generator=g)
+    flow = torch.where(torch.rand(B, 2, H, Wd, generator=g) < 0.5,
+                       torch.round(4 * torch.rand(B, 2, H, Wd, generator=g) - 2.0), 4 * torch.rand(B, 2, H, Wd, generator=g) - 2.0)
+    comp = torch.rand(B, C, H // L, Wd // L, generator=g)
+    zero = torch.zeros_like(flow)
+    inner = (slice(None), slice(None), slice(2, -2), slice(2, -2))
+    for off in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        a = W.warp(src, None, flow, mode="forward", scale=L, set_nans=False, offset=list(off)) / L ** 2
+        high = W.warp(src, None, flow, mode="forward", scale=1, set_nans=True, offset=[0, 0])
+        b = W.warp(high, None, zero, mode="forward", scale=L, set_nans=False, offset=list(off)) / L ** 2
+        assert float((a - b)[inner].abs().max()) < 1e-4, off
+        # -d mse / d method (warp_test.py:93-96), restricted to the interior the two methods share
+        ga = torch.zeros_like(a)
+        gb = torch.zeros_like(b)
+        ga[inner] = -2 * (a - comp)[inner] / a[inner].numel()
+        gb[inner] = -2 * (b - comp)[inner] / b[inner].numel()
+        assert float((ga - gb).abs().max()) < 1e-4 * float(ga.abs().max())
+        # ... and pulled back to src: scale-L ingrad against scale-1 ingrad of the zero-flow scale-L ingrad
+        da = W.splat_ingrad(flow, ga / L ** 2, src.shape, L, off[0], off[1])
+        valid = (~torch.isnan(high)).float()
+        db = W.splat_ingrad(flow, W.splat_ingrad(zero, gb / L ** 2, src.shape, L, off[0], off[1]) * valid, src.shape)
+        core = (slice(None), slice(None), slice(8, -8), slice(8, -8))
+        assert float((da - db)[core].abs().max()) < 1e-4 * float(da.abs().max()), off

@@ -384,3 +384,60 @@ def test_unet_awkward_shapes_inference_and_training_forward(L, B, H, W):
     out_t.sum().backward()
     assert rel_l2(out, ref) < 2e-2 and rel_l2(out_t.detach().cpu(), ref) < 2e-2
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+# ------------------------------------------------------------ direct: HIP engine vs the reference module's own outputs
+@pytest.mark.parametrize("tag,ch", [("c5_64x96", 5), ("c9_32x48", 9)])
+def test_hip_unet_against_the_reference_module_outputs(L, tag, ch):
+    """No oracle in between: the golden holds what the REFERENCE's `Unet` (DD:272-417) returned, in fp32 and under its own bf16
+    autocast, for weights rebuilt here from (seed, state-dict order) -- tests/golden/make_goldens.py::random_weight_unet.
+    Floor = the reference's own bf16-vs-fp32 distance on this input (rounding noise only: the weights make the two
+    dtype-dependent eps sites immaterial, oracle/unet_ref.py::random_params).  The HIP engine's bf16 output and each of its 19
+    taps must sit within 1.5x that floor of the reference's FP32 values."""
+    from conftest import load_golden
+    g = load_golden(f"unet_rand_{tag}")
+    P = R.random_params(R.unet_param_shapes(64, ch, 2), seed=int(g["seed"]))
+    u = make_unet(ch, P)
+    with torch.no_grad():
+        out = u(g["x"].cuda(), g["cond"].cuda(), g["t"].cuda())
+    torch.cuda.synchronize()
+    floor = rel_l2(g["y.autocast"], g["y.fp32"])
+    err = rel_l2(out.cpu(), g["y.fp32"])
+    print(f"\n  output: HIP vs reference fp32 {err:.3e}; reference autocast vs its fp32 {floor:.3e}; HIP vs reference autocast "
+          f"{rel_l2(out.cpu(), g['y.autocast']):.3e}")
+    assert 5e-3 < floor < 3e-2                      # the fixture is in the regime it was built for
+    assert err < 1.5 * floor
+    worst = 0.0
+    for name in TAPS:
+        ref32, ref16 = g[f"tap.{name}.fp32"], g[f"tap.{name}.autocast"]
+        got = u.read_tap(name, tuple(int(v) for v in g[f"tapshape.{name}"])).cpu()
+        got = got[:, :8, :8, :8]
+        tap_floor = max(rel_l2(ref16, ref32), 0.5 * floor)
+        e = rel_l2(got, ref32)
+        worst = max(worst, e / tap_floor)
+        print(f"  {name:18s} HIP vs reference fp32 {e:.3e}  (reference autocast vs fp32 {rel_l2(ref16, ref32):.3e})")
+        assert e < 1.5 * tap_floor, (name, e, tap_floor)
+    print(f"  worst tap error / floor = {worst:.2f}")
+
+
+def test_eps_sites_are_those_of_rocm_autocast(L):
+    """csrc/unet.hip's per-site eps table (= oracle site_eps()) restates what DD:107 / DD:122 pick from the live dtype under
+    torch.autocast on THIS backend.  Checked by running the oracle restatement (torch ops as the checker) on the GPU under
+    torch.autocast('cuda', bf16) with the reference's own rule on x.dtype and comparing the trace with the table."""
+    torch.manual_seed(11)
+    P = {k: v.cuda() for k, v in default_init_params(5).items()}
+    x, cond, t = torch.randn(1, 2, 32, 32).cuda(), torch.rand(1, 3, 32, 32).cuda(), torch.tensor([17]).cuda()
+    trace = {}
+    import oracle.unet_ref as RR
+    orig = RR.sinusoidal_pos_emb
+    RR.sinusoidal_pos_emb = lambda tt, dim: orig(tt.cpu(), dim).to(tt.device)      # arange lives on the CPU in the restatement
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            y = R.unet_forward(P, x, cond, t, mode="autocast", eps_trace=trace)
+    finally:
+        RR.sinusoidal_pos_emb = orig
+    table = R.site_eps()
+    assert set(trace) == set(table)
+    diff = {k: (trace[k], table[k]) for k in table if trace[k] != pytest.approx(table[k])}
+    assert not diff, diff
+    assert torch.isfinite(y.float()).all()

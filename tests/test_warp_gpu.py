@@ -244,6 +244,110 @@ def test_splat_full_size_properties(ofd):
     assert lo * (1 - 1e-5) <= total <= hi * (1 + 1e-5)
 
 
+def test_c5_warp_kernels_at_8x3x1080x1920(ofd):
+    """BASELINE configs[4] (1080p, bs 8): the splat conserves mass and reproduces the image under zero flow; grid_sample warp is
+    the identity under zero flow (up to the fp32 round trip of WP:108-109) and a slice under an integer shift; the two are adjoint
+    (<gather(x), g> == <x, scatter(g)>: grid_sample's d/d second is the splat kernel on the gather's coordinates)."""
+    from opticalflowdiffusion_amd.softsplat import splat_forward
+    B, C, H, W = 8, 3, 1080, 1920
+    g = torch.Generator(device="cuda").manual_seed(17)
+    img = torch.rand(B, C + 1, H, W, device="cuda", generator=g)
+    z = torch.zeros(B, 2, H, W, device="cuda")
+    assert torch.equal(splat_forward(img, z), img)
+    f = (torch.rand(B, 2, H, W, device="cuda", generator=g) * 2 - 1) * 20.0
+    out = splat_forward(img, f)
+    xs = torch.arange(W, device="cuda").view(1, 1, W) + f[:, 0]
+    ys = torch.arange(H, device="cuda").view(1, H, 1) + f[:, 1]
+    inside = ((xs >= 0) & (xs <= W - 1) & (ys >= 0) & (ys <= H - 1)).unsqueeze(1)
+    lo, hi, total = float((img * inside).double().sum()), float(img.double().sum()), float(out.double().sum())
+    assert lo * (1 - 1e-5) <= total <= hi * (1 + 1e-5)
+    # an integer shift moves whole pixels: exact
+    fi = z.clone()
+    fi[:, 0], fi[:, 1] = 7.0, -3.0
+    sh = splat_forward(img, fi)
+    assert torch.equal(sh[:, :, :-3, 7:], img[:, :, 3:, :-7]) and bool((sh[:, :, -3:] == 0).all()) and bool((sh[:, :, :, :7] == 0).all())
+    del out, sh, inside
+    im3 = img[:, :3].contiguous()
+    o, m = ofd.warp(None, im3, z, mode="backward")
+    assert float((o - im3).abs().max()) < 4e-4 and bool((m == 1).all())
+    fb = z.clone()
+    fb[:, 1], fb[:, 0] = 3.0, -2.0                       # channel 1 displaces x after the flip (WP:105)
+    o, m = ofd.warp(None, im3, fb, mode="backward")
+    assert float((o[:, :, 2:, :-3] - im3[:, :, :-2, 3:]).abs().max()) < 4e-4
+    assert bool((m[:, :, :2] == 0).all()) and bool((m[:, :, :, -3:] == 0).all())
+    gg = torch.randn(B, 3, H, W, device="cuda", generator=g)
+    x = im3.clone().requires_grad_(True)
+    o, _ = ofd.warp(None, x, f, mode="backward")
+    lhs = float((o.detach().double() * gg.double()).sum())
+    (o * gg).sum().backward()
+    rhs = float((im3.double() * x.grad.double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), 1.0) + 2e-2
+
+
+def test_hip_splat_against_aten_grid_sample_adjoint(ofd):
+    """The third-party pin of tests/test_oracle_warp.py applied to the HIP kernels themselves: at scale 1 `ofd_splat_fwd` is the
+    transpose of ATen's bilinear grid_sample at x + flow, `ofd_splat_bwd_in` is that gather and `ofd_splat_bwd_flow` its grid
+    gradient (plain branch) -- torch CPU autograd in float64 is the checker, oracle/splat_ref.c is not involved."""
+    from opticalflowdiffusion_amd.softsplat import splat_forward
+    from opticalflowdiffusion_amd._lib import lib, check, ptr, stream
+    from test_oracle_warp import _aten_grid
+    GS = lambda a, grid: torch.nn.functional.grid_sample(a, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    for (B, C, H, W, mag) in [(2, 4, 130, 200, 20.0), (1, 3, 70, 96, 4.0)]:
+        g = torch.Generator().manual_seed(43)
+        img = torch.rand(B, C, H, W, generator=g)
+        flow = (torch.rand(B, 2, H, W, generator=g) * 2 - 1) * mag
+        gout = torch.rand(B, C, H, W, generator=g)
+        G = torch.zeros(B, C, H, W, dtype=torch.float64, requires_grad=True)
+        (GS(G, _aten_grid(flow)) * img.double()).sum().backward()
+        out = splat_forward(img.cuda(), flow.cuda()).cpu()
+        assert float((out.double() - G.grad).abs().max()) <= 1e-6 * max(1.0, float(G.grad.abs().max()))
+        assert rel_l2(out, G.grad) < 2e-7
+        fl = flow.clone().requires_grad_(True)
+        gather = GS(gout.double(), _aten_grid(fl))
+        (gather * img.double()).sum().backward()
+        d_img, d_flow, d_g = img.cuda(), flow.cuda(), gout.cuda()
+        g_in, g_fl = torch.empty_like(d_img), torch.empty_like(d_flow)
+        check(lib().ofd_splat_bwd_in(ptr(d_flow), ptr(d_g), ptr(g_in), B, C, H, W, 1, 0, 0, stream()))
+        check(lib().ofd_splat_bwd_flow(ptr(d_img), ptr(d_flow), ptr(d_g), ptr(g_fl), B, C, H, W, 1, 0, 0, stream()))
+        assert float((g_in.cpu().double() - gather.detach()).abs().max()) <= 2e-6
+        xs = torch.arange(W).view(1, 1, W) + flow[:, 0]
+        ys = torch.arange(H).view(1, H, 1) + flow[:, 1]
+        fr = lambda v: v - v.floor()
+        plain = ((xs >= 0) & (xs < W - 1) & (ys >= 0) & (ys < H - 1) & (fr(xs) > 1e-3) & (fr(xs) < 1 - 1e-3) &
+                 (fr(ys) > 1e-3) & (fr(ys) < 1 - 1e-3)).unsqueeze(1).expand(B, 2, H, W)
+        assert float((g_fl.cpu().double() - fl.grad)[plain].abs().max()) <= 2e-5 * max(1.0, float(fl.grad.abs().max()))
+
+
+def test_warp_test_property_p2_values_and_gradients(ofd):
+    """warp_test.py:77-102 on the GPU path: method_a (direct scale-L splat) against method_b (scale-1 splat with NaN holes, then a
+    zero-flow scale-L splat), values and the gradient of an MSE against a random image -- carried through to `src` by autograd
+    over the HIP backward kernels, which is where the two methods use different kernels (scale-L ingrad vs scale-1 o scale-L)."""
+    g = torch.Generator().manual_seed(44)
+    L = 2
+    B, C, H, W = 1, 1, 128, 128                                                  # warp_test.py:14
+    flow = torch.where(torch.rand(B, 2, H, W, generator=g) < 0.5, torch.round(4 * torch.rand(B, 2, H, W, generator=g) - 2.0),
+                       4 * torch.rand(B, 2, H, W, generator=g) - 2.0).cuda()
+    src0 = torch.rand(B, C, H, W, generator=g).cuda()
+    comp = torch.rand(B, C, H // L, W // L, generator=g).cuda()
+    zero = torch.zeros_like(flow)
+    inner = (slice(None), slice(None), slice(2, -2), slice(2, -2))
+    for off in ([0, 0], [1, 0], [0, 1], [1, 1]):
+        grads, vals = [], []
+        for method in ("a", "b"):
+            src = src0.clone().requires_grad_(True)
+            if method == "a":
+                m = ofd.warp(src, None, flow, scale=L, set_nans=False, mode="forward", offset=off) / L ** 2
+            else:
+                high = ofd.warp(src, None, flow, scale=1, set_nans=True, mode="forward", offset=[0, 0])
+                m = ofd.warp(high, None, zero, scale=L, set_nans=False, mode="forward", offset=off) / L ** 2
+            torch.nn.functional.mse_loss(m[inner], comp[inner]).backward()
+            vals.append(m.detach())
+            grads.append(src.grad)
+        assert float((vals[0] - vals[1])[inner].abs().max()) < 1e-4, off
+        core = (slice(None), slice(None), slice(8, -8), slice(8, -8))
+        assert float((grads[0] - grads[1])[core].abs().max()) < 1e-4 * float(grads[0].abs().max()), off
+
+
 def test_diffusion_elementwise_kernels(ofd):
     from opticalflowdiffusion_amd._lib import lib, check, ptr, stream
     from oracle import diffusion_ref as D
