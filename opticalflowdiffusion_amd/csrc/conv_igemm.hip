@@ -1073,6 +1073,7 @@ static int launch_conv(const ConvParams& P, hipStream_t s) {
 }
 
 int launch_conv3x3_c64_rw(const ConvParams& P, hipStream_t s);     // conv_rw.hip
+int launch_conv3x3_wp(const ConvParams& P, bool wide, hipStream_t s);   // conv_wp.hip
 
 int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     OFD_CHECK_ARG(a && a->out && a->weight, "conv: null out/weight");
@@ -1124,6 +1125,17 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     // workgroups
     static const int small_grid = getenv("OFD_CONV_SMALL_GRID") ? atoi(getenv("OFD_CONV_SMALL_GRID")) : 256;
     const bool wide = (a->Cout % 128 == 0) && (long)P.tiles_x * P.tiles_y * P.B * (a->Cout / 128) >= small_grid;
+    // wave-private-weights kernel (conv_wp.hip): OFD_CONV_WP bit 0 = the 128-channel-block layers, bit 1 = the 64-channel-block
+    // layers other than 64 -> 64, bit 2 = 64 -> 64 (instead of the ping-pong kernel)
+    static int use_wp = -1;
+    if (use_wp < 0) { const char* e = getenv("OFD_CONV_WP"); use_wp = e ? atoi(e) : 3; }
+    if (a->ksize == 3 && use_wp) {
+        bool modes_ok = true;
+        for (int i = 0; i < a->n_src; ++i) modes_ok = modes_ok && P.src[i].mode != 2;
+        const bool c64 = a->Cout == 64 && P.Cin_total == 64 && a->n_src == 1 && P.src[0].mode == 0 && !a->residual && !a->res_act;
+        const int bit = wide ? 1 : (c64 ? 4 : 2);
+        if (modes_ok && (use_wp & bit)) return launch_conv3x3_wp(P, wide, s);
+    }
     static int no_pp = -1;
     if (no_pp < 0) { const char* e = getenv("OFD_NO_PINGPONG"); no_pp = (e && atoi(e)) ? 1 : 0; }
     static int use_rw = -1;

@@ -1,0 +1,325 @@
+// 3x3 implicit-GEMM convolution with WAVE-PRIVATE weights (gfx950, MFMA 32x32x16 bf16, fp32 accumulate, NHWC bf16).
+//
+// Same operation, prologue / epilogue fusions and data layouts as conv_igemm.hip (the reference's F.conv2d calls at
+// denoising_diffusion.py:114,200,297,339,354 with the GroupNorm-apply + SiLU of DD:181-187 in the loader); what changes is who
+// owns which operand.  In conv_igemm.hip the four waves of a workgroup share a weight slab in LDS: one workgroup barrier, one
+// register -> LDS weight copy and ~7 VALU / SALU instructions per MFMA -- measured 43 % MFMA-busy (profiles/r02_sq_counters.json).
+// Here
+//   * a wave owns a 32-output-channel slice and ALL 8 rows of a 8 x 32 pixel block: its MFMA A operand (weights) is then private
+//     to the wave and is read straight from global memory / L2 into registers as ONE 16-byte load per lane per fragment
+//     (weights are stored [tap][Cin/8][Cout][8], an A fragment is two contiguous 512-byte runs), six fragments ahead of its use:
+//     no weight traffic through LDS, no per-tap barrier, no staging VALU;
+//   * only the input tile (+halo) goes through LDS, 32 channels at a time, DOUBLE buffered: the tile of chunk k+1 is fetched
+//     while chunk k computes and written (after the prologue transform) behind its first MFMAs: ONE workgroup barrier per
+//     144 MFMAs per wave, at which nobody waits for memory;
+//   * a pixel fragment read from LDS feeds the three kernel rows: 10 row fragments per (kx, k-step) for 24 MFMAs
+//     (0.42 ds_read_b128 per MFMA against 0.75), every read = one base register + immediate.
+// Workgroup = 4 waves = NS channel slices x PH row blocks: <4,1> = 8 x 32 pixels x 128 channels, <2,2> = 16 x 32 pixels x 64 channels.
+#include <cstdlib>
+#include "common.h"
+#include "conv_params.h"
+#include "mfma_util.h"
+
+namespace ofd {
+
+namespace wp {
+
+constexpr int NTHREADS = 256, CK = 32, NC = CK / 8, IW = 34, TW = 32, RING = 6, FRAGS = 18;   // 18 weight fragments per 32-channel chunk
+
+template <int NS, int PH>
+struct Cfg {
+    static constexpr int BN = 32 * NS, ROWS = 8 * PH, IH = ROWS + 2, NPIX = IH * IW;
+    static constexpr int US = (NPIX + 1) * 16;               // octet row of the unit-major tile [NC][NPIX + 1][16 B]; NPIX + 1 is odd
+    static constexpr int XB = NC * US;
+    static constexpr int LDS_BYTES = 2 * XB;
+    static constexpr int XPT = (NPIX * NC + NTHREADS - 1) / NTHREADS;
+    static_assert(NS * PH == 4, "4 waves");
+    static_assert((NPIX + 1) % 2 == 1, "odd slot count keeps the staging writes of a pixel's octets on distinct banks");
+};
+
+__device__ __forceinline__ float silu_f(float y) { return y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+
+__device__ __forceinline__ bf16x8 as_frag(u4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// butterfly reduction of 8 per-lane values over the wave: afterwards the lanes with (lane & 7) == 0 ... hold in v[0] the total
+// of value index (lane >> 3) (same scheme as conv_igemm.hip's WaveReduce)
+__device__ __forceinline__ void wave_reduce8(float (&v)[8]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool up = (lane & 32) != 0;
+        const float send = up ? v[i] : v[i + 4], keep = up ? v[i + 4] : v[i];
+        v[i] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bool up = (lane & 16) != 0;
+        const float send = up ? v[i] : v[i + 2], keep = up ? v[i + 2] : v[i];
+        v[i] = keep + __shfl_xor(send, 16, 64);
+    }
+    {
+        const bool up = (lane & 8) != 0;
+        const float send = up ? v[0] : v[1], keep = up ? v[1] : v[0];
+        v[0] = keep + __shfl_xor(send, 8, 64);
+    }
+    v[0] += __shfl_xor(v[0], 4, 64);
+    v[0] += __shfl_xor(v[0], 2, 64);
+    v[0] += __shfl_xor(v[0], 1, 64);
+}
+
+// PRO: the GroupNorm-affine + SiLU prologue is compiled in (P.in_scale != nullptr).  The chunk body below is ONE basic block (no
+// run-time branch between its 144 MFMAs), so that the scheduler can put the LDS reads of a group behind the MFMAs of the previous one.
+template <int NS, int PH, bool PRO>
+__global__ void __launch_bounds__(NTHREADS, 2) conv3x3_wp_kernel(const ConvParams P) {
+    using C = Cfg<NS, PH>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ns = wave % NS, ph = wave / NS;
+
+    // XCD-aware tile order (blocks that share an XCD get a contiguous run of tiles: halo rows of neighbours hit one L2)
+    const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
+    const int tpi = P.tiles_x * tiles_y, ntiles = tpi * P.B;
+    int tile = blockIdx.x;
+    if (ntiles >= 8) {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int b = tile / tpi, t_in = tile % tpi;
+    const int oy0 = (t_in / P.tiles_x) * C::ROWS, ox0 = (t_in % P.tiles_x) * TW;
+    const int n0 = blockIdx.y * C::BN;
+    const int cb = n0 + 32 * ns;                      // this wave's 32 output channels
+
+    // ---- weights: buffer loads, per-lane offset fixed for the launch, per-fragment offset scalar
+    const int cin8 = P.Cin_total / 8, n32 = P.total_chunks * 2;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.weight, 0, 9 * P.Cin_total * P.Cout * 2, 0x00020000);
+    const int w_lane = (half * P.Cout + cb + l31) * 16;
+    const int w_row = P.Cout * 16;                    // bytes per [Cin/8] row
+    auto load_w = [&](int kc, int fi) -> u4 {         // fragment fi = (ks, kx, ky) of 32-channel chunk kc
+        const int g = fi / 3, ky = fi % 3, ks = g / 3, kx = g % 3;
+        const int row = (ky * 3 + kx) * cin8 + kc * NC + ks * 2;
+        return __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane, row * w_row, 0));
+    };
+    u4 ring[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) ring[i] = load_w(0, i);
+
+    // ---- input staging map (invariant over the chunks): unit u = tid + i * 256 -> octet c8 = tid % 4, tile pixel p = u / 4
+    const int c8 = tid % NC;
+    int pyx[C::XPT];            // clamped source row << 16 | clamped source column (of the OUTPUT-resolution image)
+    unsigned okmask = 0;
+#pragma unroll
+    for (int i = 0; i < C::XPT; ++i) {
+        const int p = min(tid / NC + i * (NTHREADS / NC), C::NPIX - 1);
+        const int ty = p / IW, tx = p - ty * IW;
+        const int iy = oy0 - 1 + ty, ix = ox0 - 1 + tx;
+        const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+        okmask |= (ok ? 1u : 0u) << i;
+        pyx[i] = (min(max(iy, 0), P.H - 1) << 16) | min(max(ix, 0), P.W - 1);
+    }
+
+    int src_i = 0, src_first = 0;                     // source that owns 64-channel chunk kc >> 1, and its first 64-channel chunk
+    auto load_x = [&](int kc, u4 (&xs)[C::XPT]) {
+        const int k64 = kc >> 1;
+        while (k64 >= src_first + P.src[src_i].chunks) {
+            src_first += P.src[src_i].chunks;
+            ++src_i;
+        }
+        const ConvSrcDev& S = P.src[src_i];
+        const bf16_t* base = S.ptr + (size_t)b * S.SH * S.SW * S.src_channels + S.ch_offset + (k64 - src_first) * 64 + (kc & 1) * CK + c8 * 8;
+        const int up = S.mode == 1 ? 1 : 0;           // nearest x2 up-sampling of the source (DD:91) is a shift of the coordinates
+#pragma unroll
+        for (int i = 0; i < C::XPT; ++i) {
+            const int sy = (pyx[i] >> 16) >> up, sx = (pyx[i] & 0xffff) >> up;
+            xs[i] = *(const u4*)(base + ((size_t)sy * S.SW + sx) * S.src_channels);
+        }
+    };
+    auto write_x = [&](int kc, const u4 (&xs)[C::XPT], unsigned char* xbuf) {
+        float ps[8], pb[8];
+        if constexpr (PRO) {
+            const float* sp = P.in_scale + (size_t)b * P.Cin_total + kc * CK + c8 * 8;
+            const float* bp = P.in_shift + (size_t)b * P.Cin_total + kc * CK + c8 * 8;
+            *(float4*)&ps[0] = *(const float4*)sp; *(float4*)&ps[4] = *(const float4*)(sp + 4);
+            *(float4*)&pb[0] = *(const float4*)bp; *(float4*)&pb[4] = *(const float4*)(bp + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < C::XPT; ++i) {
+            const int p = min(tid / NC + i * (NTHREADS / NC), C::NPIX - 1);
+            u4 v = xs[i];
+            if constexpr (PRO) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = silu_f(bf2f((bf16_t)(v[j] & 0xffffu)) * ps[2 * j] + pb[2 * j]);
+                    const float hi = silu_f(bf2f((bf16_t)(v[j] >> 16)) * ps[2 * j + 1] + pb[2 * j + 1]);
+                    v[j] = f2bf2(lo, hi);
+                }
+            }
+            const bool ok = (okmask >> i) & 1u;       // zero padding is applied AFTER the prologue (DD:181-187 -> DD:114)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
+            *(u4*)(xbuf + c8 * C::US + p * 16) = v;
+        }
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[r][k] = 0.0f;
+
+    u4 xs[C::XPT];
+    load_x(0, xs);
+    write_x(0, xs, smem);
+
+    const int xrow_off = half * C::US + (8 * ph * IW + l31) * 16;
+    for (int kc = 0; kc < n32; ++kc) {
+        const int kn = min(kc + 1, n32 - 1);          // past the end: the last chunk again (fetched and staged into the buffer nobody reads any more)
+        load_x(kn, xs);
+        __syncthreads();                              // tile kc complete; every wave is done reading the other buffer (chunk kc-1)
+        const unsigned char* xrow = smem + (kc & 1) * C::XB + xrow_off;
+        unsigned char* xnext = smem + ((kc + 1) & 1) * C::XB;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            const int ks = g / 3, kx = g % 3;
+            bf16x8 x[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) x[j] = *(const bf16x8*)(xrow + (j * IW + kx) * 16 + ks * 2 * C::US);
+            bf16x8 a[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int fi = g * 3 + ky;
+                a[ky] = as_frag(ring[fi % RING]);
+                ring[fi % RING] = (fi + RING < FRAGS) ? load_w(kc, fi + RING) : load_w(kn, fi + RING - FRAGS);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky], x[r + ky], acc[r], 0, 0, 0);
+            if (g == 1) write_x(kn, xs, xnext);
+        }
+    }
+
+    // ---- epilogue: bias, residual forms, bf16 16-byte stores (one v_permlane32_swap per dword pairs two register quads),
+    //      GroupNorm partial sums of the values as stored
+    float stat[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stat[i] = 0.0f;
+    const bool second = P.split > 0 && cb >= P.split;
+    bf16_t* const o_base = second ? P.out2 : P.out;
+    const bf16_t* const r_base = second ? P.residual2 : P.residual;
+    const int o_stride = P.split > 0 ? (second ? P.Cout - P.split : P.split) : P.Cout;
+    const int o_c0 = cb - (second ? P.split : 0);
+    float4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = P.bias ? *(const float4*)(P.bias + cb + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int oy = oy0 + 8 * ph + r, ox = ox0 + l31;
+        const bool ok = oy < P.H && ox < P.W && !(P.dbg & 16);
+        const size_t pix = ((size_t)b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1);
+        uint2 q[4], ra[4], rr[4];
+        if (P.res_act) {
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const uint4 t4 = *(const uint4*)(P.res_act + pix * P.Cout + cb + 8 * g + 8 * half);
+                const auto sx = __builtin_amdgcn_permlane32_swap(t4.x, t4.z, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(t4.y, t4.w, false, false);
+                ra[g] = make_uint2(sx[0], sy[0]);
+                ra[g + 1] = make_uint2(sx[1], sy[1]);
+            }
+        }
+        if (r_base) {
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const uint4 t4 = *(const uint4*)(r_base + pix * o_stride + o_c0 + 8 * g + 8 * half);
+                const auto sx = __builtin_amdgcn_permlane32_swap(t4.x, t4.z, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(t4.y, t4.w, false, false);
+                rr[g] = make_uint2(sx[0], sy[0]);
+                rr[g + 1] = make_uint2(sx[1], sy[1]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = cb + 8 * g + 4 * half;
+            float v[4] = {acc[r][4 * g] + bias4[g].x, acc[r][4 * g + 1] + bias4[g].y, acc[r][4 * g + 2] + bias4[g].z, acc[r][4 * g + 3] + bias4[g].w};
+            if (P.res_act) {
+                const uint2 t = ra[g];
+                const float4 sc = *(const float4*)(P.res_scale + (size_t)b * P.Cout + c);
+                const float4 sh = *(const float4*)(P.res_shift + (size_t)b * P.Cout + c);
+                v[0] += silu_f(bf2f((bf16_t)(t.x & 0xffffu)) * sc.x + sh.x);
+                v[1] += silu_f(bf2f((bf16_t)(t.x >> 16)) * sc.y + sh.y);
+                v[2] += silu_f(bf2f((bf16_t)(t.y & 0xffffu)) * sc.z + sh.z);
+                v[3] += silu_f(bf2f((bf16_t)(t.y >> 16)) * sc.w + sh.w);
+            }
+            if (r_base) {
+                const uint2 t = rr[g];
+                v[0] += bf2f((bf16_t)(t.x & 0xffffu));
+                v[1] += bf2f((bf16_t)(t.x >> 16));
+                v[2] += bf2f((bf16_t)(t.y & 0xffffu));
+                v[3] += bf2f((bf16_t)(t.y >> 16));
+            }
+            q[g] = make_uint2(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]));
+            if (P.gn_partial && ok) {
+                const float q0 = bf2f((bf16_t)(q[g].x & 0xffffu)), q1 = bf2f((bf16_t)(q[g].x >> 16));
+                const float q2 = bf2f((bf16_t)(q[g].y & 0xffffu)), q3 = bf2f((bf16_t)(q[g].y >> 16));
+                stat[g * 2] += (q0 + q1) + (q2 + q3);
+                stat[g * 2 + 1] += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+            const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
+            if (ok) *(uint4*)(o_base + pix * o_stride + o_c0 + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+        }
+    }
+
+    if (P.gn_partial) {
+        // layout of conv_igemm.hip, [b][8-row tile][4 slots][Cout/8][2], consumed by gn_finalize: this wave owns octets
+        // cb/8 .. cb/8 + 3 of the 8-row tile (ph); its sums go to slot ns, every other (slot, octet) of the workgroup's channel
+        // block is written as zero by the wave whose slot it is (slots ns, ns + NS, ...)
+        wave_reduce8(stat);
+        const int ty8 = oy0 / 8 + ph, tiles8 = (P.H + 7) / 8;
+        if (ty8 < tiles8) {
+            constexpr int OCT = C::BN / 8;                          // octets of the workgroup's channel block
+            constexpr int PER_WAVE = (4 / NS) * OCT * 2;            // floats this wave writes (32)
+            // lane t < PER_WAVE writes float t of this wave's share: (slot_i, octet o, sum / sum of squares)
+            const int slot_i = lane / (OCT * 2), o = (lane % (OCT * 2)) >> 1, which = lane & 1;
+            const float total = __shfl(stat[0], ((o & 3) * 2 + which) * 8, 64);      // value index k lives in lanes 8k .. 8k+7
+            if (lane < PER_WAVE) {
+                const int slot = ns + slot_i * NS;
+                const bool own = slot_i == 0 && (o >> 2) == ns;
+                const size_t base = ((((size_t)b * tiles8 + ty8) * P.tiles_x + (t_in % P.tiles_x)) * 4 + slot) * (P.Cout / 8) * 2;
+                P.gn_partial[base + (n0 / 8 + o) * 2 + which] = own ? total : 0.0f;
+            }
+        }
+    }
+}
+
+template <int NS, int PH, bool PRO>
+static int launch(const ConvParams& P, hipStream_t s) {
+    using C = Cfg<NS, PH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OFD_HIP(hipFuncSetAttribute((const void*)conv3x3_wp_kernel<NS, PH, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set = true;
+    }
+    const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
+    dim3 grid(P.tiles_x * tiles_y * P.B, P.Cout / C::BN);
+    conv3x3_wp_kernel<NS, PH, PRO><<<grid, NTHREADS, C::LDS_BYTES, s>>>(P);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+}  // namespace wp
+
+// 3x3, stride 1, sources of mode 0 (same size) or 1 (nearest x2): called from conv_forward_impl
+int launch_conv3x3_wp(const ConvParams& P, bool wide, hipStream_t s) {
+    if (P.in_scale) return wide ? wp::launch<4, 1, true>(P, s) : wp::launch<2, 2, true>(P, s);
+    return wide ? wp::launch<4, 1, false>(P, s) : wp::launch<2, 2, false>(P, s);
+}
+
+}  // namespace ofd

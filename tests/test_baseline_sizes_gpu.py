@@ -47,11 +47,11 @@ def test_c2_training_step_at_16x440x1024_is_the_mean_of_its_per_sample_steps():
 
     loss = fd.model.p_losses(tgt_, t, noise=noise, external_cond=cond)
     loss.backward()
-    assert torch.isfinite(loss) and 0 < float(loss) < 10
+    assert torch.isfinite(loss) and 0 < float(loss.detach()) < 10
     flat16 = torch.cat([p.grad.reshape(-1) for p in params]).clone()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in params)
     assert float(flat16.abs().max()) > 0
-    loss16 = float(loss)
+    loss16 = float(loss.detach())
 
     acc = torch.zeros_like(flat16, dtype=torch.float64)
     losses = []
@@ -60,7 +60,7 @@ def test_c2_training_step_at_16x440x1024_is_the_mean_of_its_per_sample_steps():
             p.grad = None
         li = fd.model.p_losses(tgt_[i:i + 1], t[i:i + 1], noise=noise[i:i + 1], external_cond=cond[i:i + 1])
         li.backward()
-        losses.append(float(li))
+        losses.append(float(li.detach()))
         acc += torch.cat([p.grad.reshape(-1) for p in params]).double()
     mean = (acc / B).float()
     assert loss16 == pytest.approx(sum(losses) / B, rel=1e-5)
@@ -85,8 +85,11 @@ def test_c2_training_step_at_16x440x1024_is_the_mean_of_its_per_sample_steps():
 
 def test_c3_ddim_50_steps_bs64_and_splat_reconstruction():
     """50-step DDIM (eta = 0: deterministic given x_T) at bs = 64, 440 x 1024, then FD:200-202's forward-splat reconstruction.
-    Chains are independent, so the first two chains of the bs-64 run must reproduce a bs-2 run from the same x_T bit for bit
-    (every kernel of the denoise step is deterministic and per-sample); outputs finite; reconstruction holes consistent."""
+    Chains are independent: (1) with the batch order reversed every chain must come out bit for bit the same (all kernels of
+    the denoise step are deterministic and per-sample); (2) a bs-2 run of the first two chains from the same x_T must agree to
+    bf16 noise -- not to the bit: the executor sizes the LinearAttention partial sums and the conv workgroup width from the
+    grid, which depends on B, so fp32 summation order differs and 50 steps carry that to ~5e-3; outputs finite; holes of
+    the reconstruction consistent across channels."""
     from opticalflowdiffusion_amd import FlowDiffuser, warp
     torch.manual_seed(0)
     B = 64
@@ -99,9 +102,15 @@ def test_c3_ddim_50_steps_bs64_and_splat_reconstruction():
     assert fd.model.is_ddim_sampling and fd.model.sampling_timesteps == 50
     with torch.no_grad():
         flow64 = fd.model.ddim_sample((B, 2, H, W), external_cond=cond, x_T=x_T)
+        rev = fd.model.ddim_sample((B, 2, H, W), external_cond=cond.flip(0).contiguous(), x_T=x_T.flip(0).contiguous())
         flow2 = fd.model.ddim_sample((2, 2, H, W), external_cond=cond[:2], x_T=x_T[:2])
     assert flow64.shape == (B, 2, H, W) and bool(torch.isfinite(flow64).all())
-    assert torch.equal(flow64[:2], flow2)
+    assert torch.equal(rev.flip(0), flow64)
+    del rev
+    for i in range(2):
+        e = rel_l2(flow64[i].cpu(), flow2[i].cpu())
+        print(f"\n  C3 chain {i}: bs-64 vs bs-2 rel-L2 {e:.2e}")
+        assert e < 2e-2
     assert not torch.equal(flow64[0], flow64[1])
     with torch.no_grad():
         rec = warp(cond, None, flow64, mode="forward")                                  # FD:200-202 (flow as the net emits it)

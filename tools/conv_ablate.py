@@ -20,12 +20,12 @@ def run_one(cin, cout, H, W, B, ks, prologue):
     a.weight = wp.data_ptr(); a.bias = bias.data_ptr(); a.out = out.data_ptr(); a.gn_partial = gn.data_ptr()
     if prologue:
         a.in_scale = sc.data_ptr(); a.in_shift = sh.data_ptr()
-    for _ in range(3):
+    for _ in range(int(os.environ.get('OFD_ABL_WARM', 40))):
         L.check(L.lib().ofd_conv_forward(ctypes.byref(a), L.stream()))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    n = 10
+    n = int(os.environ.get('OFD_ABL_N', 40))
     for _ in range(n):
         L.check(L.lib().ofd_conv_forward(ctypes.byref(a), L.stream()))
     e1.record(); torch.cuda.synchronize()
