@@ -190,7 +190,7 @@ def main():
             "unet_mfma_frac_of_peak": steps_per_s / world * B * UNET_GFLOP_PER_SAMPLE * (H * W) / (440 * 1024) / 1e3 / PEAK_BF16_TFLOPS,
         }
         if prof:
-            name = "conv_igemm_kernel<3,128>"          # dominant kernel: 27 of the 43 3x3 launches, largest total time
+            name = "conv3x3_wp_kernel<4,1>"            # dominant kernel: 25 of the 43 3x3 launches, largest total time
             k = prof[name]
             per_launch_ms = k["ms"] / max(k["launches"], 1)
             achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
@@ -200,17 +200,18 @@ def main():
             here = os.path.dirname(os.path.abspath(__file__))
             for pmc in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_summary.json")), reverse=True):
                 d = json.load(open(pmc))
-                e = d["kernels"].get("void ofd::conv_igemm_kernel<3, 128>")
-                if e and d.get("shape", [16, 440, 1024]) == [B, H, W]:
-                    traffic = (e["fetch_MB_per_launch"] + e["write_MB_per_launch"]) * 1e6
+                es = [v for k, v in d["kernels"].items() if "conv3x3_wp_kernel<4, 1" in k]     # prologue on / off instantiations
+                if es and d.get("shape") == [B, H, W]:
+                    n = sum(v["launches"] for v in es)
+                    traffic = sum((v["fetch_MB_per_launch"] + v["write_MB_per_launch"]) * v["launches"] for v in es) / n * 1e6
                     traffic_source = os.path.relpath(pmc, here)
                     break
-            line["roofline"] = {"kernel": name + " (3x3 implicit GEMM, Cout % 128 == 0)", "bound": "mfma", "achieved": achieved,
+            line["roofline"] = {"kernel": name + " (ofd::wp::conv3x3_wp_kernel<4, 1, prologue on|off>: 3x3 implicit GEMM, 128-channel blocks)", "bound": "mfma", "achieved": achieved,
                                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                                 "traffic_source": traffic_source,
                                 "algorithmic_flops_per_launch": k["flops"] / max(k["launches"], 1), "avg_launch_ms": per_launch_ms,
                                 "launches": k["launches"]}
-            c3 = [prof[n] for n in ("conv_igemm_kernel<3,128>", "conv_igemm_kernel<3,64>", "conv3x3_c64_pingpong_kernel") if n in prof]
+            c3 = [prof[n] for n in ("conv3x3_wp_kernel<4,1>", "conv3x3_wp_kernel<2,2>", "conv3x3_c64_pingpong_kernel") if n in prof]
             line["conv3x3_all_tflops"] = sum(v["flops"] for v in c3) / (sum(v["ms"] for v in c3) * 1e-3) / 1e12
             line["kernel_ms_per_step"] = {n: v["ms"] / args.steps for n, v in prof.items()}
             line["hip_events_in_timed_region"] = True      # per-kernel events cost the headline number a little; --no-profile drops them
