@@ -292,6 +292,223 @@ __global__ void __launch_bounds__(S_NT) splat_tile_kernel(const float* __restric
     }
 }
 
+// ---- scale-1 fast path of the forward splat ---------------------------------------------------------------------------------
+// scale 1, offset (0, 0), plain splat (neither grid_sample coordinates nor a pyramid mask): the reference's remap is then the
+// identity (SS:377-381 with s = 1, ox = oy = 0: `flt - 0 < 0 ? flt - 0 : (flt - 0) / 1`) -- no double arithmetic, no division.
+// The general kernel above is VALU-bound (93 M wave-instructions per launch at the benchmark size, profiles/r02_pmc_warp.json):
+// every one of its 3.06 window visits per output pixel drags the four image channels along, and the ~1 in 3 visits that touch
+// the tile run 16 branchy (corner, channel) bodies in half-empty waves.  Here
+//   phase 1 reads only the FLOW of the source window (8 bytes per visit), tests `target touches the tile` and appends the
+//           survivors' window coordinates to a list in LDS (one LDS atomic per wave and row: ballot + prefix count);
+//   phase 2 walks the list with every lane busy: image channels of survivors only (16 bytes each), corner bounds once per corner,
+//           the four channels of a corner as straight-line code.  A product is v * w in double (exact), scaled and added as a
+//           64-bit integer exactly as above; it differs from the reference's fp32-rounded product by < 2^-24 of itself, far inside
+//           what the order of the reference's float atomics moves.
+constexpr int SF_CAP = 6144;                               // survivor list entries (u16 window coordinates); overflow is handled inline
+constexpr int SF_LDS_BYTES = S_LDS_BYTES + SF_CAP * 2 + 16;
+
+__device__ __forceinline__ void sf_accumulate(unsigned long long (*acc)[S_TH][S_TW], unsigned int (*flags)[S_TW], const float (&v)[S_CG],
+                                              const double (&kd)[S_CG], float fx, float fy, int x0, int y0, int X0, int Y0, int Wo, int Ho, int cg) {
+    float w[4];
+    corner_weights(fx, fy, x0, y0, w);
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < S_CG; ++c) bad = bad || !(fabsf(v[c]) < 3.0e38f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bad = bad || !(fabsf(w[k]) < 3.0e38f);
+    double vd[S_CG];
+#pragma unroll
+    for (int c = 0; c < S_CG; ++c) vd[c] = (double)v[c] * kd[c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int lx = x0 - X0 + (k & 1), ly = y0 - Y0 + (k >> 1);
+        const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+        if (!(lx >= 0 && lx < S_TW && ly >= 0 && ly < S_TH && cx < Wo && cy < Ho)) continue;
+        if (!bad) {
+            const double wd = (double)w[k];
+#pragma unroll
+            for (int c = 0; c < S_CG; ++c)
+                if (c < cg) {
+                    const double d = __builtin_fma(vd[c], wd, 6755399441055744.0);          // round(v w 2^sh): the 1.5 * 2^52 trick
+                    atomicAdd(&acc[c][ly][lx], (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll));
+                }
+        } else {                                            // a non-finite input or weight: per product, with the IEEE flags (rare)
+#pragma unroll
+            for (int c = 0; c < S_CG; ++c)
+                if (c < cg) {
+                    const float val = v[c] * w[k];
+                    if (fabsf(val) < 3.0e38f) {
+                        const double d = __builtin_fma((double)val, kd[c], 6755399441055744.0);
+                        atomicAdd(&acc[c][ly][lx], (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll));
+                    } else {
+                        const unsigned bit = (val != val) ? 1u : (val > 0.0f ? 2u : 4u);
+                        atomicOr(&flags[ly][lx], bit << (3 * c));
+                    }
+                }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(S_NT) splat_tile_fast_kernel(const float* __restrict__ in, const float* __restrict__ flow,
+                                                               float* __restrict__ out, unsigned long long* __restrict__ far_list,
+                                                               unsigned int* __restrict__ far_count, unsigned int far_cap,
+                                                               const unsigned int* __restrict__ absmax, SplatGeom g, int c0, int cg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_lds[];
+    unsigned long long(*acc)[S_TH][S_TW] = (unsigned long long(*)[S_TH][S_TW])s_lds;          // [S_CG][S_TH][S_TW]
+    unsigned int(*flags)[S_TW] = (unsigned int(*)[S_TW])(s_lds + S_CG * S_TH * S_TW * 8);
+    unsigned short* list = (unsigned short*)(s_lds + S_LDS_BYTES);
+    unsigned int* list_n = (unsigned int*)(s_lds + S_LDS_BYTES + SF_CAP * 2);
+    __shared__ float k_s[S_CG];
+    __shared__ double kinv_s[S_CG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // XCD-aware tile order: workgroups whose ids are equal mod 8 share an XCD (L2) and get a contiguous run of tiles, so the
+    // window overlap of neighbouring tiles (3.06 visits per pixel) is served by one L2 instead of eight
+    const int ntile = g.ntx * g.nty * g.B;
+    int t = blockIdx.x;
+    if (ntile >= 8) {
+        const int q = ntile / 8, r = ntile % 8, xcd = t % 8, idx = t / 8;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tx = t % g.ntx, ty = (t / g.ntx) % g.nty, n = t / (g.ntx * g.nty);
+    const int X0 = tx * S_TW, Y0 = ty * S_TH;
+
+    for (int i = tid; i < S_CG * S_TH * S_TW; i += S_NT) (&acc[0][0][0])[i] = 0ull;
+    for (int i = tid; i < S_TH * S_TW; i += S_NT) (&flags[0][0])[i] = 0u;
+    if (tid == 0) *list_n = 0u;
+
+    const int fx0 = X0, fx1 = (tx == g.ntx - 1) ? g.W : X0 + S_TW, fy0 = Y0, fy1 = (ty == g.nty - 1) ? g.H : Y0 + S_TH;
+    const int wx0 = max(0, fx0 - g.radius), wx1 = min(g.W, fx1 + g.radius);
+    const int wy0 = max(0, fy0 - g.radius), wy1 = min(g.H, fy1 + g.radius);
+    const int ww = wx1 - wx0, wh = wy1 - wy0;            // <= 128 each (checked by the host)
+    const int plane = g.H * g.W;
+    const float* flow_n = flow + (size_t)n * 2 * plane;
+    const float* in_n = in + ((size_t)n * g.C + c0) * plane;
+
+    if (tid < S_CG) {
+        const float v = (tid < cg) ? __uint_as_float(absmax[(size_t)n * g.C + c0 + tid]) : 0.0f;
+        int e = 0;
+        if (v > 0.0f) frexpf(v, &e);
+        int sh = S_FIX - e;
+        sh = min(max(sh, -100), 126);
+        k_s[tid] = ldexpf(1.0f, sh);
+        kinv_s[tid] = ldexp(1.0, -sh);
+    }
+    __syncthreads();
+    double kd[S_CG];
+#pragma unroll
+    for (int c = 0; c < S_CG; ++c) kd[c] = (double)k_s[c];
+
+    // ---- phase 1: flow of the window -> survivors.  Thread -> window column tid % 128, rows tid / 128 + 8 i
+    constexpr int S_U = 7, S_COLS = 128, S_ROWS = S_NT / S_COLS;
+    const int col = tid % S_COLS;
+    const int xw = wx0 + min(col, ww - 1);
+    for (int r0 = tid / S_COLS; r0 < wh; r0 += S_ROWS * S_U) {
+        float f0[S_U], f1[S_U];
+#pragma unroll
+        for (int u = 0; u < S_U; ++u) {
+            const int pix = (wy0 + min(r0 + u * S_ROWS, wh - 1)) * g.W + xw;
+            f0[u] = flow_n[pix];
+            f1[u] = flow_n[plane + pix];
+        }
+#pragma unroll
+        for (int u = 0; u < S_U; ++u) {
+            const int r = r0 + u * S_ROWS, y = wy0 + min(r, wh - 1), x = xw;
+            const float fx = (float)x + f0[u], fy = (float)y + f1[u];
+            const bool ok = r < wh && col < ww && isfinite(fx) && isfinite(fy);
+            const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
+            const int lx0 = x0 - X0, ly0 = y0 - Y0;
+            const bool touches = ok && (lx0 >= -1) && (lx0 < S_TW) && (ly0 >= -1) && (ly0 < S_TH);
+            // append (r, col) to the list: one LDS atomic per wave
+            const unsigned long long m = __ballot(touches);
+            unsigned base = 0;
+            if (m) {
+                if (lane == 0) base = atomicAdd(list_n, (unsigned)__popcll(m));
+                base = __shfl(base, 0, 64);
+            }
+            const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (touches) {
+                if (slot < (unsigned)SF_CAP) {
+                    list[slot] = (unsigned short)((r << 7) | col);
+                } else {                                    // list full (flows converging on this tile): done in place
+                    float v[S_CG];
+                    const int pix = y * g.W + x;
+#pragma unroll
+                    for (int c = 0; c < S_CG; ++c) v[c] = (c < cg) ? in_n[(size_t)c * plane + pix] : 0.0f;
+                    sf_accumulate(acc, flags, v, kd, fx, fy, x0, y0, X0, Y0, g.Wo, g.Ho, cg);
+                }
+            }
+            // far corners (|displacement| > radius): as in the general kernel, by the workgroup that owns the source pixel
+            const bool own = ok && (x >= fx0) && (x < fx1) && (y >= fy0) && (y < fy1);
+            const bool maybe_far = fabsf(fx - (float)x) >= (float)(g.radius - 2) || fabsf(fy - (float)y) >= (float)(g.radius - 2);
+            if (own && c0 == 0 && maybe_far) {
+                unsigned mask = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
+                    if (cx < 0 || cx >= g.Wo || cy < 0 || cy >= g.Ho) continue;
+                    int lo, hi;
+                    footprint(cx / S_TW, g.ntx, S_TW, 1, g.W, lo, hi);
+                    bool near = (x >= lo - g.radius) && (x < hi + g.radius);
+                    footprint(cy / S_TH, g.nty, S_TH, 1, g.H, lo, hi);
+                    near = near && (y >= lo - g.radius) && (y < hi + g.radius);
+                    if (!near) mask |= 1u << k;
+                }
+                if (mask) {
+                    const unsigned s_ = atomicAdd(far_count, 1u);
+                    if (s_ < far_cap) far_list[s_] = ((unsigned long long)((size_t)n * plane + (size_t)(y * g.W + x)) << 4) | mask;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: the survivors, every lane busy; S_V entries per thread in flight
+    const int count = (int)min(*list_n, (unsigned)SF_CAP);
+    constexpr int S_V = 3;
+    for (int i0 = tid; i0 < count; i0 += S_NT * S_V) {
+        int px[S_V];
+        float f0[S_V], f1[S_V], v[S_V][S_CG];
+        int xs[S_V], ys[S_V];
+        bool live[S_V];
+#pragma unroll
+        for (int u = 0; u < S_V; ++u) {
+            const int i = i0 + u * S_NT;
+            live[u] = i < count;
+            const unsigned e = list[min(i, count - 1)];
+            ys[u] = wy0 + (int)(e >> 7);
+            xs[u] = wx0 + (int)(e & 127u);
+            px[u] = ys[u] * g.W + xs[u];
+            f0[u] = flow_n[px[u]];
+            f1[u] = flow_n[plane + px[u]];
+#pragma unroll
+            for (int c = 0; c < S_CG; ++c) v[u][c] = (c < cg) ? in_n[(size_t)c * plane + px[u]] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < S_V; ++u) {
+            if (!live[u]) continue;
+            const float fx = (float)xs[u] + f0[u], fy = (float)ys[u] + f1[u];
+            sf_accumulate(acc, flags, v[u], kd, fx, fy, floor_to_int(fx), floor_to_int(fy), X0, Y0, g.Wo, g.Ho, cg);
+        }
+    }
+    __syncthreads();
+
+    const size_t oplane = (size_t)g.Ho * g.Wo;
+    float* out_n = out + ((size_t)n * g.C + c0) * oplane;
+    for (int i = tid; i < cg * S_TH * S_TW; i += S_NT) {
+        const int c = i / (S_TH * S_TW), r = (i / S_TW) % S_TH, cl = i % S_TW;
+        const int oy_ = Y0 + r, ox_ = X0 + cl;
+        if (oy_ < g.Ho && ox_ < g.Wo) {
+            float v = (float)((double)(long long)acc[c][r][cl] * kinv_s[c]);
+            const unsigned f = (flags[r][cl] >> (3 * c)) & 7u;
+            if (f) {
+                const float inf = __builtin_huge_valf();
+                v = ((f & 1u) || (f & 6u) == 6u) ? __builtin_nanf("") : ((f & 2u) ? inf : -inf);
+            }
+            out_n[(size_t)c * oplane + (size_t)oy_ * g.Wo + ox_] = v;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) splat_far_kernel(const float* __restrict__ in, const float* __restrict__ flow,
                                                         float* __restrict__ out, const unsigned long long* __restrict__ far_list,
                                                         const unsigned int* __restrict__ far_count, unsigned int far_cap, SplatGeom g) {
@@ -1190,7 +1407,7 @@ extern "C" size_t ofd_splat_workspace_bytes(int B, int H, int W) {
 
 extern "C" int ofd_splat_fwd(const float* in, const float* flow, float* out, int B, int C, int H, int W, int scale,
                              int offset_x, int offset_y, int radius, void* workspace, size_t workspace_bytes, void* stream) {
-    SplatGeom g;
+    SplatGeom g{};
     int rc = make_geom(g, B, C, H, W, scale, offset_x, offset_y, radius);
     if (rc) return rc;
     OFD_CHECK_ARG(in && flow && out && workspace, "splat_fwd: null pointer");
@@ -1217,10 +1434,19 @@ static int splat_launch(const float* in, const float* flow, float* out, const Sp
         splat_absmax_kernel<<<dim3(gx, B * C), 256, 0, s>>>(in, absmax, plane);
     }
     static bool attr = false;
-    if (!attr) { OFD_HIP(hipFuncSetAttribute((const void*)splat_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES)); attr = true; }
+    if (!attr) {
+        OFD_HIP(hipFuncSetAttribute((const void*)splat_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
+        OFD_HIP(hipFuncSetAttribute((const void*)splat_tile_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES));
+        attr = true;
+    }
+    static int no_fast = -1;
+    if (no_fast < 0) { const char* e = getenv("OFD_SPLAT_NO_FAST"); no_fast = (e && atoi(e)) ? 1 : 0; }
+    // fast path: identity remap and a window that fits the 7-bit list coordinates (radius <= 32)
+    const bool fast = g.scale == 1 && g.ox == 0 && g.oy == 0 && !g.grid && g.pyr_L == 0 && g.radius >= 3 && S_TW + 2 * g.radius <= 128 && !no_fast;
     for (int c0 = 0; c0 < C; c0 += S_CG) {
         const int cg = (C - c0 < S_CG) ? (C - c0) : S_CG;
-        splat_tile_kernel<<<dim3(g.ntx, g.nty, B), S_NT, S_LDS_BYTES, s>>>(in, flow, out, list, count, cap, absmax, g, c0, cg);
+        if (fast) splat_tile_fast_kernel<<<g.ntx * g.nty * B, S_NT, SF_LDS_BYTES, s>>>(in, flow, out, list, count, cap, absmax, g, c0, cg);
+        else splat_tile_kernel<<<dim3(g.ntx, g.nty, B), S_NT, S_LDS_BYTES, s>>>(in, flow, out, list, count, cap, absmax, g, c0, cg);
     }
     splat_far_kernel<<<256, 256, 0, s>>>(in, flow, out, list, count, cap, g);
     OFD_LAUNCH_CHECK();
@@ -1353,7 +1579,7 @@ extern "C" int ofd_pyramid_charbonnier_bwd(const float* Tin, const float* Ttg, c
 
 extern "C" int ofd_splat_corners(const float* flow, int32_t* corners, int B, int H, int W, int scale, int offset_x,
                                  int offset_y, void* stream) {
-    SplatGeom g;
+    SplatGeom g{};
     int rc = make_geom(g, B, 1, H, W, scale, offset_x, offset_y, 0);
     if (rc) return rc;
     OFD_CHECK_ARG(flow && corners, "splat_corners: null pointer");
@@ -1364,7 +1590,7 @@ extern "C" int ofd_splat_corners(const float* flow, int32_t* corners, int B, int
 
 extern "C" int ofd_splat_bwd_in(const float* flow, const float* outgrad, float* ingrad, int B, int C, int H, int W,
                                 int scale, int offset_x, int offset_y, void* stream) {
-    SplatGeom g;
+    SplatGeom g{};
     int rc = make_geom(g, B, C, H, W, scale, offset_x, offset_y, 0);
     if (rc) return rc;
     OFD_CHECK_ARG(flow && outgrad && ingrad, "splat_bwd_in: null pointer");
@@ -1375,7 +1601,7 @@ extern "C" int ofd_splat_bwd_in(const float* flow, const float* outgrad, float* 
 
 extern "C" int ofd_splat_bwd_flow(const float* in, const float* flow, const float* outgrad, float* flowgrad, int B,
                                   int C, int H, int W, int scale, int offset_x, int offset_y, void* stream) {
-    SplatGeom g;
+    SplatGeom g{};
     int rc = make_geom(g, B, C, H, W, scale, offset_x, offset_y, 0);
     if (rc) return rc;
     OFD_CHECK_ARG(in && flow && outgrad && flowgrad, "splat_bwd_flow: null pointer");
@@ -1440,7 +1666,7 @@ extern "C" int ofd_grid_warp_bwd(const float* second, const float* flow, const f
     if (grad_second) {
         // adjoint of the bilinear gather = bilinear scatter of grad_out to the same four corners: the splat kernel with
         // grid_sample's coordinates (bit-identical corner indices to ofd_grid_warp_fwd)
-        SplatGeom g;
+        SplatGeom g{};
         int rc = make_geom(g, B, C, H, W, 1, 0, 0, radius);
         if (rc) return rc;
         g.grid = 1;
