@@ -218,14 +218,126 @@ class FlowDiffuser(_Base):
         })
         return loss
 
-    @torch.no_grad()
+    def _log_image(self, key, images):
+        """`self.logger.log_image(key=, images=, step=)` when the trainer attached a logger with that method (W&B in the
+        reference, FD:296-347); kept in `self.logged_images` otherwise."""
+        logger = getattr(self, "logger", None)
+        if logger is not None and hasattr(logger, "log_image"):
+            logger.log_image(key=key, images=images, step=getattr(self, "global_step", 0))
+        else:
+            if not hasattr(self, "logged_images"):
+                self.logged_images = {}
+            self.logged_images[key] = images
+
     def validation_step(self, batch, batch_idx):
-        """FD:237-281 without the W&B image logging (FD:283-364, out of scope)."""
+        """FD:237-364: validation loss, a full sampling run, 19 logged scalars incl. `val/mse` and `val/ideal_loss` (the loss
+        of the ground-truth flow pushed through `model_out_override`, FD:256-259), flow colour images, mid-trajectory strips
+        (`[:, ::50]`), `val/last_step` and the `grad_flow` image (the loss gradient w.r.t. the sampled flow, through the splat
+        backward kernels, FD:351-364).  The reference is only coherent for target in {target, joint} (with target == flow its
+        `ideal_loss` is undefined and the call raises NameError); here the flow target logs the scalars that exist."""
+        from .visualization import flow_to_image
         img, tgt, flow = batch
         tgt_, cond, flow_ = self.preprocess(batch, aug=False)
-        loss = self.loss(tgt_, cond, flow_)
-        samples, flow_pred = self.sample(cond, flow_)
-        final_flow = flow_pred[:, -1] if flow_pred.dim() == 5 else flow_pred
-        self.log_dict({"val/loss": loss,
-                       "val/flow_mse": torch.nn.functional.mse_loss(final_flow[:, -2:], flow_)}, sync_dist=True)
+        bsz = img.shape[0]
+        warped_target = self.target in ("target", "joint")
+
+        with torch.no_grad():
+            loss = self.loss(tgt_, cond, flow_)
+            samples, p_flows = self.sample(cond, flow_)
+            mid_samples = mid_flows = None
+            if self.is_diffusion and warped_target:
+                mid_samples = samples[:, ::50]                               # FD:246
+                samples = samples[:, -1]
+                if self.target == "target":
+                    p_flows = [None] + [p * self.flow_max for p in p_flows[1:]]
+                    mid_flows = p_flows[1::50]
+                    p_flows = p_flows[-1]
+                else:
+                    mid_flows = p_flows[:, ::50] * self.flow_max
+                    p_flows = p_flows[:, -1] * self.flow_max
+            elif self.is_diffusion:                                          # flow target: trajectory of flows, one reconstruction
+                p_flows = p_flows[:, -1] * self.flow_max
+            else:
+                p_flows = p_flows * self.flow_max if not warped_target else p_flows
+            # samples / tgt live in [-1, 1] / [0, 1] exactly as in the reference's comparison (FD:255)
+            mse = torch.nn.functional.mse_loss(torch.nan_to_num(samples), tgt)
+            scalars = {
+                "val/loss": loss, "val/mse": mse,
+                "val/cond_min": torch.min(cond), "val/cond_max": torch.max(cond), "val/cond_mean": torch.mean(cond),
+                "val/cond_std": torch.mean(torch.std(cond, dim=0)),
+                "val/flow_min": torch.min(flow), "val/flow_max": torch.max(flow), "val/flow_mean": torch.mean(flow),
+                "val/flow_std": torch.mean(torch.std(flow, dim=0)),
+                "val/samples_min": torch.min(torch.nan_to_num(samples)), "val/samples_max": torch.max(torch.nan_to_num(samples)),
+                "val/samples_mean": torch.nanmean(samples), "val/samples_std": torch.mean(torch.std(torch.nan_to_num(samples), dim=0)),
+                "val/p_flow_min": torch.min(p_flows), "val/p_flow_max": torch.max(p_flows), "val/p_flow_mean": torch.mean(p_flows),
+                "val/p_flow_std": torch.mean(torch.std(p_flows, dim=0)),
+                "val/flow_mse": torch.nn.functional.mse_loss(p_flows / self.flow_max, flow_),
+            }
+            if self.is_diffusion and warped_target:                          # FD:256-259
+                ideal_img = warp(cond[:, :self.dim], None, flow_ * self.flow_max, mode="forward")
+                if self.target == "target":
+                    scalars["val/ideal_loss"] = self.loss(tgt_, cond, flow_, override=(ideal_img, flow_))
+                else:
+                    scalars["val/ideal_loss"] = self.loss(tgt_, cond, flow_, override=(torch.cat((ideal_img, flow_), dim=1), None))
+            self.log_dict(scalars, sync_dist=True)
+
+            def chunk(x):
+                x = x.clone()
+                x[:, 0, 0, 0] = x[:, 0, 0, 0] * 0.95                        # FD:285: not completely white
+                return list(torch.chunk(x, bsz))
+
+            flos = flow_to_image(torch.cat((flow, p_flows, flow - p_flows), dim=0)) / 255.0      # FD:289-292
+            gt_flow, sample_flow, diff_flow = flos[:bsz], flos[bsz:2 * bsz], flos[2 * bsz:]
+            self._log_image("original", chunk(img))
+            self._log_image("target", chunk(tgt))
+            self._log_image("diffusion_tgt", chunk((tgt_[:, :self.dim] + 1.0) * 0.5) if tgt_.shape[1] >= self.dim else chunk(tgt))
+            self._log_image("original_warped", chunk(warp(img, None, flow, mode="forward")))
+            self._log_image("gt_flow", chunk(gt_flow))
+            self._log_image("target_p", chunk(sample_flow))
+            self._log_image("concat", chunk(torch.cat((gt_flow, sample_flow), dim=3)))
+            self._log_image("difference", chunk(diff_flow))
+            self._log_image("samples", chunk(samples))
+
+            if self.is_diffusion and warped_target:                          # FD:317-338: strips of every 50th step
+                strip = torch.cat(torch.chunk(mid_samples, mid_samples.shape[1], dim=1), dim=-1)[:, 0]
+                strip = torch.clamp(torch.nan_to_num(strip), -1.0, 1.0)
+                if self.target == "target":
+                    fstrip = torch.cat([flow_to_image(m) / 255.0 for m in mid_flows], dim=-1)
+                else:
+                    shp = list(mid_flows.shape)
+                    fl = flow_to_image(mid_flows.reshape(-1, 2, shp[-2], shp[-1])) / 255.0
+                    shp[2] = 3
+                    fstrip = torch.cat(torch.chunk(fl.reshape(shp), shp[1], dim=1), dim=-1)[:, 0]
+                self._log_image("mid_samples", chunk(strip))
+                self._log_image("mid_flows", chunk(fstrip))
+                # FD:341-349: what the network answers at t = 0 when shown the clean target
+                last_step = self.model.model(tgt_, cond, torch.zeros((bsz,), device=tgt_.device, dtype=torch.long), None, additional_out=True)
+                last_step = last_step[:, -2:]
+                self.log_dict({"val/last_step": torch.nn.functional.mse_loss(last_step, flow_)}, sync_dist=True)
+                fl2 = flow_to_image(torch.cat((flow_, last_step), dim=0)) / 255.0
+                self._log_image("last_step", chunk(torch.cat((fl2[:bsz], fl2[bsz:]), dim=-1)))
+
+        if self.is_diffusion and warped_target:                              # FD:351-364: descent direction of the pyramid loss w.r.t. the flow
+            with torch.set_grad_enabled(True):
+                pf = p_flows.detach().clone().requires_grad_(True)
+                gl = self.model._loss(warp(cond, None, pf, mode="forward"), tgt_[:, :self.dim], None, flow_, cond, pf / self.flow_max, 0.0)
+                gl.backward()
+                grad_flow = -pf.grad.clone()
+            self._log_image("grad_flow", list(torch.chunk(flow_to_image(grad_flow) / 255.0, bsz, dim=0)))
         return loss
+
+    def log_grad_norm_stat(self):
+        """FD:367-388: gradient-norm and gradient-to-parameter-ratio statistics over the parameters that have a gradient."""
+        with torch.no_grad():
+            gn, gpr = [], []
+            for _name, p in self.named_parameters():
+                if p.grad is not None:
+                    gn.append(torch.norm(p.grad))
+                    gpr.append(torch.norm(p.grad) / torch.norm(p))
+            gn, gpr = torch.stack(gn), torch.stack(gpr)
+            self.log_dict({
+                "train/grad_norm/min": gn.min(), "train/grad_norm/max": gn.max(), "train/grad_norm/std": gn.std(),
+                "train/grad_norm/mean": gn.mean(), "train/grad_norm/median": torch.median(gn),
+                "train/gpr/min": gpr.min(), "train/gpr/max": gpr.max(), "train/gpr/std": gpr.std(), "train/gpr/mean": gpr.mean(),
+                "train/gpr/median": torch.median(gpr),
+            })

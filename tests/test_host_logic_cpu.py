@@ -87,3 +87,25 @@ def test_photometric_loss_helpers_match_reference_goldens():
     f = fill_holes_nan(g["img"], g["w"])
     assert torch.equal(torch.isnan(f), torch.isnan(g["fill_holes_nan"])) and torch.equal(torch.nan_to_num(f), torch.nan_to_num(g["fill_holes_nan"]))
     assert float(edgeaware_smoothness1(g["img"], g["flow"])) == pytest.approx(float(g["edgeaware_smoothness1"]), rel=1e-6)
+
+
+def test_flow_to_image_colour_wheel():
+    """visualization.flow_to_image (stand-in for torchvision.utils.flow_to_image, FD:289): zero flow is white, the hue follows the
+    direction, the saturation the magnitude relative to the batch maximum, opposite directions get complementary hues."""
+    from opticalflowdiffusion_amd.visualization import flow_to_image
+    z = flow_to_image(torch.zeros(1, 2, 3, 4))
+    assert z.dtype == torch.uint8 and z.shape == (1, 3, 3, 4) and bool((z == 255).all())
+    f = torch.zeros(4, 2, 1, 1)
+    f[0, 0], f[1, 0], f[2, 1], f[3, 1] = 1.0, -1.0, 1.0, -1.0            # +x, -x, +y, -y at full magnitude
+    im = flow_to_image(f)[:, :, 0, 0].int()
+    assert im[0].tolist() == [255, 0, 0]                                 # +x: red (start of the wheel)
+    assert im[1, 0] == 0 and im[1, 1] > 200 and im[1, 2] > 200           # -x: cyan
+    assert im[2, 0] > 200 and im[2, 1] > 200 and im[2, 2] == 0           # +y: yellow
+    assert im[3, 0] < 160 and im[3, 1] == 0 and im[3, 2] == 255          # -y: blue-violet
+    half = torch.zeros(2, 2, 1, 1)
+    half[0, 0], half[1, 0] = 1.0, 0.5                                    # same hue, half the magnitude -> half-way to white
+    h = flow_to_image(half)[:, :, 0, 0].int()
+    assert h[1].tolist() == [255, 127, 127]
+    assert flow_to_image(torch.randn(2, 5, 7)).shape == (3, 5, 7)
+    with pytest.raises(ValueError):
+        flow_to_image(torch.zeros(1, 3, 4, 4))

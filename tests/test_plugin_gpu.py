@@ -372,3 +372,41 @@ def _eager(net, x, c, t):
     out = net(x, external_cond=c, time=t).clone()
     net.set_graph(True)
     return out
+
+
+@pytest.mark.parametrize("target", ["joint", "target"])
+def test_validation_step_diagnostics(target):
+    """FD:237-364 for the two warped targets: the reference's 19 `val/*` scalars (incl. `val/mse`, `val/ideal_loss` through the
+    `override=` path FD:256-259), `val/last_step`, every image key it logs, the mid-trajectory strips (`[:, ::50]`) and the
+    `grad_flow` image from `_loss` backward through the splat kernels (FD:351-364)."""
+    from opticalflowdiffusion_amd import FlowDiffuser
+    torch.manual_seed(3)
+    H, W, B, T = 32, 48, 2, 100
+    fd = FlowDiffuser(dict(target=target, image_size=[H, W], timesteps=T, flow_max=20, zero_init=False)).cuda()
+    img, tgt = torch.rand(B, 3, H, W).cuda(), torch.rand(B, 3, H, W).cuda()
+    flow = ((torch.rand(B, 2, H, W) * 2 - 1) * 6).cuda()
+    loss = fd.validation_step((img, tgt, flow), 0)
+    want = ["val/loss", "val/mse", "val/ideal_loss", "val/last_step"] + [f"val/{a}_{b}" for a in ("cond", "flow", "samples", "p_flow")
+                                                                          for b in ("min", "max", "mean", "std")]
+    assert len(want) == 20
+    for k in want:
+        assert k in fd.logged and bool(torch.isfinite(fd.logged[k])), k
+    assert float(loss) == pytest.approx(float(fd.logged["val/loss"]))
+    # the ground-truth flow pushed through the override path must beat the untrained net's own prediction on the pyramid loss
+    assert float(fd.logged["val/ideal_loss"]) < float(fd.logged["val/loss"])
+    imgs = fd.logged_images
+    for k in ("original", "target", "diffusion_tgt", "original_warped", "gt_flow", "target_p", "concat", "difference", "samples",
+              "mid_samples", "mid_flows", "last_step", "grad_flow"):
+        assert k in imgs and len(imgs[k]) == B, k
+    nstrip = len(range(0, T + 1, 50))                                   # samples[:, ::50] of a (B, T+1, ...) trajectory
+    nflow = nstrip if target == "joint" else len(range(1, T + 1, 50))   # FD:249-250: the "target" mode slices a list that starts with None
+    assert imgs["mid_samples"][0].shape == (1, 3, H, W * nstrip) and imgs["mid_flows"][0].shape == (1, 3, H, W * nflow)
+    assert imgs["concat"][0].shape == (1, 3, H, 2 * W) and imgs["grad_flow"][0].shape == (1, 3, H, W)
+    g = torch.cat(imgs["grad_flow"])
+    assert bool(torch.isfinite(g).all()) and float(g.std()) > 0         # a non-trivial descent direction
+    # gradient-norm statistics of a training step (FD:367-388)
+    fd.training_step((img, tgt, flow), 0).backward()
+    fd.log_grad_norm_stat()
+    assert all(bool(torch.isfinite(fd.logged[f"train/grad_norm/{b}"])) for b in ("min", "max", "std", "mean", "median"))
+    assert all(f"train/gpr/{b}" in fd.logged for b in ("min", "max", "std", "mean", "median"))      # (a zero-norm parameter makes the ratio inf, as in the reference)
+    assert bool(torch.isfinite(fd.logged["train/gpr/min"])) and bool(torch.isfinite(fd.logged["train/gpr/median"]))
