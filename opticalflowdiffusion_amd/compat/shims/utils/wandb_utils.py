@@ -1,0 +1,26 @@
+"""`from utils.wandb_utils import download_latest_checkpoint, rewrite_checkpoint_for_compatibility` (main.py:9, 67-76).
+Checkpoints live on W&B servers; this box has no network, so the download raises with the local alternative spelled out,
+and the compatibility rewrite (Lightning checkpoint -> the triple-aliased key layout unet.* / _model.* / model.* the plugin's
+state dict has) works on local files."""
+import os
+
+import torch
+
+
+def download_latest_checkpoint(run_path, download_dir):
+    raise RuntimeError(f"download_latest_checkpoint({run_path!r}): W&B is unreachable here; pass a local Lightning-layout checkpoint "
+                       f"(train.py --resume <file>, or build_experiment(cfg, logger, ckpt_path))")
+
+
+def rewrite_checkpoint_for_compatibility(path):
+    """returns a path whose state dict carries every alias of the UNet's parameters (a checkpoint written from `.unet` alone
+    loads into `FlowDiffuser`, whose modules `unet`, `_model` and `model.model` share them)"""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ck.get("state_dict", ck)
+    unet = {k[len("unet."):]: v for k, v in sd.items() if k.startswith("unet.")}
+    for k, v in unet.items():
+        for prefix in ("_model.", "model.model."):
+            sd.setdefault(prefix + k, v)
+    out = os.path.splitext(str(path))[0] + ".compat.ckpt"
+    torch.save(ck, out)
+    return out

@@ -164,3 +164,25 @@ def attach_grad_sync(flow_diffuser_or_unet, bucket_bytes=32 << 20, group=None):
         raise ValueError(f"attach_grad_sync: expected exactly one engine Unet under the module, found {len(unets)}")
     unets[0].grad_sync = BucketedAllReduce(bucket_bytes, group)
     return unets[0].grad_sync
+
+
+class TorchDDP(torch.nn.Module):
+    """The plugin wrapped the way Lightning's DDPStrategy wraps it (exp_base.py:198): torch.nn.parallel.DistributedDataParallel
+    around a module whose forward is `training_step`.  The engine's parameters are ordinary leaf nn.Parameters fed by a custom
+    autograd Function, so DDP's reducer hooks see them like any other module's (tests/test_trainer_gpu.py)."""
+
+    class _Step(torch.nn.Module):
+        def __init__(self, plugin):
+            super().__init__()
+            self.plugin = plugin
+
+        def forward(self, batch, batch_idx):
+            return self.plugin.training_step(batch, batch_idx)
+
+    def __init__(self, plugin, device=None, **ddp_kwargs):
+        super().__init__()
+        ids = [device.index] if (device is not None and device.type == "cuda") else None
+        self.ddp = torch.nn.parallel.DistributedDataParallel(TorchDDP._Step(plugin), device_ids=ids, find_unused_parameters=False, **ddp_kwargs)
+
+    def training_step(self, batch, batch_idx):
+        return self.ddp(batch, batch_idx)

@@ -109,3 +109,80 @@ def test_flow_to_image_colour_wheel():
     assert flow_to_image(torch.randn(2, 5, 7)).shape == (3, 5, 7)
     with pytest.raises(ValueError):
         flow_to_image(torch.zeros(1, 3, 4, 4))
+
+
+def _write_config_tree(root):
+    """a `configurations/` tree with the reference's layout and keys (configurations/config.yaml, experiment/base.yaml,
+    experiment/matrix_flow.yaml, algorithm/flow_diffuser.yaml, dataset/sintel.yaml)"""
+    import os
+    files = {
+        "config.yaml": "defaults:\n  - experiment: matrix_flow\n  - dataset: sintel\n  - algorithm: pwc_learner\n\nwandb:\n  entity: e\n  project: p\n  mode: dryrun\n  resume: null\n",
+        "experiment/base.yaml": "tasks: [train]\nepochs: -1\ntraining:\n  precision: 32\n  data:\n    batch_size: 64\n    num_workers: 16\n    shuffle: True\n"
+                                "  optim:\n    accumulate_grad_batches: 1\n  checkpointing:\n    every_n_train_steps: 5000\n"
+                                "validation:\n  check_interval: 400\n  check_epoch: 1\n  limit_batch: 1\n  data:\n    batch_size: 8\n",
+        "experiment/matrix_flow.yaml": "defaults:\n  - base\n\nname: matrix_flow\n",
+        "algorithm/pwc_learner.yaml": "name: pwc_learner\nlr: 1e-4\n",
+        "algorithm/flow_diffuser.yaml": "name: flow_diffuser\n\nimage_size: 128\nlatent_dim: 16\nflow_max: 20\nlatent_max: 2\n\nlr: 1e-5\nflow_weight: 0.0\n"
+                                        "weight_decay: 1e-6\nis_diffusion: true\nlatent: false\ntimesteps: 1000\n\ntarget: joint\nae: px8q8g0m\nnoiser: image\n\nzero_init: true\n",
+        "dataset/sintel.yaml": "name: sintel\n\nimage_size: 512,256\n",
+    }
+    for rel, text in files.items():
+        path = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text)
+
+
+def test_compose_reads_a_reference_style_configuration_tree(tmp_path):
+    """compat.compose = what @hydra.main(config_path="configurations", config_name="config") hands main.py:30, for the override
+    grammar the reference is launched with; the result answers the probes the reference makes on its DictConfig."""
+    from opticalflowdiffusion_amd.compat import Config, compose
+    _write_config_tree(str(tmp_path))
+    cfg = compose(str(tmp_path))
+    assert cfg.algorithm.name == "pwc_learner" and cfg.experiment.name == "matrix_flow" and cfg.dataset.name == "sintel"   # config.yaml:1-4
+    assert cfg.experiment.training.data.batch_size == 64 and cfg.experiment.tasks == ["train"]           # base.yaml through `defaults: [base]`
+    assert cfg.wandb.mode == "dryrun" and cfg.wandb.get("resume", None) is None                           # main.py:46-47
+    cfg = compose(str(tmp_path), ["algorithm=flow_diffuser", "algorithm.target=flow", "experiment.training.data.batch_size=16",
+                                  "+experiment.training.clipping=100", "algorithm.lr=3e-5", "~algorithm.ae"])
+    assert cfg.algorithm.name == "flow_diffuser" and cfg.algorithm.target == "flow" and cfg.algorithm.timesteps == 1000
+    assert cfg.algorithm.lr == pytest.approx(3e-5) and cfg.algorithm.weight_decay == pytest.approx(1e-6) and "ae" not in cfg.algorithm
+    assert cfg.experiment.training.data.batch_size == 16
+    assert "clipping" in dir(cfg.experiment.training) and cfg.experiment.training.clipping == 100        # exp_base.py:191
+    assert isinstance(cfg.experiment.training, Config) and {**cfg.experiment.training.checkpointing} == {"every_n_train_steps": 5000}   # main.py:20
+    assert "zero_init" in cfg.algorithm and cfg.algorithm.zero_init is True                               # `in` probing, flow_learner.py:71-73
+    with pytest.raises(FileNotFoundError):
+        compose(str(tmp_path), ["algorithm=does_not_exist"])
+    with pytest.raises(AttributeError):
+        cfg.algorithm.no_such_key
+    # the plugin accepts the composed node as its cfg (attribute and `in` access, FD:70-129)
+    from opticalflowdiffusion_amd.flow_diffuser import _Cfg
+    c = _Cfg(cfg.algorithm)
+    assert c.target == "flow" and c.flow_max == 20 and "sampling_timesteps" in c and c.sampling_timesteps is None
+
+
+def test_utils_shim_and_import_alias(tmp_path):
+    """the `utils` package main.py:9 imports (absent from the reference repository) and the `algorithms.diffusion_animation` alias"""
+    import importlib
+    import os
+    import sys
+    shims = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "opticalflowdiffusion_amd", "compat", "shims")
+    sys.path.insert(0, shims)
+    try:
+        for m in [k for k in sys.modules if k == "utils" or k.startswith("utils.") or k == "algorithms" or k.startswith("algorithms.")]:
+            del sys.modules[m]
+        wu = importlib.import_module("utils.wandb_utils")
+        importlib.import_module("utils.video_prediction.visualization").log_video()
+        with pytest.raises(RuntimeError):
+            wu.download_latest_checkpoint("entity/project/run", tmp_path)
+        ck = tmp_path / "a.ckpt"
+        torch.save({"state_dict": {"unet.final_conv.weight": torch.ones(2), "betas": torch.zeros(3)}, "global_step": 7}, ck)
+        out = torch.load(wu.rewrite_checkpoint_for_compatibility(str(ck)), weights_only=False)
+        assert set(out["state_dict"]) == {"unet.final_conv.weight", "_model.final_conv.weight", "model.model.final_conv.weight", "betas"}
+        assert out["global_step"] == 7
+        da = importlib.import_module("algorithms.diffusion_animation")
+        import opticalflowdiffusion_amd as m
+        assert da.FlowDiffuser is m.FlowDiffuser and da.Unet is m.Unet and da.ConditionalDiffusion is m.ConditionalDiffusion
+    finally:
+        sys.path.remove(shims)
+        for m in [k for k in sys.modules if k == "utils" or k.startswith("utils.") or k == "algorithms" or k.startswith("algorithms.")]:
+            del sys.modules[m]

@@ -110,3 +110,72 @@ def test_two_rank_gradient_allreduce_on_the_gpu():
     for rank, err, moved in res:
         assert err < 1e-3, (rank, err)          # (fp32 atomics in the weight-gradient kernels: two runs differ in the last bits)
         assert moved > 1e-2                     # and it really is a different vector than the rank's own gradient
+
+
+def test_trainer_composes_a_reference_style_configuration_tree(tmp_path):
+    """`python train.py --config-dir <configurations> algorithm=flow_diffuser ...` = main.py's Hydra composition (main.py:25-30)
+    followed by exp_base.py's train(): group selection, `defaults: [base]` inheritance, leaf overrides and the keys the trainer
+    reads (batch size, lr, clipping, checkpoint interval)."""
+    import train
+    from test_host_logic_cpu import _write_config_tree
+    _write_config_tree(str(tmp_path / "configurations"))
+    fd, logs = train.main(["--steps", "2", "--log-every", "1", "--config-dir", str(tmp_path / "configurations"),
+                           "algorithm=flow_diffuser", "algorithm.target=flow", "algorithm.image_size=[32,48]", "algorithm.timesteps=20",
+                           "algorithm.zero_init=false", "experiment.training.data.batch_size=2", "+experiment.training.clipping=50",
+                           "dataset.name=synthetic"])
+    from opticalflowdiffusion_amd import FlowDiffuser
+    assert isinstance(fd, FlowDiffuser) and fd.cfg.target == "flow" and fd.cfg.lr == pytest.approx(1e-5) and fd.cfg.clip == 50.0
+    assert fd.optimizers.param_groups[0]["max_grad_norm"] == 50.0 and len(logs) == 2 and logs[-1]["global_batch"] == 2
+
+
+def _torch_ddp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      OFD_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from opticalflowdiffusion_amd import FlowDiffuser, parallel
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    parallel.init()
+    torch.manual_seed(0)                                   # same weights on every rank (DDP broadcasts rank 0's anyway)
+    fd = FlowDiffuser(dict(target="flow", image_size=[16, 32], timesteps=10, flow_max=20, zero_init=False)).to(dev)
+    fd.log_dict = lambda *a, **k: None
+    g = torch.Generator().manual_seed(100 + rank)          # different data per rank
+    batch = (torch.rand(1, 3, 16, 32, generator=g).to(dev), torch.rand(1, 3, 16, 32, generator=g).to(dev),
+             ((torch.rand(1, 2, 16, 32, generator=g) * 2 - 1) * 8).to(dev))
+    params = list(fd.model.parameters())
+
+    def grads(module):
+        for p in params:
+            p.grad = None
+        torch.manual_seed(7 + rank)                        # the same t and noise in both passes
+        module.training_step(batch, 0).backward()
+        return torch.cat([p.grad.flatten() for p in params])
+
+    local = grads(fd)                                      # this rank's own gradient
+    synced = grads(parallel.TorchDDP(fd, dev))             # through torch.nn.parallel.DistributedDataParallel (exp_base.py:198)
+    others = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(others, local)
+    want = sum(others) / world
+    q.put((rank, float((synced - want).norm() / want.norm()), float((synced - local).norm() / local.norm())))
+    dist.destroy_process_group()
+
+
+def test_plugin_trains_under_torch_distributed_data_parallel():
+    """What Lightning's DDPStrategy(find_unused_parameters=False) does to the plugin (exp_base.py:193-206): wrapped in
+    torch.nn.parallel.DistributedDataParallel, two ranks end up with the mean of their gradients -- the engine's flat-buffer
+    parameters and custom autograd Function are transparent to DDP's reducer."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_torch_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, moved in res:
+        assert err < 1e-3, (rank, err)
+        assert moved > 1e-2

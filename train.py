@@ -83,9 +83,24 @@ def main(argv=None):
     ap.add_argument("--ckpt-dir", default=None)
     ap.add_argument("--resume", default=None)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--config-dir", default=None, help="a `configurations/` tree laid out as the reference's (config.yaml + experiment/ "
+                    "algorithm/ dataset/ groups): composed the way main.py's @hydra.main does, then overlaid on the built-in defaults")
+    ap.add_argument("--ddp", choices=["hook", "torch"], default="hook", help="multi-GPU gradient averaging: the executor's bucketed "
+                    "all-reduce hook (default) or torch.nn.parallel.DistributedDataParallel around the module (what Lightning's DDPStrategy does, exp_base.py:198)")
+    ap.add_argument("overrides", nargs="*", help="Hydra-style overrides for --config-dir: group=option, a.b=value, +a.b=value, ~a.b")
     a = ap.parse_args(argv)
 
     cfg = json.loads(json.dumps(DEFAULTS))
+    if a.config_dir:
+        from opticalflowdiffusion_amd.compat import compose
+        composed = compose(a.config_dir, a.overrides).to_container()
+        if composed.get("algorithm", {}).get("name") == "flow_learner":
+            cfg["algorithm"] = dict(FLOW_LEARNER)
+        deep_update(cfg, composed)
+        size = cfg["algorithm"].get("image_size")
+        if isinstance(size, str):                          # dataset/sintel.yaml writes "512,256" (W,H)
+            w, h = (int(v) for v in size.split(","))
+            cfg["algorithm"]["image_size"] = [h, w]
     if a.config:
         deep_update(cfg, yaml.safe_load(open(a.config)) or {})
     if any(kv.replace(" ", "") == "algorithm.name=flow_learner" for kv in a.set):
@@ -106,8 +121,11 @@ def main(argv=None):
 
     fd = ALGORITHMS[alg.get("name", "flow_diffuser")](alg).to(dev)
     parallel.broadcast_parameters(fd)
-    if world > 1:
+    step_module = fd
+    if world > 1 and a.ddp == "hook":
         parallel.attach_grad_sync(fd)
+    elif world > 1:
+        step_module = parallel.TorchDDP(fd, dev)
     opt = fd.configure_optimizers()
     step, epoch = (load_checkpoint(a.resume, fd, opt) if a.resume else (0, 0))
 
@@ -129,7 +147,7 @@ def main(argv=None):
         for micro in range(accum):
             base = ((step * accum + micro) * world + rank) * B            # disjoint samples per rank and step
             batch = ds.batch(base, B, dev)
-            loss = fd.training_step(batch, step)
+            loss = step_module.training_step(batch, step)
             (loss / accum).backward()
         opt.step()
         step += 1
