@@ -461,23 +461,52 @@ class ConditionalDiffusion(nn.Module):
                                         L.ptr(pred), L.ptr(x_start), b, x[0].numel(), L.stream()))
         return pred, x_start, additional_out
 
+    def _sampling_tables(self, batch, device):
+        """per-(T, batch) views of everything a reverse step reads that does not depend on the data: timestep tensors and the
+        posterior coefficients, expanded once so that a step indexes a ROW (a view, no gather launch, no allocation)"""
+        key = (batch, str(device))
+        if getattr(self, "_samp_tab", None) is None or self._samp_tab[0] != key:
+            T = self.num_timesteps
+            rep = lambda v: v.to(device=device, dtype=torch.float32).reshape(T, 1).repeat(1, batch).contiguous()
+            sigma = (0.5 * self.posterior_log_variance_clipped).exp()
+            self._samp_tab = (key, dict(t=torch.arange(T, device=device, dtype=torch.long).reshape(T, 1).repeat(1, batch).contiguous(),
+                                        c1=rep(self.posterior_mean_coef1), c2=rep(self.posterior_mean_coef2), sigma=rep(sigma),
+                                        sr=rep(self.sqrt_recip_alphas_cumprod), srm1=rep(self.sqrt_recipm1_alphas_cumprod)))
+        return self._samp_tab[1]
+
     @torch.no_grad()
     def p_sample_loop(self, shape, return_all_timesteps=False, external_cond=None, additional_tgt=None, verbose=False, x_T=None):
-        """DD:700-729 (no per-step print / host sync).  `x_T` (optional, not in the reference): the start of the chains (DD:705)."""
+        """DD:700-729 (no per-step print / host sync).  `x_T` (optional, not in the reference): the start of the chains (DD:705).
+        A step is: one UNet call, one in-place normal_ into a reused buffer, one fused update kernel writing into the other of
+        two ping-pong images -- no per-step allocation, no coefficient gathers (rows of `_sampling_tables`)."""
         img = torch.randn(shape, device=self.device) if x_T is None else L.f32c(x_T)
         assert tuple(img.shape) == tuple(shape)
+        if additional_tgt is not None:                                                # target='target': the general step (DD:676-698)
+            imgs, additionals = [img], [None]
+            for i, t in enumerate(reversed(range(0, self.num_timesteps))):
+                img, _, additional_out = self.p_sample(img, t, None, external_cond=external_cond, additional_tgt=additional_tgt)
+                if return_all_timesteps:
+                    imgs.append(img)
+                additionals.append(additional_out)
+            return (img if not return_all_timesteps else torch.stack(imgs, dim=1)), additionals
         imgs = [img]
-        additionals = [None]
         stride = self.trajectory_stride
+        tab = self._sampling_tables(shape[0], img.device)
+        b, n = shape[0], img[0].numel()
+        pong = [torch.empty_like(img), torch.empty_like(img)]
+        noise, x_start = torch.empty_like(img), torch.empty_like(img)
+        lib = L.lib()
         for i, t in enumerate(reversed(range(0, self.num_timesteps))):
-            img, x_start, additional_out = self.p_sample(img, t, None, external_cond=external_cond, additional_tgt=additional_tgt)
+            out = L.f32c(self.model_with_condition(img, tab["t"][t], None, external_cond=external_cond))
+            if t > 0:
+                noise.normal_()                                                       # DD:687: z = 0 at t = 0
+            nxt = pong[i & 1]
+            L.check(lib.ofd_ddpm_update(L.ptr(img), L.ptr(out), L.ptr(noise) if t > 0 else None, L.ptr(tab["c1"][t]), L.ptr(tab["c2"][t]),
+                                        L.ptr(tab["sigma"][t]), L.ptr(nxt), L.ptr(x_start), b, n, L.stream()))
+            img = nxt
             if return_all_timesteps and (stride is None or (i + 1) % stride == 0 or t == 0):
-                imgs.append(img)
-            additionals.append(additional_out)
-        ret = img if not return_all_timesteps else torch.stack(imgs, dim=1)
-        if additional_tgt is not None:
-            ret = (ret, additionals)
-        return ret
+                imgs.append(img.clone())
+        return img if not return_all_timesteps else torch.stack(imgs, dim=1)
 
     # -- DDIM --------------------------------------------------------------------------------
     @torch.no_grad()
@@ -492,30 +521,31 @@ class ConditionalDiffusion(nn.Module):
         assert tuple(img.shape) == tuple(shape)
         imgs = [img]
         n = img[0].numel()
-        ac = self.alphas_cumprod
         stride = self.trajectory_stride
+        tab = self._sampling_tables(batch, img.device)
+        # the per-pair scalars of DD:757-761 for ALL pairs at once, in the reference's fp32 operation order -> one (S, 3, batch) table
+        ac = self.alphas_cumprod
+        tt = torch.tensor([p[0] for p in time_pairs], device=ac.device)
+        tn = torch.tensor([max(p[1], 0) for p in time_pairs], device=ac.device)
+        alpha, alpha_next = ac[tt], ac[tn]
+        sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+        c = (1 - alpha_next - sigma ** 2).sqrt()
+        coef = torch.stack((alpha_next.sqrt(), c, sigma), dim=1).to(torch.float32).reshape(len(time_pairs), 3, 1).repeat(1, 1, batch).contiguous()
+        pong = [torch.empty_like(img), torch.empty_like(img)]
+        noise = torch.empty_like(img) if eta > 0 else None
+        lib = L.lib()
         for i, (time, time_next) in enumerate(time_pairs):
-            tc = torch.full((batch,), time, device=device, dtype=torch.long)
-            out = self.model_with_condition(img, tc, None, external_cond=external_cond)
-            sr = self.sqrt_recip_alphas_cumprod[tc].contiguous()
-            srm1 = self.sqrt_recipm1_alphas_cumprod[tc].contiguous()
-            nxt = torch.empty_like(img)
+            out = L.f32c(self.model_with_condition(img, tab["t"][time], None, external_cond=external_cond))
             last = time_next < 0
-            if last:
-                san = cc = sg = noise = None
-            else:
-                alpha, alpha_next = ac[time], ac[time_next]
-                sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
-                c = (1 - alpha_next - sigma ** 2).sqrt()
-                san = alpha_next.sqrt().reshape(1).repeat(batch).contiguous()
-                cc = c.reshape(1).repeat(batch).contiguous()
-                sg = sigma.reshape(1).repeat(batch).contiguous()
-                noise = torch.randn_like(img)                                            # DD:763
-            L.check(L.lib().ofd_ddim_update(L.ptr(img), L.ptr(out), L.ptr(noise), L.ptr(sr), L.ptr(srm1), L.ptr(san), L.ptr(cc),
-                                            L.ptr(sg), int(last), L.ptr(nxt), None, batch, n, L.stream()))
+            if noise is not None and not last:
+                noise.normal_()                                                          # DD:763
+            nxt = pong[i & 1]
+            L.check(lib.ofd_ddim_update(L.ptr(img), L.ptr(out), L.ptr(noise) if not last else None, L.ptr(tab["sr"][time]), L.ptr(tab["srm1"][time]),
+                                        None if last else L.ptr(coef[i, 0]), None if last else L.ptr(coef[i, 1]), None if last else L.ptr(coef[i, 2]),
+                                        int(last), L.ptr(nxt), None, batch, n, L.stream()))
             img = nxt
             if return_all_timesteps and (stride is None or (i + 1) % stride == 0 or last):
-                imgs.append(img)
+                imgs.append(img.clone())
         return img if not return_all_timesteps else torch.stack(imgs, dim=1)
 
     @torch.no_grad()
