@@ -10,6 +10,7 @@
 //   pass 2  x -> LN -> q = Wq x^ -> softmax over d -> out = ctx^T q -> o = Wout out + b
 //           -> LN -> + x   (each stage's accumulator tile is the next MFMA's B operand)
 // The PreNorm gain g is folded into Wq / Wkv (W.diag(g)) when the weights are prepared.
+#include <cstdlib>
 #include "blocks.h"
 
 namespace ofd {
@@ -375,7 +376,9 @@ static int launch_la(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const
     la_ctx_combine_frag_kernel<<<dim3(B * 4, 4), 256, 0, s>>>(partial, ctxfrag, gx * 4, 1.0f / (float)n);
     int gx2 = cdiv(cdiv(n, 32), 4 * 4);     // >= 4 tiles per wave amortise the weight staging
     if (gx2 < 1) gx2 = 1;
-    if (gx2 > 128) gx2 = 128;
+    static int gx2_cap = -1;
+    if (gx2_cap < 0) { const char* e = getenv("OFD_LA_GX2"); gx2_cap = e ? atoi(e) : 128; }
+    if (gx2 > gx2_cap) gx2 = gx2_cap;
     la_out_fused_kernel<C><<<dim3(gx2, B), 256, LDS2, s>>>(x, wq, woutp, ctxfrag, bias, g2, y, n, eps_pre, eps_post, 0.17677669529663687f);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
