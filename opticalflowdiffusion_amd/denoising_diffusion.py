@@ -592,6 +592,7 @@ class ConditionalDiffusion(nn.Module):
         levels = [1, 2, 4, 8, 16]                                                      # DD:896
         s1, n1 = nan_sq_sum(image_out, target)
         num, den = s1, n1
+        self.last_levels = [(1, s1.detach(), n1)]                                      # (level, S_L, N_L): device scalars, no host sync
         for level in levels[1:]:
             image_out_ = self.model._warp(external_cond, flow_out, scale=level)       # DD:936
             with torch.no_grad():
@@ -599,6 +600,7 @@ class ConditionalDiffusion(nn.Module):
             s, n = nan_sq_sum(image_out_, image_out_tgt)
             num = num + s * float(level ** 4)                                          # DD:956
             den = den + n
+            self.last_levels.append((level, s.detach(), n))
         return num / den.float()
 
     def forward(self, img, external_cond=None, *args, **kwargs):
