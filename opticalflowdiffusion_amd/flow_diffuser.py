@@ -37,7 +37,7 @@ class _Cfg:
     _DEFAULTS = dict(name="flow_diffuser", image_size=128, latent_dim=16, flow_max=20, latent_max=2, lr=1e-5,
                      flow_weight=0.0, weight_decay=1e-6, is_diffusion=True, latent=False, timesteps=1000,
                      target="joint", ae="px8q8g0m", noiser="image", zero_init=True,
-                     sampling_timesteps=None, precision="bf16")
+                     sampling_timesteps=None, precision="bf16", augment=True)
 
     def __init__(self, cfg):
         self._d = dict(self._DEFAULTS)
@@ -154,8 +154,15 @@ class FlowDiffuser(_Base):
         return self.optimizers
 
     def preprocess(self, batch, aug=True):
-        """FD:136-168.  The reference's Augmentor is torchvision-on-CPU and assumes square inputs
-        (augmentation.py:45-49); it is outside this path, so aug=True is accepted and ignored."""
+        """FD:136-168.  `aug=True` (what training_step passes, FD:219) runs the batched GPU `Augmentor` (augmentation.py of this
+        package: same structure and probabilities as the reference's torchvision pipeline, non-square aware); the optional cfg key
+        `augment: false` switches it off."""
+        if aug and self.cfg.augment:
+            if getattr(self, "augmentor", None) is None:
+                from .augmentation import Augmentor
+                self.augmentor = Augmentor()
+            with torch.no_grad():
+                batch = self.augmentor(batch)
         img, tgt, flow = batch
         flow = torch.clamp(flow / self.flow_max, -1.0, 1.0)
         img = 2 * img - 1.0

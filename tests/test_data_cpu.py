@@ -90,3 +90,45 @@ def test_sintel_pairs_adapter(tmp_path):
     assert float(f2[0, 5, 5]) == pytest.approx(2.0) and float(f2[1, 5, 5]) == pytest.approx(-2.0)   # vectors rescaled by 24/12, 20/10
     with pytest.raises(FileNotFoundError):
         SintelPairs(str(tmp_path / "nothing"))
+
+
+def test_gpu_augmentor_keeps_the_flow_consistent():
+    """augmentation.Augmentor (the batched stand-in for the reference's torchvision pipeline, augmentation.py:6-76) on non-square
+    inputs: shapes, determinism under the global seed, the flip negates the flow component ALONG the flipped axis so that a
+    translated pair stays a translated pair, the crop rescales the vectors by its zoom per axis, grayscale / identity branches."""
+    import torch
+    from opticalflowdiffusion_amd.augmentation import Augmentor
+    B, H, W = 64, 24, 40
+    g = torch.Generator().manual_seed(0)
+    img, tgt = torch.rand(B, 3, H, W, generator=g), torch.rand(B, 3, H, W, generator=g)
+    flow = torch.zeros(B, 2, H, W)
+    flow[:, 0], flow[:, 1] = 3.0, -2.0                                  # constant flow: every geometric transform keeps it constant
+    torch.manual_seed(5)
+    a = Augmentor()
+    i1, t1, f1 = a((img, tgt, flow))
+    torch.manual_seed(5)
+    i2, t2, f2 = Augmentor()((img, tgt, flow))
+    assert i1.shape == img.shape and t1.shape == tgt.shape and f1.shape == flow.shape
+    assert torch.equal(i1, i2) and torch.equal(f1, f2)                  # reproducible from the global RNG state
+    assert float(i1.min()) >= 0.0 and float(i1.max()) <= 1.0 and bool(torch.isfinite(f1).all())
+    fx, fy = f1[:, 0, H // 2, W // 2], f1[:, 1, H // 2, W // 2]
+    # per sample the flow stays constant over the image, and is +-3 / +-2 times the crop zoom (1 .. 1 / 0.8 / 0.9)
+    assert float((f1[:, 0] - fx.view(B, 1, 1)).abs().max()) < 1e-4 and float((f1[:, 1] - fy.view(B, 1, 1)).abs().max()) < 1e-4
+    zx, zy = fx.abs() / 3.0, fy.abs() / 2.0
+    assert float(zx.min()) >= 1.0 - 1e-5 and float(zx.max()) < 1.45 and float(zy.min()) >= 1.0 - 1e-5 and float(zy.max()) < 1.45
+    nflip_x, nflip_y, ncrop = int((fx < 0).sum()), int((fy > 0).sum()), int(((zx > 1 + 1e-4) | (zy > 1 + 1e-4)).sum())
+    assert 8 <= nflip_x <= 32 and 8 <= nflip_y <= 32 and 2 <= ncrop <= 22      # p = 0.3, 0.3, 0.15 of 64
+    # a horizontally flipped translated pair is a translated pair with the x displacement negated (channel 0 = x, SS:368)
+    class OnlyFlipX(Augmentor):
+        def _rand(self, n, device):
+            self.k = getattr(self, "k", 0) + 1
+            return torch.zeros(n) if self.k == 8 else torch.ones(n)      # draws 1-7 are photometric (all off), 8 = h-flip (on), the rest off
+    base = torch.rand(1, 3, H, W + 8, generator=g)
+    im, tg = base[..., 4:W + 4], base[..., 1:W + 1]                      # tg(x) = im(x - 3): flow = (+3, 0)
+    fl = torch.zeros(1, 2, H, W)
+    fl[:, 0] = 3.0
+    i3, t3, f3 = OnlyFlipX()((im, tg, fl))
+    assert torch.equal(i3, im.flip(-1)) and float(f3[:, 0].mean()) == -3.0 and float(f3[:, 1].abs().max()) == 0.0
+    assert torch.allclose(t3[..., :-3], i3[..., 3:])                     # t3(x) = i3(x + 3), i.e. flow x = -3
+    r = OnlyFlipX(reference_flip_channels=True)((im, tg, fl))[2]
+    assert float(r[:, 0].mean()) == 3.0                                 # the reference's own channel choice leaves x untouched (augmentation.py:37-39)
