@@ -333,6 +333,13 @@ int ofd_time_mlp(const int64_t* t, const float* w1, const float* b1, const float
 int ofd_gn_finalize(const float* partial, int B, int H, int W, int C, const float* gamma, const float* beta,
                     const float* ss, int ss_stride, int ss_offset, float* a_out, float* s_out, float* stats_out, void* stream);
 
+/* Batched training augmentation in one pass (replaces the per-sample torchvision pipeline of augmentation.py:6-76 behind
+ * FlowDiffuser.preprocess(aug=True), flow_diffuser.py:137-138).  img / tgt (B,3,H,W), flow (B,2,H,W) fp32 NCHW; params (B,16) fp32:
+ * 0 jitter on, 1 brightness, 2 contrast, 3 saturation, 4 grayscale on, 5 blur on, 6 sigma, 7 h-flip, 8 v-flip, 9 crop on,
+ * 10 oy, 11 ox, 12 ch, 13 cw (crop window origin / size as fractions of the image; 1, 1 without a crop).  means_ws: B*2 doubles. */
+int ofd_augment(const float* img, const float* tgt, const float* flow, const float* params, void* means_ws, float* out_img,
+                float* out_tgt, float* out_flow, int B, int H, int W, int reference_flip_channels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

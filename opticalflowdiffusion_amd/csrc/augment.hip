@@ -1,0 +1,136 @@
+// Batched training augmentation in ONE pass (the reference's Augmentor, augmentation.py:6-76, runs torchvision transforms per
+// sample on the host): photometric jitter / grayscale / 3x3 Gaussian blur on the two frames, horizontal / vertical flip and a
+// random resized crop (bilinear, resized back to (H, W)) on frames and flow, the flow negated along flipped axes and rescaled by the
+// crop's zoom.  HBM-bound: every output element is written once; a sample that takes no transform is a copy.
+// The per-sample decisions are drawn on the host side of the boundary (augmentation.py of this package) and arrive as a table.
+#include "common.h"
+
+namespace ofd {
+
+// params[b][16]: 0 jitter on, 1 brightness, 2 contrast, 3 saturation, 4 grayscale on, 5 blur on, 6 sigma, 7 h-flip, 8 v-flip,
+//                9 crop on, 10 oy, 11 ox, 12 ch, 13 cw (window origin / size as fractions of the image)
+constexpr int AUG_NP = 16;
+
+__device__ __forceinline__ float aug_gray(float r, float g, float b) { return 0.299f * r + 0.587f * g + 0.114f * b; }
+
+// mean gray level of every (sample, frame): what the contrast factor pivots on
+__global__ void __launch_bounds__(256) aug_gray_mean_kernel(const float* __restrict__ img, const float* __restrict__ tgt, double* __restrict__ means, int plane) {
+    const int b = blockIdx.y >> 1, frame = blockIdx.y & 1;
+    const float* p = (frame ? tgt : img) + (size_t)b * 3 * plane;
+    double s = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < plane; i += gridDim.x * 256) s += (double)aug_gray(p[i], p[plane + i], p[2 * plane + i]);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ double ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(means + blockIdx.y, (ws[0] + ws[1] + ws[2] + ws[3]) / (double)plane);
+}
+
+__global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ img, const float* __restrict__ tgt, const float* __restrict__ flow,
+                                                      const float* __restrict__ params, const double* __restrict__ means,
+                                                      float* __restrict__ o_img, float* __restrict__ o_tgt, float* __restrict__ o_flow,
+                                                      int H, int W, int ref_flip) {
+    const int b = blockIdx.y, plane = H * W;
+    const float* P = params + (size_t)b * AUG_NP;
+    const bool jit = P[0] != 0.0f, gray = P[4] != 0.0f, blur = P[5] != 0.0f, hf = P[7] != 0.0f, vf = P[8] != 0.0f, crop = P[9] != 0.0f;
+    const float br = P[1], ct = P[2], st = P[3], sigma = P[6], oy = P[10], ox = P[11], ch = P[12], cw = P[13];
+    float k1[3] = {0.0f, 1.0f, 0.0f};
+    if (blur) {
+        const float e = __expf(-0.5f / (sigma * sigma));
+        const float n = 1.0f / (1.0f + 2.0f * e);
+        k1[0] = e * n; k1[1] = n; k1[2] = e * n;
+    }
+    const float mean_g[2] = {(float)means[b * 2] * br, (float)means[b * 2 + 1] * br};    // mean gray after the brightness factor
+    const float* src[2] = {img + (size_t)b * 3 * plane, tgt + (size_t)b * 3 * plane};
+    const float* fsrc = flow + (size_t)b * 2 * plane;
+
+    auto photo = [&](int frame, int y, int x, float (&rgb)[3]) {       // pointwise part, at integer coordinates of the ORIGINAL image
+        const float* p = src[frame] + y * W + x;
+        float r = p[0], g = p[plane], bl = p[2 * plane];
+        if (jit) {
+            r *= br; g *= br; bl *= br;
+            const float m = mean_g[frame];
+            r = (r - m) * ct + m; g = (g - m) * ct + m; bl = (bl - m) * ct + m;
+            const float gy = aug_gray(r, g, bl);
+            r = fminf(fmaxf((r - gy) * st + gy, 0.0f), 1.0f);
+            g = fminf(fmaxf((g - gy) * st + gy, 0.0f), 1.0f);
+            bl = fminf(fmaxf((bl - gy) * st + gy, 0.0f), 1.0f);
+        }
+        if (gray) r = g = bl = aug_gray(r, g, bl);
+        rgb[0] = r; rgb[1] = g; rgb[2] = bl;
+    };
+    auto refl = [](int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); };
+    auto blurred = [&](int frame, int y, int x, float (&rgb)[3]) {
+        if (!blur) { photo(frame, y, x, rgb); return; }
+        rgb[0] = rgb[1] = rgb[2] = 0.0f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                float t[3];
+                photo(frame, refl(y + dy, H), refl(x + dx, W), t);
+                const float w = k1[dy + 1] * k1[dx + 1];
+                rgb[0] += w * t[0]; rgb[1] += w * t[1]; rgb[2] += w * t[2];
+            }
+    };
+
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < plane; i += gridDim.x * 256) {
+        const int y = i / W, x = i - y * W;
+        // sampling position in the (flipped) image: the crop window resized to (H, W), pixel centres (grid_sample align_corners=False,
+        // border padding); identity without a crop
+        float fy = (float)y, fx = (float)x;
+        if (crop) {
+            fy = fminf(fmaxf(oy * (float)H + ch * ((float)y + 0.5f) - 0.5f, 0.0f), (float)(H - 1));
+            fx = fminf(fmaxf(ox * (float)W + cw * ((float)x + 0.5f) - 0.5f, 0.0f), (float)(W - 1));
+        }
+        const int y0 = (int)floorf(fy), x0 = (int)floorf(fx), y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float wy = fy - (float)y0, wx = fx - (float)x0;
+        const int ys[2] = {vf ? H - 1 - y0 : y0, vf ? H - 1 - y1 : y1}, xs[2] = {hf ? W - 1 - x0 : x0, hf ? W - 1 - x1 : x1};
+        const float wts[4] = {(1.0f - wy) * (1.0f - wx), (1.0f - wy) * wx, wy * (1.0f - wx), wy * wx};
+        float out_rgb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, out_f[2] = {0.f, 0.f};
+        const int ncorner = crop ? 4 : 1;
+        for (int k = 0; k < ncorner; ++k) {
+            const int yy = ys[k >> 1], xx = xs[k & 1];
+            const float w = crop ? wts[k] : 1.0f;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                float t[3];
+                blurred(f, yy, xx, t);
+                out_rgb[f][0] += w * t[0]; out_rgb[f][1] += w * t[1]; out_rgb[f][2] += w * t[2];
+            }
+            out_f[0] += w * fsrc[yy * W + xx];
+            out_f[1] += w * fsrc[plane + yy * W + xx];
+        }
+        // flips negate the flow component along the flipped axis (channel 0 = x); ref_flip: the reference's own (swapped) choice
+        const int cx = ref_flip ? 1 : 0, cy = ref_flip ? 0 : 1;
+        if (hf) out_f[cx] = -out_f[cx];
+        if (vf) out_f[cy] = -out_f[cy];
+        out_f[0] /= cw;
+        out_f[1] /= ch;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            o_img[((size_t)b * 3 + c) * plane + i] = out_rgb[0][c];
+            o_tgt[((size_t)b * 3 + c) * plane + i] = out_rgb[1][c];
+        }
+        o_flow[((size_t)b * 2) * plane + i] = out_f[0];
+        o_flow[((size_t)b * 2 + 1) * plane + i] = out_f[1];
+    }
+}
+
+}  // namespace ofd
+using namespace ofd;
+
+extern "C" int ofd_augment(const float* img, const float* tgt, const float* flow, const float* params, void* means_ws, float* out_img,
+                           float* out_tgt, float* out_flow, int B, int H, int W, int reference_flip_channels, void* stream) {
+    OFD_CHECK_ARG(img && tgt && flow && params && means_ws && out_img && out_tgt && out_flow, "augment: null pointer");
+    OFD_CHECK_ARG(B > 0 && H > 1 && W > 1 && (long)H * W < (1L << 30), "augment: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    OFD_HIP(hipMemsetAsync(means_ws, 0, (size_t)B * 2 * sizeof(double), s));
+    const int plane = H * W;
+    int gx = (plane + 255) / 256;
+    aug_gray_mean_kernel<<<dim3(gx < 64 ? gx : 64, B * 2), 256, 0, s>>>(img, tgt, (double*)means_ws, plane);
+    augment_kernel<<<dim3(gx < 512 ? gx : 512, B), 256, 0, s>>>(img, tgt, flow, params, (const double*)means_ws, out_img, out_tgt, out_flow, H, W,
+                                                                  reference_flip_channels);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}

@@ -321,7 +321,7 @@ def test_unet_training_step_gradients(L, B, H, W):
         worst.append((e, n))
     worst.sort(reverse=True)
     print("worst parameter-gradient errors:", [(f"{e:.3e}", n) for e, n in worst[:8]])
-    bad = [(e, n) for e, n in worst if e > 5e-2]
+    bad = [(e, n) for e, n in worst if e > 4.8e-2]          # 1.5x the worst measured (3.2e-2, r02)
     assert not bad, bad
     # global direction: cosine of the flattened gradients
     g1 = torch.cat([p.grad.flatten().cpu() for _, p in net.named_parameters()])
@@ -359,7 +359,7 @@ def test_regression_unet_time_in_false_forward_and_gradients(L):
     (ref * gy).sum().backward()
     worst = sorted(((rel_l2(p.grad.cpu(), P[n].grad), n) for n, p in net.named_parameters()), reverse=True)
     print("worst parameter-gradient errors:", [(f"{e:.3e}", n) for e, n in worst[:6]])
-    assert worst[0][0] < 5e-2, worst[:4]
+    assert worst[0][0] < 4.8e-2, worst[:4]
     with torch.no_grad():
         out_inf = net(x.cuda())
     assert rel_l2(out_inf.cpu(), ref.detach()) < 2e-2

@@ -120,9 +120,10 @@ def test_gpu_augmentor_keeps_the_flow_consistent():
     assert 8 <= nflip_x <= 32 and 8 <= nflip_y <= 32 and 2 <= ncrop <= 22      # p = 0.3, 0.3, 0.15 of 64
     # a horizontally flipped translated pair is a translated pair with the x displacement negated (channel 0 = x, SS:368)
     class OnlyFlipX(Augmentor):
-        def _rand(self, n, device):
-            self.k = getattr(self, "k", 0) + 1
-            return torch.zeros(n) if self.k == 8 else torch.ones(n)      # draws 1-7 are photometric (all off), 8 = h-flip (on), the rest off
+        def draw(self, B, device):
+            P = torch.zeros(B, self.NP, device=device)
+            P[:, 1:4], P[:, 6], P[:, 7], P[:, 12:14] = 1.0, 0.25, 1.0, 1.0     # h-flip only
+            return P
     base = torch.rand(1, 3, H, W + 8, generator=g)
     im, tg = base[..., 4:W + 4], base[..., 1:W + 1]                      # tg(x) = im(x - 3): flow = (+3, 0)
     fl = torch.zeros(1, 2, H, W)

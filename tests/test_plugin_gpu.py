@@ -410,3 +410,40 @@ def test_validation_step_diagnostics(target):
     assert all(bool(torch.isfinite(fd.logged[f"train/grad_norm/{b}"])) for b in ("min", "max", "std", "mean", "median"))
     assert all(f"train/gpr/{b}" in fd.logged for b in ("min", "max", "std", "mean", "median"))      # (a zero-norm parameter makes the ratio inf, as in the reference)
     assert bool(torch.isfinite(fd.logged["train/gpr/min"])) and bool(torch.isfinite(fd.logged["train/gpr/median"]))
+
+
+def test_fused_augmentation_kernel_against_its_tensor_op_restatement():
+    """`ofd_augment` (one pass over the batch) against `Augmentor.apply_torch` on the SAME table of per-sample decisions: random
+    draws on a non-square batch, then every transform forced on at once (jitter + grayscale + blur + both flips + crop), the
+    reference's swapped flip channels, and the wiring through FlowDiffuser.preprocess(aug=True)."""
+    from opticalflowdiffusion_amd import FlowDiffuser
+    from opticalflowdiffusion_amd.augmentation import Augmentor
+    torch.manual_seed(4)
+    B, H, W = 12, 40, 72
+    img, tgt = torch.rand(B, 3, H, W, device="cuda"), torch.rand(B, 3, H, W, device="cuda")
+    flow = torch.randn(B, 2, H, W, device="cuda") * 5
+    for ref_flip in (False, True):
+        a = Augmentor(reference_flip_channels=ref_flip)
+        for trial in range(3):
+            P = a.draw(B, img.device)
+            if trial == 2:                                  # everything at once, for every sample
+                P[:, 0] = P[:, 4] = P[:, 5] = P[:, 7] = P[:, 8] = P[:, 9] = 1.0
+                P[:, 4] = (torch.arange(B, device="cuda") % 2).float()
+                P[:, 12], P[:, 13], P[:, 10], P[:, 11] = 0.85, 0.93, 0.1, 0.05
+            got = a.apply_hip(img, tgt, flow, P)
+            want = a.apply_torch(img, tgt, flow, P)
+            for g_, w_, name in zip(got, want, ("img", "tgt", "flow")):
+                assert g_.shape == w_.shape and float((g_ - w_).abs().max()) < 2e-5 * max(1.0, float(w_.abs().max())), (name, trial, ref_flip)
+    ident = torch.zeros(B, Augmentor.NP, device="cuda")
+    ident[:, 1:4], ident[:, 6], ident[:, 12:14] = 1.0, 0.25, 1.0
+    got = Augmentor().apply_hip(img, tgt, flow, ident)
+    assert torch.equal(got[0], img) and torch.equal(got[1], tgt) and torch.equal(got[2], flow)      # no transform: a copy
+    fd = FlowDiffuser(dict(target="flow", image_size=[H, W], timesteps=10, flow_max=20)).cuda()
+    torch.manual_seed(9)
+    t1 = fd.preprocess((img, tgt, flow), aug=True)
+    torch.manual_seed(9)
+    t2 = fd.preprocess((img, tgt, flow), aug=True)
+    plain = fd.preprocess((img, tgt, flow), aug=False)
+    assert torch.equal(t1[1], t2[1]) and not torch.equal(t1[1], plain[1]) and t1[0].shape == plain[0].shape
+    fd_off = FlowDiffuser(dict(target="flow", image_size=[H, W], timesteps=10, flow_max=20, augment=False)).cuda()
+    assert torch.equal(fd_off.preprocess((img, tgt, flow), aug=True)[1], plain[1])

@@ -5,8 +5,9 @@ on bf16-stored tensors, per-site eps of the reference's bf16 path).
 Tolerance: north_star asks 1e-3 relative for bf16 UNet activations.  A stored bf16 value
 carries 2^-9 = 1.95e-3 relative rounding, so per-op results are compared AFTER both sides are
 rounded to bf16 with rel-L2 <= 1e-3 (differences come only from fp32 summation order flipping
-a rounding), and end-to-end (~100 chained roundings) the measured rel-L2 is asserted < 2e-2,
-the reference's own bf16-vs-fp32 noise floor (1.2e-2).
+a rounding), and end-to-end (~100 chained roundings) the measured rel-L2 (6e-3 ... 8e-3 at the output, <= 1.1e-2 at
+any tap) is asserted at ~1.5x that; the reference's own bf16-vs-fp32 floor on the same kind of input is 1.5e-2
+(test_hip_unet_against_the_reference_module_outputs).
 """
 import ctypes
 import math
@@ -244,9 +245,11 @@ def test_unet_forward_vs_engine_contract_oracle(L, ch, B, H, W):
     print("\n".join(f"  {n:18s} rel-L2 {e:.3e}" for n, e in report))
     print(f"  {'output':18s} rel-L2 {err:.3e}")
     assert report[0][1] < 2e-3, report[0]                 # first op: plain per-op tolerance
+    # ~1.5x the measured values (r02: taps <= 1.11e-2 at mid_block2, output 6.2e-3 ... 7.9e-3), so that a regression shows; the
+    # north_star's 1e-3 holds per op (PER_OP_TOL above), not across ~100 chained bf16 roundings
     for n, e in report:
-        assert e < 2e-2, (n, e)
-    assert err < 2e-2
+        assert e < 1.7e-2, (n, e)
+    assert err < 1.2e-2
     assert torch.isfinite(out).all()
 
 
