@@ -1074,6 +1074,7 @@ static int launch_conv(const ConvParams& P, hipStream_t s) {
 
 int launch_conv3x3_c64_rw(const ConvParams& P, hipStream_t s);     // conv_rw.hip
 int launch_conv3x3_wp(const ConvParams& P, bool wide, hipStream_t s);   // conv_wp.hip
+int launch_conv1x1_wp(const ConvParams& P, hipStream_t s);              // conv1_wp.hip: 1 = shape not served
 
 int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     OFD_CHECK_ARG(a && a->out && a->weight, "conv: null out/weight");
@@ -1161,6 +1162,13 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     if (use_ws < 0) { const char* e = getenv("OFD_CONV_WS"); use_ws = (e && atoi(e)) ? 1 : 0; }
     if (a->ksize == 3 && use_ws && !a->split) return wide ? launch_conv_ws<128>(P, s) : launch_conv_ws<64>(P, s);
     if (a->ksize == 3) return wide ? launch_conv<3, 128>(P, s) : launch_conv<3, 64>(P, s);
+    // streaming 1x1 kernel (conv1_wp.hip) where it serves the shape: OFD_CONV1_WP=0 switches it off
+    static int use_c1 = -1;
+    if (use_c1 < 0) { const char* e = getenv("OFD_CONV1_WP"); use_c1 = e ? atoi(e) : 1; }
+    if (a->ksize == 1 && use_c1 && !P.dbg) {
+        const int r = launch_conv1x1_wp(P, s);
+        if (r != 1) return r;
+    }
     if (a->ksize == 1) return wide ? launch_conv<1, 128>(P, s) : launch_conv<1, 64>(P, s);
     if (a->ksize == 2) return wide ? launch_conv<2, 128>(P, s) : launch_conv<2, 64>(P, s);
     return launch_conv<7, 64>(P, s);

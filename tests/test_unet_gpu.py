@@ -147,9 +147,13 @@ def test_conv3x3_concat_prologue_upsample_epilogues(L):
     check_close(from_nhwc(out), ref2, what="residual")
 
 
-def test_conv1x1_variants(L):
+@pytest.mark.parametrize("B,H,W,grid", [(2, 10, 48, 0), (2, 12, 64, 0), (3, 6, 128, 5), (2, 16, 192, 3)])
+def test_conv1x1_variants(L, B, H, W, grid, monkeypatch):
+    """(10, 48): the shared-slab kernel; the others have H*W % 128 == 0 and W % 64 == 0 and take the streaming kernel of
+    conv1_wp.hip where it serves the shape -- with `grid` workgroups, so that each walks several tiles and crosses samples."""
+    if grid:
+        monkeypatch.setenv("OFD_CONV1_GRID", str(grid))
     torch.manual_seed(2)
-    B, H, W = 2, 10, 48
     x = q(torch.randn(B, 64, H, W))
     w = torch.randn(384, 64, 1, 1) / 8
     ref = F.conv2d(x, q(w))
@@ -165,15 +169,40 @@ def test_conv1x1_variants(L):
     out, _ = run_conv(L, B, H, W, 1, [dict(t=to_nhwc(x1)), dict(t=to_nhwc(x2))], 128, prep_weight(L, w, 1), bias=b,
                       res_act=to_nhwc(h), res_scale=a, res_shift=s)
     check_close(from_nhwc(out), ref, what="res_conv + silu(affine)")
+    # the full-resolution res_conv: cat(64, 64) -> 64 (ups.3), and 128 -> 64 from one tensor's channel window
+    w = torch.randn(64, 128, 1, 1) / math.sqrt(128)
+    ref = F.conv2d(torch.cat((x2, x), 1), q(w), b[:64]) + F.silu(h[:, :64] * a[:, :64, None, None] + s[:, :64, None, None])
+    out, _ = run_conv(L, B, H, W, 1, [dict(t=to_nhwc(x2)), dict(t=to_nhwc(x))], 64, prep_weight(L, w, 1), bias=b[:64],
+                      res_act=to_nhwc(h[:, :64].contiguous()), res_scale=a[:, :64], res_shift=s[:, :64])
+    check_close(from_nhwc(out), ref, what="res_conv 128 -> 64 + silu(affine)")
+    ref = F.conv2d(x1, q(w), b[:64])
+    out, _ = run_conv(L, B, H, W, 1, [dict(t=to_nhwc(x1))], 64, prep_weight(L, w, 1), bias=b[:64])
+    check_close(from_nhwc(out), ref, what="128 -> 64 plain")
+    # attention output projection 128 -> 256 (DD:225)
+    w = torch.randn(256, 128, 1, 1) / math.sqrt(128)
+    b2 = torch.randn(256) * 0.1
+    ref = F.conv2d(x1, q(w), b2)
+    out, _ = run_conv(L, B, H, W, 1, [dict(t=to_nhwc(x1))], 256, prep_weight(L, w, 1), bias=b2)
+    check_close(from_nhwc(out), ref, what="to_out 128 -> 256")
+    # res_conv of ups.1: cat(256, 128) -> 256 with the fused epilogue
+    x3 = q(torch.randn(B, 256, H, W))
+    w = torch.randn(256, 384, 1, 1) / math.sqrt(384)
+    h3 = q(torch.randn(B, 256, H, W))
+    a3, s3 = torch.rand(B, 256) + 0.5, torch.randn(B, 256) * 0.3
+    ref = F.conv2d(torch.cat((x3, x1), 1), q(w), b2) + F.silu(h3 * a3[:, :, None, None] + s3[:, :, None, None])
+    out, _ = run_conv(L, B, H, W, 1, [dict(t=to_nhwc(x3)), dict(t=to_nhwc(x1))], 256, prep_weight(L, w, 1), bias=b2,
+                      res_act=to_nhwc(h3), res_scale=a3, res_shift=s3)
+    check_close(from_nhwc(out), ref, what="res_conv 384 -> 256 + silu(affine)")
     # Downsample = pixel-unshuffle + 1x1 (DD:95-99)
     xs = q(torch.randn(B, 64, 2 * H, 2 * W))
-    w = torch.randn(128, 256, 1, 1) / 16
-    P = {"m.1.weight": w, "m.1.bias": b}
-    ref = R.downsample(P, "m", xs, R.q_bf16)
-    t = to_nhwc(xs)
-    srcs = [dict(t=t, unshuffle=1, p1=sub >> 1, p2=sub & 1) for sub in range(4)]
-    out, _ = run_conv(L, B, H, W, 1, srcs, 128, prep_weight(L, w, 1, unshuffle=1), bias=b)
-    check_close(from_nhwc(out), ref, what="downsample")
+    for co in (128, 64):
+        w = torch.randn(co, 256, 1, 1) / 16
+        P = {"m.1.weight": w, "m.1.bias": b[:co]}
+        ref = R.downsample(P, "m", xs, R.q_bf16)
+        t = to_nhwc(xs)
+        srcs = [dict(t=t, unshuffle=1, p1=sub >> 1, p2=sub & 1) for sub in range(4)]
+        out, _ = run_conv(L, B, H, W, 1, srcs, co, prep_weight(L, w, 1, unshuffle=1), bias=b[:co])
+        check_close(from_nhwc(out), ref, what=f"downsample -> {co}")
 
 
 @pytest.mark.parametrize("Cin", [5, 9])
