@@ -22,7 +22,7 @@ int k_wgrad_finish(const float* acc, const float* w_raw, float* dst, int Cout, i
 int k_grad_scatter(const bf16_t* D, int Ctot, int ch_off, bf16_t* dst, int C, int B, int H, int W, int mode, int p1, int p2, int accumulate,
                    hipStream_t s);
 
-int k_pack_input(const float* x, int Cx, const float* cond, int Cc, bf16_t* out, int B, int H, int W, hipStream_t s);
+int k_pack_input(const float* x, int Cx, const float* cond, int Cc, bf16_t* out, int B, int H, int W, hipStream_t s, int cpad = 16);
 int k_time_mlp(const int64_t* t, const float* w1, const float* b1, const float* w2, const float* b2, float* temb,
                float* temb_silu, int B, int dim, hipStream_t s);
 int k_block_mlp(const float* temb_silu, const MlpDesc* descs, int n_desc, float* ss, int B, int tdim, int ss_stride, hipStream_t s);

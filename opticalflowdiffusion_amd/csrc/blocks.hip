@@ -23,23 +23,25 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
 }
 
-// ---- DD:368: cat(x, cond) -> NHWC bf16 padded to 16 channels (input of the 7x7 init_conv) --------
+// ---- DD:368: cat(x, cond) -> NHWC bf16 padded to CP = 8 or 16 channels (input of the 7x7 init_conv) --------
+template <int CP>
 __global__ void __launch_bounds__(256) pack_input_kernel(const float* __restrict__ x, int Cx, const float* __restrict__ cond, int Cc,
                                                          bf16_t* __restrict__ out, int B, size_t plane) {
     const size_t total = (size_t)B * plane;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t n = i / plane, pix = i % plane;
-        float v[16];
+        float v[CP];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        for (int c = 0; c < CP; ++c) {
             float t = 0.0f;
             if (c < Cx) t = x[(n * Cx + c) * plane + pix];
             else if (c < Cx + Cc) t = cond[(n * Cc + (c - Cx)) * plane + pix];
             v[c] = t;
         }
-        uint4* o = (uint4*)(out + i * 16);
-        o[0] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-        o[1] = make_uint4(pack2(v[8], v[9]), pack2(v[10], v[11]), pack2(v[12], v[13]), pack2(v[14], v[15]));
+        uint4* o = (uint4*)(out + i * CP);
+#pragma unroll
+        for (int k = 0; k < CP / 8; ++k)
+            o[k] = make_uint4(pack2(v[8 * k], v[8 * k + 1]), pack2(v[8 * k + 2], v[8 * k + 3]), pack2(v[8 * k + 4], v[8 * k + 5]), pack2(v[8 * k + 6], v[8 * k + 7]));
     }
 }
 
@@ -385,9 +387,10 @@ static inline int sgrid(size_t total, int block = 256, int cap = 4096) {
 }
 
 // ------------------------------------------------------------------------------------ launchers
-int k_pack_input(const float* x, int Cx, const float* cond, int Cc, bf16_t* out, int B, int H, int W, hipStream_t s) {
-    OFD_CHECK_ARG(Cx + Cc <= 16 && Cx > 0, "pack_input: %d+%d channels (max 16)", Cx, Cc);
-    pack_input_kernel<<<sgrid((size_t)B * H * W), 256, 0, s>>>(x, Cx, cond, Cc, out, B, (size_t)H * W);
+int k_pack_input(const float* x, int Cx, const float* cond, int Cc, bf16_t* out, int B, int H, int W, hipStream_t s, int cpad) {
+    OFD_CHECK_ARG((cpad == 8 || cpad == 16) && Cx + Cc <= cpad && Cx > 0, "pack_input: %d+%d channels into %d", Cx, Cc, cpad);
+    if (cpad == 8) pack_input_kernel<8><<<sgrid((size_t)B * H * W), 256, 0, s>>>(x, Cx, cond, Cc, out, B, (size_t)H * W);
+    else pack_input_kernel<16><<<sgrid((size_t)B * H * W), 256, 0, s>>>(x, Cx, cond, Cc, out, B, (size_t)H * W);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

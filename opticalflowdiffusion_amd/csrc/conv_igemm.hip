@@ -30,11 +30,16 @@ constexpr int TH = 8, TW = 32, NTHREADS = 256;
 
 template <int KS, int BN>
 struct Cfg {
-    static constexpr int CK = (KS == 7) ? 16 : 64;          // channels per K-chunk
+    // KS == 8 is not a kernel size: it is the 7x7 conv over an input padded to 8 channels (16 bytes per pixel), where the two
+    // channel octets of one MFMA k-step are two horizontally ADJACENT PIXELS, i.e. the taps (ky, 2j) and (ky, 2j+1): 4 k-steps per
+    // kernel row instead of 7 (the 8th tap column carries zero weights).  Every other KS == 7 property applies.
+    static constexpr bool K7P = (KS == 8);
+    static constexpr int KSZ = K7P ? 7 : KS;                // the kernel size proper
+    static constexpr int CK = K7P ? 8 : ((KS == 7) ? 16 : 64);          // channels per K-chunk
     static constexpr int NC = CK / 8;                       // 16-byte units per pixel
-    static constexpr int PAD = KS / 2;
-    static constexpr int IH = TH + KS - 1, IW = TW + KS - 1, NPIX = IH * IW;
-    static constexpr int STAGES = (KS == 3) ? 9 : (KS == 7 ? 7 : (KS == 2 ? 4 : 1));   // weight slabs per chunk
+    static constexpr int PAD = KSZ / 2;
+    static constexpr int IH = TH + KSZ - 1, IW = TW + KSZ - 1 + (K7P ? 1 : 0), NPIX = IH * IW;
+    static constexpr int STAGES = (KS == 3) ? 9 : (KSZ == 7 ? 7 : (KS == 2 ? 4 : 1));   // weight slabs per chunk
     static constexpr int KSTEPS = (KS == 7) ? 7 : 4;                    // MFMA k-steps per slab
     static constexpr int SC8 = KSTEPS * 2;                              // 8-channel rows per slab
     // X tile in LDS is unit-major: [NC channel-octets][NPIX+1 slots][16 B] (see PP_US below)
@@ -109,6 +114,7 @@ __device__ __forceinline__ void conv_load_w(U4Arr<Cfg<KS, BN>::WPT>& wr, const b
         const int r = u / BN, n = u % BN;
         size_t row;
         if (KS == 7) row = (size_t)(st * 7 + r / 2) * 2 + (r & 1);
+        else if (KS == 8) row = (size_t)st * 8 + r;
         else row = (size_t)st * cin8 + kc * 8 + r;
         wr.v[i] = *(const u32x4*)(weight + (row * Cout + n0 + n) * 8);   // (diagnostic bit 2 handled by the caller)
     }
@@ -147,7 +153,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
     const int oy0 = (t_in / P.tiles_x) * TH, ox0 = (t_in % P.tiles_x) * TW;
     const int n0 = blockIdx.y * BN;
 
-    const unsigned char* xrow = lds_x + half * C::US + (wave * 2 * C::IW + l31) * 16;
+    const unsigned char* xrow = lds_x + half * (C::K7P ? 16 : C::US) + (wave * 2 * C::IW + l31) * 16;
 
     f32x16 acc[C::NTN][2];
 #pragma unroll
@@ -266,12 +272,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             if (!DEEP && g + 1 < total_slabs) conv_load_w<KS, BN>(w1, P.weight, cin8, P.Cout, n0, kc, st + 1, tid);
             __syncthreads();   // lds_x (st == 0) and the W buffer of slab g are complete
             const unsigned char* wbuf = lds_w + (g & 1) * C::W_BYTES;
-            const int ky = (KS == 3) ? st / 3 : (KS == 7 ? st : (KS == 2 ? st / 2 : 0));
+            const int ky = (KS == 3) ? st / 3 : (C::KSZ == 7 ? st : (KS == 2 ? st / 2 : 0));
             const int kx3 = (KS == 3) ? st % 3 : (KS == 2 ? st % 2 : 0);
 #pragma unroll
             for (int ks = 0; ks < C::KSTEPS; ++ks) {
-                const int kx = (KS == 7) ? ks : kx3;
-                const int unit = (KS == 7) ? half : (ks * 2 + half);
+                const int kx = (KS == 7) ? ks : (C::K7P ? 2 * ks : kx3);
+                const int unit = (C::KSZ == 7) ? half : (ks * 2 + half);
                 bf16x8 xf[2], wf[C::NTN];
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt)   // base + (tap, k-step) offset: no per-read address math
@@ -1033,8 +1039,12 @@ __global__ void __launch_bounds__(256) conv_weight_prep_kernel(const float* __re
             }
             v = (wo[(size_t)ci * taps + tap] - mean) * rstd;
         }
-        out[(((size_t)tap * c8n + cp / 8) * Cout + o) * 8 + (cp % 8)] = f2bf(v);
+        // 7x7 over 8 channels: rows [ky][8 tap columns] (Cfg::K7P), the 8th column zero
+        const size_t row = (ksize == 7 && Cin_pad == 8) ? (size_t)(tap / 7) * 8 + tap % 7 : (size_t)tap * c8n + cp / 8;
+        out[(row * Cout + o) * 8 + (cp % 8)] = f2bf(v);
     }
+    if (ksize == 7 && Cin_pad == 8)
+        for (int i = tid; i < 7 * 8; i += 256) out[(((size_t)(i / 8) * 8 + 7) * Cout + o) * 8 + (i % 8)] = 0;
 }
 
 // nearest-x2 up-sample followed by a 3x3 conv (DD:89-93) = four 2x2 convs on the LOW-RES input, one per output phase
@@ -1088,7 +1098,8 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     OFD_CHECK_ARG(!a->res_act || (a->res_scale && a->res_shift), "conv: res_act needs res_scale/res_shift");
     OFD_CHECK_ARG(a->split == 0 || (a->split > 0 && a->split < a->Cout && a->split % 64 == 0 && a->out2 && a->ksize != 2 && !a->gn_partial && !a->res_act),
                   "conv: split=%d needs out2, a multiple of 64 below Cout, no GroupNorm statistics", a->split);
-    const int ck = a->ksize == 7 ? 16 : 64;
+    const bool k7p = a->ksize == 7 && a->n_src == 1 && a->src[0].channels == 8;      // 8-channel input: tap-pair packing (Cfg::K7P)
+    const int ck = a->ksize == 7 ? (k7p ? 8 : 16) : 64;
     ConvParams P{};
     P.B = a->B; P.H = a->H; P.W = a->W; P.Cout = a->Cout; P.n_src = a->n_src;
     P.tiles_x = cdiv(a->W, TW); P.tiles_y = cdiv(a->H, TH);
@@ -1111,7 +1122,8 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
         P.total_chunks += d.chunks;
     }
     P.Cin_total = cin;
-    OFD_CHECK_ARG(a->ksize != 7 || (P.total_chunks == 1 && a->Cout == 64 && !a->in_scale), "conv: 7x7 supports one 16-channel source, Cout=64");
+    OFD_CHECK_ARG(a->ksize != 7 || (P.total_chunks == 1 && a->Cout == 64 && !a->in_scale && !a->src[0].upsample && !a->src[0].unshuffle),
+                  "conv: 7x7 supports one 8- or 16-channel source, Cout=64");
     P.weight = (const bf16_t*)a->weight; P.bias = a->bias; P.in_scale = a->in_scale; P.in_shift = a->in_shift;
     P.residual = (const bf16_t*)a->residual; P.res_act = (const bf16_t*)a->res_act; P.res_scale = a->res_scale; P.res_shift = a->res_shift;
     P.out = (bf16_t*)a->out; P.gn_partial = a->gn_partial;
@@ -1171,7 +1183,7 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     }
     if (a->ksize == 1) return wide ? launch_conv<1, 128>(P, s) : launch_conv<1, 64>(P, s);
     if (a->ksize == 2) return wide ? launch_conv<2, 128>(P, s) : launch_conv<2, 64>(P, s);
-    return launch_conv<7, 64>(P, s);
+    return k7p ? launch_conv<8, 64>(P, s) : launch_conv<7, 64>(P, s);
 }
 
 }  // namespace ofd
@@ -1183,7 +1195,10 @@ extern "C" size_t ofd_conv_gn_partial_count(int B, int H, int W, int Cout) {
     return (size_t)B * cdiv(H, TH) * cdiv(W, TW) * 4 * (Cout / 8) * 2;     // [b][tile][wave][Cout/8][2]
 }
 
-extern "C" size_t ofd_conv_weight_elems(int Cout, int Cin_pad, int ksize) { return (size_t)ksize * ksize * Cin_pad * Cout; }
+extern "C" size_t ofd_conv_weight_elems(int Cout, int Cin_pad, int ksize) {
+    if (ksize == 7 && Cin_pad == 8) return (size_t)7 * 8 * 8 * Cout;      // tap-pair packing: 8 tap columns per kernel row (the 8th zero)
+    return (size_t)ksize * ksize * Cin_pad * Cout;
+}
 
 extern "C" int ofd_conv_weight_prep(const float* w_oihw, void* w_out, int Cout, int Cin, int Cin_pad, int ksize, float ws_eps,
                                     int unshuffle, void* stream) {

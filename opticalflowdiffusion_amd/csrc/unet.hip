@@ -36,6 +36,10 @@ static void add_conv(ofd_unet* u, const std::string& prefix, int co, int ci, int
     if (bias) add_param(u, prefix + ".bias", {co});
     ConvDesc c{prefix + ".weight", co, ci, (k == 7) ? 16 : ci, k, ws_eps, unshuffle, u->n_wbuf};
     u->n_wbuf += (size_t)k * k * c.Cin_pad * co;
+    if (k == 7 && ci <= 8) {
+        c.pack8_off = (long)u->n_wbuf;
+        u->n_wbuf += ofd_conv_weight_elems(co, 8, 7);
+    }
     u->cindex[prefix] = (int)u->convs.size();
     u->convs.push_back(c);
 }
@@ -134,8 +138,9 @@ void conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& srcs, T
         a.src[i].p2 = srcs[i].p2;
         cin += srcs[i].t.C;
     }
-    if (cin != d.Cin_pad) { set_error("conv %s: got %d input channels, expected %d", prefix.c_str(), cin, d.Cin_pad); c.rc = OFD_ERR_ARG; return; }
-    a.weight = c.u->d_wbuf + d.w_off;
+    const bool pack8 = d.ksize == 7 && cin == 8 && d.pack8_off >= 0;
+    if (cin != d.Cin_pad && !pack8) { set_error("conv %s: got %d input channels, expected %d", prefix.c_str(), cin, d.Cin_pad); c.rc = OFD_ERR_ARG; return; }
+    a.weight = c.u->d_wbuf + (pack8 ? (size_t)d.pack8_off : d.w_off);
     a.bias = c.u->P(prefix + ".bias");
     a.in_scale = in_scale; a.in_shift = in_shift; a.residual = residual; a.res_act = res_act;
     a.res_scale = res_scale; a.res_shift = res_shift; a.out = out.p; a.gn_partial = gn_partial;
@@ -318,9 +323,13 @@ int run_forward(Ctx& c, const float* x, int Cx, const float* cond, int Cc, const
     u->taps.clear();
     u->last_B = B;
     if (c.train) u->tape.clear();
-    Tensor xin = c.keep(16, H, W);
+    // inference with <= 8 input channels: 8-channel packing, the 7x7 pairs horizontally adjacent taps into one k-step (conv_igemm.hip
+    // Cfg::K7P).  Training keeps the 16-channel tensor its weight-gradient kernel reads (conv_bwd.hip conv7_wgrad_kernel).
+    static const bool no_pack8 = getenv("OFD_NO_CONV7_PACK8") && atoi(getenv("OFD_NO_CONV7_PACK8"));
+    const int cpad = (!c.train && !no_pack8 && u->convs[u->cindex.at("init_conv")].pack8_off >= 0) ? 8 : 16;
+    Tensor xin = c.keep(cpad, H, W);
     c.begin(PC_MISC, 0, 0);
-    RUN(k_pack_input(x, Cx, cond, cond ? Cc : 0, xin.p, B, H, W, c.s));
+    RUN(k_pack_input(x, Cx, cond, cond ? Cc : 0, xin.p, B, H, W, c.s, cpad));
     if (!u->cfg.no_time) {
         RUN(k_time_mlp(t, u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"), u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), temb, temb_silu, B, dim, c.s));
         RUN(k_block_mlp(temb_silu, u->d_mlp, (int)u->resblocks.size(), c.ss, B, dim * 4, u->ss_stride, c.s));
@@ -553,6 +562,10 @@ extern "C" int ofd_unet_prepare(ofd_unet* u, void* stream) {
         if (rc != OFD_OK) return rc;
         if (c.phase_off >= 0) {
             rc = ofd_conv_upsample_phase_weight_prep(u->P(c.wname), u->d_wbuf + c.phase_off, c.Cout, c.Cin, stream);
+            if (rc != OFD_OK) return rc;
+        }
+        if (c.pack8_off >= 0) {
+            rc = ofd_conv_weight_prep(u->P(c.wname), u->d_wbuf + c.pack8_off, c.Cout, c.Cin, 8, 7, c.ws_eps, 0, stream);
             if (rc != OFD_OK) return rc;
         }
     }

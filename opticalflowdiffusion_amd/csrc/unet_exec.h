@@ -26,6 +26,7 @@ struct ConvDesc {
     int unshuffle;
     size_t w_off;        // bf16 elements into d_wbuf
     long phase_off = -1; // up-sample convs: 4 collapsed 2x2 kernels (bf16 elements into d_wbuf), else -1
+    long pack8_off = -1; // 7x7 with <= 8 input channels: the tap-pair-packed weights for an 8-channel input (inference), else -1
 };
 
 struct Tensor {

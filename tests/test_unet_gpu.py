@@ -217,6 +217,11 @@ def test_conv7x7_init(L, Cin):
     xp[:, :Cin] = x
     out, _ = run_conv(L, B, H, W, 7, [dict(t=to_nhwc(xp))], 64, prep_weight(L, w, 7, cin_pad=16), bias=b)
     check_close(from_nhwc(out), ref, what="7x7")
+    if Cin <= 8:     # 8-channel input: two horizontally adjacent taps per MFMA k-step (what inference runs for the 5-channel UNet)
+        out8, _ = run_conv(L, B, H, W, 7, [dict(t=to_nhwc(xp[:, :8].contiguous()))], 64, prep_weight(L, w, 7, cin_pad=8), bias=b)
+        check_close(from_nhwc(out8), ref, what="7x7, tap pairs")
+        # same products in another fp32 summation order: at most one bf16 ulp apart from the 16-channel kernel
+        assert float((out8.float() - out.float()).abs().max()) <= 2.0 ** -7 * float(out.float().abs().max())
 
 
 # ------------------------------------------------------------------------------- whole forward
