@@ -69,33 +69,41 @@ struct Params {
     int B, H, W, Cout, ntiles;
 };
 
-// NSG: 32-channel slices per workgroup (output block = 32 NSG channels), CIN, TILE pixels per step, RA: fused SiLU(affine(h2)) input
-template <int NSG, int CIN, int TILE, bool RA>
+// NSG: 32-channel slices per workgroup (output block = 32 NSG channels), CIN, TILE pixels per step, RA: fused SiLU(affine(h2)) input,
+// NCB: output blocks a workgroup computes from one staged tile (to_qkv: 3 x 128 channels -- the input is read once, not per block)
+template <int NSG, int CIN, int TILE, bool RA, int NCB = 1>
 __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P) {
     constexpr int KS = CIN / 16, UNITS = CIN / 64, UNITB = TILE * 128, BUFB = UNITS * UNITB;
     constexpr int PG = 4 / NSG, F = (TILE / 32) / PG;                 // pixel groups of waves, 32-pixel fragments per wave
     constexpr int NPW = BUFB / 1024 / 4;                               // 1-KiB DMA pieces per wave and tile
-    constexpr int NRA = RA ? F * 2 : 0, NST = F * 2;                   // per wave and tile: h2 loads, output stores (16 B per lane each)
+    constexpr int NRA = RA ? F * 2 : 0, NST = F * 2 * NCB;             // per wave and tile: h2 loads, output stores (16 B per lane each)
     static_assert(TILE % 32 == 0 && (TILE / 32) % PG == 0 && BUFB % 4096 == 0, "tile shape");
+    static_assert(!(RA && NCB > 1) && NRA + NST <= 63, "the fused epilogue input is for single-block launches; vmcnt is 6 bits");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int ns = wave % NSG, pg = wave / NSG;
-    const int n0 = blockIdx.y * 32 * NSG, cb = n0 + 32 * ns;
+    const int n0 = blockIdx.y * 32 * NSG * NCB, cb = n0 + 32 * ns;    // (block k of this workgroup: cb + 32 NSG k)
 
     // ---- weights: this wave's A fragments, for good
-    bf16x8 wf[KS];
+    bf16x8 wf[NCB][KS];
+    float4 bias4[4];                                                  // (multi-block launches are bias-free: to_qkv, DD:222 -- host check)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[ks] = *(const bf16x8*)(P.weight + ((size_t)(ks * 2 + half) * P.Cout + cb + l31) * 8);
-    float4 bias4[4];
+    for (int k = 0; k < NCB; ++k)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bias4[g] = P.bias ? *(const float4*)(P.bias + cb + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
-
+        for (int ks = 0; ks < KS; ++ks) wf[k][ks] = *(const bf16x8*)(P.weight + ((size_t)(ks * 2 + half) * P.Cout + cb + 32 * NSG * k + l31) * 8);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        bias4[g] = (NCB == 1 && P.bias) ? *(const float4*)(P.bias + cb + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
     // a visible use right here: the compiler's wait for these loads lands before the loop, not (as vmcnt(0)) inside it
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[ks]));
+    for (int k = 0; k < NCB; ++k)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bias4[g].x), "+v"(bias4[g].y), "+v"(bias4[g].z), "+v"(bias4[g].w));
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[k][ks]));
+    if constexpr (NCB == 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bias4[g].x), "+v"(bias4[g].y), "+v"(bias4[g].z), "+v"(bias4[g].w));
+    }
     const int plane = P.H * P.W, tps = plane / TILE;                   // tiles per sample
     // DMA lane constants: piece = 8 pixel rows x 128 B of one unit; lane -> row lane >> 3, 16-byte chunk (lane & 7) ^ (lane >> 3)
     const int d_row = lane >> 3, d_chunk = ((lane & 7) ^ (lane >> 3)) * 8;          // (elements)
@@ -162,6 +170,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P)
         __builtin_amdgcn_s_barrier();                       // every wave's pieces of tile t are in LDS; buffer buf ^ 1 is free
         issue_dma(tq, buf ^ 1);
 
+        const unsigned xaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)(xlane + buf * BUFB);
+        unsigned xa[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xa[q] = xaddr + cx[q];
+        const int b = t / tps;
+        const size_t gp0 = (size_t)t * TILE;
+        static_for<0, NCB>([&](auto cbc) {
+        constexpr int cbk = decltype(cbc)::value;
         f32x16 acc[F];
 #pragma unroll
         for (int f = 0; f < F; ++f)
@@ -170,10 +186,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P)
         // fragment reads by hand as well: an LDS load the compiler can see makes it wait for ALL LDS-DMA in flight (vmcnt(0))
         // before the first use, i.e. for tile t + 1.  Two register sets, the reads of k-step ks + 1 fly under the MFMAs of ks.
         u4 xs_[2][F];
-        const unsigned xaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)(xlane + buf * BUFB);
-        unsigned xa[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xa[q] = xaddr + cx[q];
         auto rd = [&](auto ksc) {
             constexpr int ks = decltype(ksc)::value;
             static_for<0, F>([&](auto fc) {
@@ -190,12 +202,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P)
             lds_wait<F, pend>(x);
 #pragma unroll
             for (int f = 0; f < F; ++f)
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], __builtin_bit_cast(bf16x8, x[f]), acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cbk][ks], __builtin_bit_cast(bf16x8, x[f]), acc[f], 0, 0, 0);
         });
 
         // ---- epilogue: bias, + SiLU(affine(h2)), bf16, 16-byte stores (one v_permlane32_swap per dword pairs two register quads)
-        const int b = t / tps;
-        const size_t gp0 = (size_t)t * TILE;
         if constexpr (RA) {
             if (b != b_cur) {                                // (ordinary loads: the compiler's wait drains the queue -- once per sample)
                 b_cur = b;
@@ -247,9 +257,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P)
             for (int g = 0; g < 4; g += 2) {
                 const auto rx = __builtin_amdgcn_permlane32_swap(qout[f][g].x, qout[f][g + 1].x, false, false);
                 const auto ry = __builtin_amdgcn_permlane32_swap(qout[f][g].y, qout[f][g + 1].y, false, false);
-                *(uint4*)(P.out + pix * P.Cout + cb + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                *(uint4*)(P.out + pix * P.Cout + cb + 32 * NSG * cbk + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
             }
         }
+        });
         if (tn >= t_end) break;
         t = tn;
         buf ^= 1;
@@ -258,19 +269,19 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NSG, int CIN, int TILE, bool RA>
+template <int NSG, int CIN, int TILE, bool RA, int NCB = 1>
 static int launch(const Params& P, hipStream_t s) {
     constexpr int LDS = 2 * (CIN / 64) * TILE * 128;
     static bool attr = false;
     if (!attr) {
-        OFD_HIP(hipFuncSetAttribute((const void*)conv1x1_wp_kernel<NSG, CIN, TILE, RA>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        OFD_HIP(hipFuncSetAttribute((const void*)conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
     const int per_cu = (LDS * 2 <= 160 * 1024) ? 2 : 1;
     int gx = 256 * per_cu;
     if (const char* e = getenv("OFD_CONV1_GRID")) gx = atoi(e) > 0 ? atoi(e) : gx;       // diagnostics / tests: long tile ranges on small inputs
     if (gx > P.ntiles) gx = P.ntiles;
-    conv1x1_wp_kernel<NSG, CIN, TILE, RA><<<dim3(gx, P.Cout / (32 * NSG)), NTHREADS, LDS, s>>>(P);
+    conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB><<<dim3(gx, P.Cout / (32 * NSG * NCB)), NTHREADS, LDS, s>>>(P);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -284,8 +295,8 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
     if (C.res_act && !(C.res_scale && C.res_shift)) return 1;
     const int cin = C.Cin_total, plane = C.H * C.W;
     const bool ra = C.res_act != nullptr;
-    if (cin % 64 != 0 || cin > 384 || cin == 320 || cin < 128 || (C.Cout != 64 && C.Cout % 128 != 0)) return 1;
-    const int tile = (cin == 128) ? 128 : (cin == 384 ? 32 : 64);
+    if (cin % 64 != 0 || cin > 384 || cin == 320 || (cin < 128 && !(cin == 64 && C.Cout == 384 && !ra && !C.bias)) || (C.Cout != 64 && C.Cout % 128 != 0)) return 1;
+    const int tile = (cin <= 128) ? 128 : (cin == 384 ? 32 : 64);
     if (plane % tile != 0 || (size_t)C.B * plane * (size_t)(C.Cout > cin ? C.Cout : cin) * 2 >= (1ull << 40)) return 1;
     Params P{};
     int nu = 0;
@@ -306,6 +317,8 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
     P.weight = C.weight; P.bias = C.bias; P.res_act = C.res_act; P.res_scale = C.res_scale; P.res_shift = C.res_shift; P.out = C.out;
     P.B = C.B; P.H = C.H; P.W = C.W; P.Cout = C.Cout; P.ntiles = C.B * (plane / tile);
     const bool narrow = C.Cout == 64;
+    if (cin == 64) return launch<4, 64, 128, false, 3>(P, s);                 // to_qkv of the 64-channel LinearAttention (training)
+    if (cin == 128 && C.Cout == 384 && !ra && !C.bias) return launch<4, 128, 128, false, 3>(P, s);
     if (cin == 128) {
         if (narrow) return ra ? launch<2, 128, 128, true>(P, s) : launch<2, 128, 128, false>(P, s);
         return ra ? 1 : launch<4, 128, 128, false>(P, s);      // (no 128 -> 128+ res_conv in this UNet)

@@ -159,6 +159,10 @@ def test_conv1x1_variants(L, B, H, W, grid, monkeypatch):
     ref = F.conv2d(x, q(w))
     out, _ = run_conv(L, B, H, W, 1, [dict(t=to_nhwc(x))], 384, prep_weight(L, w, 1))
     check_close(from_nhwc(out), ref, what="qkv 1x1")
+    xw = q(torch.randn(B, 128, H, W))
+    w = torch.randn(384, 128, 1, 1) / math.sqrt(128)
+    out, _ = run_conv(L, B, H, W, 1, [dict(t=to_nhwc(xw))], 384, prep_weight(L, w, 1))
+    check_close(from_nhwc(out), F.conv2d(xw, q(w)), what="qkv 1x1, 128 -> 384")
     # res_conv on a concatenated input with the fused "+ SiLU(affine(h))" epilogue (DD:214)
     x1, x2 = q(torch.randn(B, 128, H, W)), q(torch.randn(B, 64, H, W))
     w = torch.randn(128, 192, 1, 1) / math.sqrt(192)
