@@ -24,16 +24,17 @@ namespace ofd {
 
 namespace wp {
 
-constexpr int NTHREADS = 256, CK = 32, NC = CK / 8, IW = 34, TW = 32, RING = 6, FRAGS = 18;   // 18 weight fragments per 32-channel chunk
+constexpr int CK = 32, NC = CK / 8, IW = 34, TW = 32, RING = 6, FRAGS = 18;   // 18 weight fragments per 32-channel chunk
 
 template <int NS, int PH>
 struct Cfg {
+    static constexpr int NTHREADS = 64 * NS * PH;            // 4 waves; <8,1>: 8 waves = 256 output channels over one staged tile
     static constexpr int BN = 32 * NS, ROWS = 8 * PH, IH = ROWS + 2, NPIX = IH * IW;
     static constexpr int US = (NPIX + 1) * 16;               // octet row of the unit-major tile [NC][NPIX + 1][16 B]; NPIX + 1 is odd
     static constexpr int XB = NC * US;
     static constexpr int LDS_BYTES = 2 * XB;
     static constexpr int XPT = (NPIX * NC + NTHREADS - 1) / NTHREADS;
-    static_assert(NS * PH == 4, "4 waves");
+    static_assert(NS * PH == 4 || (NS == 8 && PH == 1), "4 waves, or 8 channel slices");
     static_assert((NPIX + 1) % 2 == 1, "odd slot count keeps the staging writes of a pixel's octets on distinct banks");
 };
 
@@ -72,8 +73,9 @@ __device__ __forceinline__ void wave_reduce8(float (&v)[8]) {
 // PRO: the GroupNorm-affine + SiLU prologue is compiled in (P.in_scale != nullptr).  The chunk body below is ONE basic block (no
 // run-time branch between its 144 MFMAs), so that the scheduler can put the LDS reads of a group behind the MFMAs of the previous one.
 template <int NS, int PH, bool PRO>
-__global__ void __launch_bounds__(NTHREADS, 2) conv3x3_wp_kernel(const ConvParams P) {
+__global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_wp_kernel(const ConvParams P) {
     using C = Cfg<NS, PH>;
+    constexpr int NTHREADS = C::NTHREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -283,7 +285,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv3x3_wp_kernel(const ConvParam
         // block is written as zero by the wave whose slot it is (slots ns, ns + NS, ...)
         wave_reduce8(stat);
         const int ty8 = oy0 / 8 + ph, tiles8 = (P.H + 7) / 8;
-        if (ty8 < tiles8) {
+        if constexpr (NS * PH == 8) {
+            // 8 slices: every wave writes all four slots of its own four octets -- the sums into slot 0, zeros into the others
+            const int slot = (lane & 31) >> 3, o = (lane & 7) >> 1, which = lane & 1;
+            const float total = __shfl(stat[0], (o * 2 + which) * 8, 64);           // value index k lives in lanes 8k .. 8k+7
+            if (ty8 < tiles8 && lane < 32) {
+                const size_t base = ((((size_t)b * tiles8 + ty8) * P.tiles_x + (t_in % P.tiles_x)) * 4 + slot) * (P.Cout / 8) * 2;
+                P.gn_partial[base + (cb / 8 + o) * 2 + which] = slot == 0 ? total : 0.0f;
+            }
+        } else if (ty8 < tiles8) {
             constexpr int OCT = C::BN / 8;                          // octets of the workgroup's channel block
             constexpr int PER_WAVE = (4 / NS) * OCT * 2;            // floats this wave writes (32)
             // lane t < PER_WAVE writes float t of this wave's share: (slot_i, octet o, sum / sum of squares)
@@ -309,7 +319,7 @@ static int launch(const ConvParams& P, hipStream_t s) {
     }
     const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
     dim3 grid(P.tiles_x * tiles_y * P.B, P.Cout / C::BN);
-    conv3x3_wp_kernel<NS, PH, PRO><<<grid, NTHREADS, C::LDS_BYTES, s>>>(P);
+    conv3x3_wp_kernel<NS, PH, PRO><<<grid, C::NTHREADS, C::LDS_BYTES, s>>>(P);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -318,6 +328,9 @@ static int launch(const ConvParams& P, hipStream_t s) {
 
 // 3x3, stride 1, sources of mode 0 (same size) or 1 (nearest x2): called from conv_forward_impl
 int launch_conv3x3_wp(const ConvParams& P, bool wide, hipStream_t s) {
+    // 256-channel blocks (8 waves over one staged tile: half the tile loads, LDS writes and prologue arithmetic per MFMA): OFD_CONV_WP_BN256=1
+    static const int bn256 = getenv("OFD_CONV_WP_BN256") ? atoi(getenv("OFD_CONV_WP_BN256")) : 0;
+    if (wide && bn256 && P.Cout % 256 == 0) return P.in_scale ? wp::launch<8, 1, true>(P, s) : wp::launch<8, 1, false>(P, s);
     if (P.in_scale) return wide ? wp::launch<4, 1, true>(P, s) : wp::launch<2, 2, true>(P, s);
     return wide ? wp::launch<4, 1, false>(P, s) : wp::launch<2, 2, false>(P, s);
 }
