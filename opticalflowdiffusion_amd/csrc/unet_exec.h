@@ -194,28 +194,41 @@ struct Ctx {
     float* tmpf(size_t n) { return (float*)alloc(scratch, scratch_used, scratch_cap, n * 4); }
     void reset_scratch() { scratch_used = 0; }
 
-    // profiling bracket
-    void begin(int cls, double flops, double bytes, const std::string& label = std::string()) {
-        if (!u->profiling || dry) return;
-        while (u->pool.size() < u->pool_used + 2) {
+    // profiling bracket.  Back-to-back regions share an event: the end of one is the start of the next unless something was
+    // launched in between (RUN outside a region) -- half the event records, half their cost in the timed region.
+    bool in_region = false, chain_ok = false;
+    hipEvent_t last_end = nullptr;
+    hipEvent_t next_event() {
+        while (u->pool.size() < u->pool_used + 1) {
             hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) return;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
             u->pool.push_back(e);
         }
-        ProfRec r{cls, u->pool[u->pool_used], u->pool[u->pool_used + 1], flops, bytes, label};
-        u->pool_used += 2;
-        hipEventRecord(r.e0, s);
+        return u->pool[u->pool_used++];
+    }
+    void begin(int cls, double flops, double bytes, const std::string& label = std::string()) {
+        if (!u->profiling || dry) return;
+        hipEvent_t e0 = chain_ok ? last_end : next_event();
+        hipEvent_t e1 = next_event();
+        if (!e0 || !e1) return;
+        ProfRec r{cls, e0, e1, flops, bytes, label};
+        if (!chain_ok) hipEventRecord(r.e0, s);
         u->recs.push_back(r);
+        in_region = true;
     }
     void end() {
-        if (!u->profiling || dry || u->recs.empty()) return;
+        if (!u->profiling || dry || u->recs.empty() || !in_region) return;
         hipEventRecord(u->recs.back().e1, s);
+        last_end = u->recs.back().e1;
+        chain_ok = true;
+        in_region = false;
     }
 };
 
 #define RUN(expr)                         \
     do {                                  \
         if (c.rc == OFD_OK && !c.dry) {   \
+            if (!c.in_region) c.chain_ok = false; \
             int rc__ = (expr);            \
             if (rc__ != OFD_OK) c.rc = rc__; \
         }                                 \
