@@ -67,6 +67,7 @@ struct Params {
     const float* res_shift;
     bf16_t* out;
     int B, H, W, Cout, ntiles;
+    int interleave;            // 1: workgroup w walks tiles w, w + G, ... (the resident workgroups sweep ONE moving window of memory); 0: a contiguous range each
 };
 
 // NSG: 32-channel slices per workgroup (output block = 32 NSG channels), CIN, TILE pixels per step, RA: fused SiLU(affine(h2)) input,
@@ -136,9 +137,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P)
         }
     };
 
-    // contiguous tile range of this workgroup: the sample index (and with it the GroupNorm affine of h2) changes once or twice
-    int t = (int)(((long)blockIdx.x * P.ntiles) / gridDim.x);
-    const int t_end = (int)(((long)(blockIdx.x + 1) * P.ntiles) / gridDim.x);
+    // tile walk: interleaved (t = w, w + G, ...) keeps the ~500 resident workgroups inside one moving window of a few MB -- DRAM pages
+    // are streamed through once; contiguous per-workgroup ranges spread them over the whole tensor (measured 20 % slower on the
+    // same pattern in resblock_out).  The price: the sample index changes every plane / TILE / G tiles instead of once or twice.
+    const int t_step = P.interleave ? (int)gridDim.x : 1;
+    int t = P.interleave ? (int)blockIdx.x : (int)(((long)blockIdx.x * P.ntiles) / gridDim.x);
+    const int t_end = P.interleave ? P.ntiles : (int)(((long)(blockIdx.x + 1) * P.ntiles) / gridDim.x);
     if (t >= t_end) return;
     int b_cur = -1;
     float4 sc4[RA ? 4 : 1], sh4[RA ? 4 : 1];
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P)
     for (int q = 0; q < 4; ++q) cx[q] = ((q * 2 + half) ^ (l31 & 7)) * 16;
 
     for (;;) {
-        const int tn = t + 1, tq = tn < t_end ? tn : t;                           // past the end: the same tile again (never used)
+        const int tn = t + t_step, tq = tn < t_end ? tn : t;                           // past the end: the same tile again (never used)
         // VMEM issue order per wave: ... [h2(t)] [stores(t-1)] | [DMA(t+1)] ... [h2(t+1)] [stores(t)] | ...   (in-order return)
         // here: all but the youngest NRA + NST have landed, i.e. this wave's DMA pieces of tile t
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRA + NST) : "memory");
@@ -316,6 +320,8 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
     if (nu * 64 != cin) return 1;
     P.weight = C.weight; P.bias = C.bias; P.res_act = C.res_act; P.res_scale = C.res_scale; P.res_shift = C.res_shift; P.out = C.out;
     P.B = C.B; P.H = C.H; P.W = C.W; P.Cout = C.Cout; P.ntiles = C.B * (plane / tile);
+    static const int order = getenv("OFD_CONV1_ORDER") ? atoi(getenv("OFD_CONV1_ORDER")) : 1;
+    P.interleave = order;
     const bool narrow = C.Cout == 64;
     if (cin == 64) return launch<4, 64, 128, false, 3>(P, s);                 // to_qkv of the 64-channel LinearAttention (training)
     if (cin == 128 && C.Cout == 384 && !ra && !C.bias) return launch<4, 128, 128, false, 3>(P, s);

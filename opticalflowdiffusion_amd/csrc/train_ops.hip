@@ -2,6 +2,7 @@
 // DD:116-125 LayerNorm, DD:361 final conv) plus the un-fused forward pieces the training forward
 // keeps (the inference path fuses them into conv loaders / epilogues).  NHWC bf16 activations and
 // activation gradients, fp32 statistics and parameter gradients.
+#include <cstdlib>
 #include "blocks.h"
 
 namespace ofd {
@@ -373,7 +374,9 @@ __global__ void __launch_bounds__(256) time_mlp_bwd_weight_kernel(const float* _
     }
 }
 
-static inline int tgrid(size_t total, int cap = 4096) {
+static inline int tgrid(size_t total, int cap = 4096) {   // cap = 0: uncapped, see sgrid in blocks.hip
+    static const int env_cap = getenv("OFD_GRID_CAP") ? atoi(getenv("OFD_GRID_CAP")) : (1 << 22);
+    if (cap <= 0) cap = env_cap;
     size_t b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > (size_t)cap ? cap : b));
 }
@@ -417,7 +420,7 @@ int k_gn_silu_backward(const bf16_t* g, const bf16_t* h, const float* a, const f
     gnbwd_finalize_kernel<<<dim3(B, 8), 256, 0, st>>>(partial, chunks, C, (double)pps * (C / 8), (double)pps, stats, gamma, beta, a, ss, ss_stride,
                                                     ss_offset, c2c3, dgamma, dbeta, dss, dconv_bias);
     const size_t units = (size_t)B * pps * (C / 8);
-    gnbwd_apply_kernel<<<tgrid(units), 256, 0, st>>>(g, h, a, s, c2c3, dh, C, pps, units);
+    gnbwd_apply_kernel<<<tgrid(units, 0), 256, 0, st>>>(g, h, a, s, c2c3, dh, C, pps, units);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
