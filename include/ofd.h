@@ -236,7 +236,8 @@ typedef struct {
     int up2_phase;          /* ksize 2 only: 1 + py*2 + px.  Upsample(x2, nearest) + 3x3 (DD:89-93) as four 2x2 convs on
                                the LOW-RES source: B,H,W are the low-res size, `out` is the (2H, 2W) tensor and this
                                launch writes its pixels (2y+py, 2x+px); weights from ofd_conv_upsample_phase_weight_prep
-                               (+ (up2_phase-1) * 4*Cin*Cout elements) */
+                               (+ (up2_phase-1) * 4*Cin*Cout elements).  5 = all four phases in one launch (`weight` =
+                               the base of the four kernels): the phases of a pixel tile run together on one XCD */
 } ofd_conv_args;
 
 int ofd_conv_forward(const ofd_conv_args* a, void* stream);

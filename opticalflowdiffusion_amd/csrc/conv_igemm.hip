@@ -144,6 +144,16 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
     // the halo rows two neighbouring tiles share are served by one L2.
     const int ntiles = P.tiles_x * P.tiles_y * P.B;
     int tile = blockIdx.x;
+    // KS == 2, all four phases in this launch: phase from the block index, the per-phase fields derived here
+    int ph_pad_y = P.pad_y, ph_pad_x = P.pad_x, ph_oy = P.out_oy, ph_ox = P.out_ox;
+    const bf16_t* ph_weight = P.weight;
+    if (KS == 2 && P.phase_all) {
+        const int j = blockIdx.x, g = j >> 3, ph = g & 3;
+        tile = (g >> 2) * 8 + (j & 7);
+        if (tile >= ntiles) return;                       // (grid padded to whole groups of 8 tiles x 4 phases; uniform per workgroup)
+        ph_pad_y = 1 - (ph >> 1); ph_pad_x = 1 - (ph & 1); ph_oy = ph >> 1; ph_ox = ph & 1;
+        ph_weight = P.weight + (size_t)ph * 4 * P.Cin_total * P.Cout;
+    }
     if (ntiles >= 8) {
         const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -195,8 +205,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
     const int cin8 = P.Cin_total / 8;
     const int total_slabs = P.total_chunks * C::STAGES;
     const int dbg = P.dbg;
-    conv_load_w<KS, BN>(w1, P.weight, cin8, P.Cout, n0, 0, 0, tid);                                   // slab 0
-    if (DEEP) conv_load_w<KS, BN>(w2, P.weight, cin8, P.Cout, n0, 0, (total_slabs > 1) ? 1 : 0, tid);   // slab 1
+    conv_load_w<KS, BN>(w1, ph_weight, cin8, P.Cout, n0, 0, 0, tid);                                   // slab 0
+    if (DEEP) conv_load_w<KS, BN>(w2, ph_weight, cin8, P.Cout, n0, 0, (total_slabs > 1) ? 1 : 0, tid);   // slab 1
 
     int src_i = 0, src_first = 0;   // source that owns chunk kc, and its first chunk
     for (int kc = 0; kc < P.total_chunks; ++kc) {
@@ -219,7 +229,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
         for (int i = 0; i < C::XPT; ++i) {
             const int p = min(tid / C::NC + i * (NTHREADS / C::NC), C::NPIX - 1);
             const int ty = p / C::IW, tx = p - ty * C::IW;
-            const int iy = oy0 - (KS == 2 ? P.pad_y : C::PAD) + ty, ix = ox0 - (KS == 2 ? P.pad_x : C::PAD) + tx;
+            const int iy = oy0 - (KS == 2 ? ph_pad_y : C::PAD) + ty, ix = ox0 - (KS == 2 ? ph_pad_x : C::PAD) + tx;
             const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
             okmask |= (ok ? 1u : 0u) << i;
             const int cy = min(max(iy, 0), P.H - 1), cx = min(max(ix, 0), P.W - 1);
@@ -260,7 +270,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             conv_store_w<KS, BN>(w1, lds_w, tid);
             if (DEEP) {
                 w1 = w2;
-                conv_load_w<KS, BN>(w2, P.weight, cin8, P.Cout, n0, 0, (total_slabs > 2) ? 2 : 0, tid);
+                conv_load_w<KS, BN>(w2, ph_weight, cin8, P.Cout, n0, 0, (total_slabs > 2) ? 2 : 0, tid);
             }
         }
 
@@ -269,7 +279,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
 #pragma unroll UNR
         for (int st = 0; st < C::STAGES; ++st) {
             const int g = g0 + st;
-            if (!DEEP && g + 1 < total_slabs) conv_load_w<KS, BN>(w1, P.weight, cin8, P.Cout, n0, kc, st + 1, tid);
+            if (!DEEP && g + 1 < total_slabs) conv_load_w<KS, BN>(w1, ph_weight, cin8, P.Cout, n0, kc, st + 1, tid);
             __syncthreads();   // lds_x (st == 0) and the W buffer of slab g are complete
             const unsigned char* wbuf = lds_w + (g & 1) * C::W_BYTES;
             const int ky = (KS == 3) ? st / 3 : (C::KSZ == 7 ? st : (KS == 2 ? st / 2 : 0));
@@ -307,7 +317,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             if (g + 1 < total_slabs) conv_store_w<KS, BN>(w1, lds_w + ((g + 1) & 1) * C::W_BYTES, tid);
             if (DEEP) {
                 w1 = w2;
-                if (g + 3 < total_slabs) conv_load_w<KS, BN>(w2, P.weight, cin8, P.Cout, n0, kc, st + 3, tid);
+                if (g + 3 < total_slabs) conv_load_w<KS, BN>(w2, ph_weight, cin8, P.Cout, n0, kc, st + 3, tid);
             }
         }
     }
@@ -332,7 +342,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
         const bool ok = oy < P.H && ox < P.W && !(dbg & 16);
         const size_t pix = ((size_t)b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1);   // clamped: loads stay in bounds
         // KS == 2: this launch is one phase of an up-sampled 3x3 -> the output pixel is (2y + oy, 2x + ox) of a (2H, 2W) tensor
-        const size_t opix = (KS == 2) ? ((size_t)b * (2 * P.H) + 2 * min(oy, P.H - 1) + P.out_oy) * (2 * P.W) + 2 * min(ox, P.W - 1) + P.out_ox : pix;
+        const size_t opix = (KS == 2) ? ((size_t)b * (2 * P.H) + 2 * min(oy, P.H - 1) + ph_oy) * (2 * P.W) + 2 * min(ox, P.W - 1) + ph_ox : pix;
 #pragma unroll
         for (int nt = 0; nt < C::NTN; ++nt) {
             // destination of this 32-channel block (uniform per workgroup and nt): the second one when the output is split
@@ -423,7 +433,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             const int oy = oy0 + wave * 2 + (pl >> 5), ox = ox0 + (pl & 31);
             const bool ok = oy < P.H && ox < P.W && !(dbg & 16);
             const size_t pix = ((size_t)b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1);
-            const size_t opix = (KS == 2) ? ((size_t)b * (2 * P.H) + 2 * min(oy, P.H - 1) + P.out_oy) * (2 * P.W) + 2 * min(ox, P.W - 1) + P.out_ox : pix;
+            const size_t opix = (KS == 2) ? ((size_t)b * (2 * P.H) + 2 * min(oy, P.H - 1) + ph_oy) * (2 * P.W) + 2 * min(ox, P.W - 1) + ph_ox : pix;
             const int c0 = n0 + cu * 8;
             const bool second = P.split > 0 && c0 >= P.split;
             bf16_t* const o_base = second ? P.out2 : P.out;
@@ -1076,7 +1086,8 @@ static int launch_conv(const ConvParams& P, hipStream_t s) {
         OFD_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<KS, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_set = true;
     }
-    dim3 grid(P.tiles_x * P.tiles_y * P.B, P.Cout / BN);
+    const int ntiles = P.tiles_x * P.tiles_y * P.B;
+    dim3 grid((KS == 2 && P.phase_all) ? (ntiles + 7) / 8 * 32 : ntiles, P.Cout / BN);
     conv_igemm_kernel<KS, BN><<<grid, NTHREADS, C::LDS_BYTES, s>>>(P);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
@@ -1090,7 +1101,7 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     OFD_CHECK_ARG(a && a->out && a->weight, "conv: null out/weight");
     OFD_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0, "conv: bad shape");
     OFD_CHECK_ARG(a->ksize == 1 || a->ksize == 2 || a->ksize == 3 || a->ksize == 7, "conv: ksize %d unsupported", a->ksize);
-    OFD_CHECK_ARG((a->ksize == 2) == (a->up2_phase >= 1 && a->up2_phase <= 4), "conv: ksize 2 is one phase (up2_phase 1..4) of an up-sampled 3x3");
+    OFD_CHECK_ARG((a->ksize == 2) == (a->up2_phase >= 1 && a->up2_phase <= 5), "conv: ksize 2 is one phase (up2_phase 1..4) of an up-sampled 3x3, or all four (5)");
     OFD_CHECK_ARG(a->ksize != 2 || (!a->residual && !a->res_act && !a->gn_partial), "conv: phase convs take no residual / GroupNorm statistics");
     OFD_CHECK_ARG(a->Cout > 0 && a->Cout % 64 == 0, "conv: Cout=%d must be a multiple of 64", a->Cout);
     OFD_CHECK_ARG(a->n_src >= 1 && a->n_src <= 4, "conv: n_src=%d", a->n_src);
@@ -1131,6 +1142,7 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
     if (a->ksize == 2) {
         const int py = (a->up2_phase - 1) >> 1, px = (a->up2_phase - 1) & 1;
         P.pad_y = 1 - py; P.pad_x = 1 - px; P.out_oy = py; P.out_ox = px;
+        P.phase_all = a->up2_phase == 5;
     }
     { static int dbg_env = -1; if (dbg_env < 0) { const char* e = getenv("OFD_CONV_DBG"); dbg_env = e ? atoi(e) : 0; } P.dbg = dbg_env; }
     // 128 output channels per workgroup unless that leaves CUs without work: small images (the reference's default 128 x 128 reaches

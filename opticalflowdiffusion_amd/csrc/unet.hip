@@ -298,14 +298,15 @@ static void upsample_conv(Ctx& c, const std::string& prefix, const SrcSpec& src_
     const double px = (double)c.B * out.H * out.W;
     c.begin(PC_CONVUP, 2.0 * px * d.Cout * (double)d.Cin * 9 /* algorithmic: as the reference executes it */, px * 2.0 * (d.Cout + d.Cin / 4.0),
             prefix + " " + std::to_string(d.Cin) + "->" + std::to_string(d.Cout) + " @" + std::to_string(out.H) + "x" + std::to_string(out.W) + " (4 phases)");
-    for (int ph = 0; ph < 4; ++ph) {
+    static const int one_launch = getenv("OFD_PHASE_ONE_LAUNCH") ? atoi(getenv("OFD_PHASE_ONE_LAUNCH")) : 1;
+    for (int ph = 0; ph < (one_launch ? 1 : 4); ++ph) {
         ofd_conv_args a{};
         a.B = c.B; a.H = lo.H; a.W = lo.W; a.ksize = 2; a.n_src = 1; a.Cout = d.Cout;
         a.src[0].src = lo.p; a.src[0].channels = lo.C; a.src[0].src_channels = lo.C;
         a.weight = u->d_wbuf + d.phase_off + (size_t)ph * 4 * d.Cin * d.Cout;
         a.bias = u->P(prefix + ".bias");
         a.out = out.p;
-        a.up2_phase = ph + 1;
+        a.up2_phase = one_launch ? 5 : ph + 1;          // 5: the four phases in one launch (phases of a tile on one XCD: conv_params.h)
         RUN(conv_forward_impl(&a, c.s));
     }
     c.end();

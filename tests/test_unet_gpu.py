@@ -358,6 +358,15 @@ def test_upsample_conv_as_four_phase_convs(L, B, H, W, Cin, Cout):
     assert torch.isfinite(got).all()                       # every output pixel written by exactly one phase
     # vs the per-tap-rounded weights of the bf16c contract: two different bf16 roundings of the same fp32 kernel ...
     check_close(got, ref, tol=4e-3, what="phase-decomposed upsample conv")
+    # the four phases in ONE launch (up2_phase = 5, what the UNet runs): the same kernel per phase, bit-identical output
+    out1 = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    a = L.ConvArgs()
+    a.B, a.H, a.W, a.ksize, a.n_src, a.Cout = B, H, W, 2, 1, Cout
+    a.src[0].src, a.src[0].channels, a.src[0].src_channels = xd.data_ptr(), Cin, Cin
+    a.weight, a.bias, a.out, a.up2_phase = wp.data_ptr(), bd.data_ptr(), out1.data_ptr(), 5
+    L.check(L.lib().ofd_conv_forward(ctypes.byref(a), L.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out)
     # ... and vs the un-rounded fp32 weights the collapsed kernels are at least as close as the per-tap rounding is
     exact = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, bias, padding=1)
     assert rel_l2(got, q(exact)) <= 1.25 * rel_l2(q(ref), q(exact)) + 1e-4
