@@ -85,14 +85,20 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
     // XCD-aware tile order (blocks that share an XCD get a contiguous run of tiles: halo rows of neighbours hit one L2)
     const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
     const int tpi = P.tiles_x * tiles_y, ntiles = tpi * P.B;
-    int tile = blockIdx.x;
+    int tile = blockIdx.x, cy = blockIdx.y;
+    if (P.cy_fast) {                                  // block j -> XCD j % 8, channel block (j / 8) % NY, tile slot j / 8 / NY
+        const int ny = P.Cout / C::BN, j = blockIdx.x, g = j >> 3;
+        cy = g % ny;
+        tile = (g / ny) * 8 + (j & 7);
+        if (tile >= ntiles) return;
+    }
     if (ntiles >= 8) {
         const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int b = tile / tpi, t_in = tile % tpi;
     const int oy0 = (t_in / P.tiles_x) * C::ROWS, ox0 = (t_in % P.tiles_x) * TW;
-    const int n0 = blockIdx.y * C::BN;
+    const int n0 = cy * C::BN;
     const int cb = n0 + 32 * ns;                      // this wave's 32 output channels
 
     // ---- weights: buffer loads, per-lane offset fixed for the launch, per-fragment offset scalar
@@ -318,7 +324,9 @@ static int launch(const ConvParams& P, hipStream_t s) {
         attr_set = true;
     }
     const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
-    dim3 grid(P.tiles_x * tiles_y * P.B, P.Cout / C::BN);
+    const int ntiles = P.tiles_x * tiles_y * P.B, ny = P.Cout / C::BN;
+    dim3 grid(ntiles, ny);
+    if (P.cy_fast) grid = dim3((ntiles + 7) / 8 * 8 * ny, 1);
     conv3x3_wp_kernel<NS, PH, PRO><<<grid, C::NTHREADS, C::LDS_BYTES, s>>>(P);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
@@ -327,7 +335,10 @@ static int launch(const ConvParams& P, hipStream_t s) {
 }  // namespace wp
 
 // 3x3, stride 1, sources of mode 0 (same size) or 1 (nearest x2): called from conv_forward_impl
-int launch_conv3x3_wp(const ConvParams& P, bool wide, hipStream_t s) {
+int launch_conv3x3_wp(const ConvParams& P0, bool wide, hipStream_t s) {
+    static const int cy_fast = getenv("OFD_CONV_WP_CYFAST") ? atoi(getenv("OFD_CONV_WP_CYFAST")) : 0;
+    ConvParams P = P0;
+    P.cy_fast = cy_fast && P.Cout / (wide ? 128 : 64) > 1;
     // 256-channel blocks (8 waves over one staged tile: half the tile loads, LDS writes and prologue arithmetic per MFMA): OFD_CONV_WP_BN256=1
     static const int bn256 = getenv("OFD_CONV_WP_BN256") ? atoi(getenv("OFD_CONV_WP_BN256")) : 0;
     if (wide && bn256 && P.Cout % 256 == 0) return P.in_scale ? wp::launch<8, 1, true>(P, s) : wp::launch<8, 1, false>(P, s);
