@@ -100,12 +100,22 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
                                                           float* __restrict__ a_out, float* __restrict__ s_out, float* __restrict__ stats_out) {
     const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const int gs = C / 8, octs = gs / 8, noct = C / 8;
+    // the entries of one group are 8 bytes every C/8 * 8 bytes: a latency chain if walked one load at a time (13 us per launch at full
+    // resolution, 38 launches per step) -- GU independent loads per thread are in flight together
+    constexpr int GU = 8;
     double s1 = 0.0, s2 = 0.0;
-    for (int i = tid; i < tiles * octs; i += 256) {
-        const int tile = i / octs, o = g * octs + i % octs;
-        const float* p = partial + (((size_t)b * tiles + tile) * noct + o) * 2;
-        s1 += (double)p[0];
-        s2 += (double)p[1];
+    const int total = tiles * octs;
+    for (int i0 = tid; i0 < total; i0 += 256 * GU) {
+        float2 v[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = min(i0 + u * 256, total - 1);
+            const int tile = i / octs, o = g * octs + i % octs;
+            v[u] = *(const float2*)(partial + (((size_t)b * tiles + tile) * noct + o) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+            if (i0 + u * 256 < total) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
     }
     __shared__ double r1[256], r2[256];
     r1[tid] = s1;
