@@ -521,6 +521,7 @@ extern "C" void ofd_unet_destroy(ofd_unet* u) {
     if (u->d_mlp) hipFree(u->d_mlp);
     if (u->d_labuf) hipFree(u->d_labuf);
     if (u->d_wtbuf) hipFree(u->d_wtbuf);
+    if (u->d_wacc) hipFree(u->d_wacc);
     drop_graphs(u);
     for (auto e : u->pool) hipEventDestroy(e);
     delete u;

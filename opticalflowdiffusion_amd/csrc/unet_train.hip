@@ -67,9 +67,8 @@ static Tensor conv_backward(Bwd& b, const std::string& prefix, const std::vector
     // (block convs: the GroupNorm backward already summed dh)
     float* gb = bias_done ? nullptr : u->G(prefix + ".bias");
     const size_t nacc = (size_t)taps * d.Cin_pad * d.Cout;
-    float* acc = b.stmpf(nacc);
-    if (c.rc != OFD_OK) return D;
-    if (!c.dry && hipMemsetAsync(acc, 0, nacc * 4, c.s) != hipSuccess) { set_error("conv_backward: memset failed"); c.rc = OFD_ERR_HIP; return D; }
+    float* acc = u->d_wacc + d.w_off;          // zeroed once per backward (run_backward): no memset launch per conv
+    (void)nacc;
     c.begin(d.ksize == 3 ? PC_WGRAD3 : PC_WGRAD1, 2.0 * px * d.Cout * (double)d.Cin * taps, px * 2.0 * (d.Cout + cin), prefix + " wgrad");
     if (d.ksize == 7) {
         RUN(k_conv7_wgrad(srcs[0].t.p, dy, acc, B, H, W, c.s, gb));
@@ -293,7 +292,8 @@ static int run_backward(Ctx& c, const float* dout, const TrainLayout& L, float* 
         if (it != u->prange.end()) cb(it->second.first, it->second.second, user);
     };
     if (!c.dry) {
-        if (hipMemsetAsync(u->d_grads, 0, u->n_param_floats * 4, c.s) != hipSuccess ||
+        if (hipMemsetAsync(u->d_wacc, 0, u->n_wbuf * sizeof(float), c.s) != hipSuccess ||
+            hipMemsetAsync(u->d_grads, 0, u->n_param_floats * 4, c.s) != hipSuccess ||
             hipMemsetAsync(dss, 0, ((size_t)B * u->ss_stride + (size_t)B * dim * 4) * 4, c.s) != hipSuccess) {
             set_error("unet_backward: memset failed");
             return OFD_ERR_HIP;
@@ -412,6 +412,7 @@ static int prepare_train(ofd_unet* u, hipStream_t s) {
         }
     }
     if (!u->d_wtbuf) OFD_HIP(hipMalloc(&u->d_wtbuf, u->n_wbuf * sizeof(bf16_t)));
+    if (!u->d_wacc) OFD_HIP(hipMalloc(&u->d_wacc, u->n_wbuf * sizeof(float)));
     if (!u->wt_prepared) {
         for (auto& cd : u->convs) {
             if (cd.ksize == 7) continue;                      // first layer: no data gradient
