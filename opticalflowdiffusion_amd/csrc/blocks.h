@@ -22,6 +22,16 @@ int k_wgrad_finish(const float* acc, const float* w_raw, float* dst, int Cout, i
 int k_grad_scatter(const bf16_t* D, int Ctot, int ch_off, bf16_t* dst, int C, int B, int H, int W, int mode, int p1, int p2, int accumulate,
                    hipStream_t s);
 
+struct ofd_weight_prep_desc {      // one conv of conv_weight_prep_batched_kernel / wt_transpose_batched_kernel
+    const float* w;                // OIHW fp32 (prep) | prepared bf16 weights (transpose: reinterpret)
+    void* out;
+    int Cout, Cin, Cin_pad, ksize;
+    float ws_eps;
+    int unshuffle;
+    int block0;                    // first block of this conv in the batched grid
+};
+int k_conv_weight_prep_batched(const ofd_weight_prep_desc* d_descs, int n, int total_blocks, hipStream_t s);
+int k_wt_transpose_batched(const ofd_weight_prep_desc* d_descs, int n, int total_blocks, hipStream_t s);
 int k_pack_input(const float* x, int Cx, const float* cond, int Cc, bf16_t* out, int B, int H, int W, hipStream_t s, int cpad = 16);
 int k_time_mlp(const int64_t* t, const float* w1, const float* b1, const float* w2, const float* b2, float* temb,
                float* temb_silu, int B, int dim, hipStream_t s);

@@ -31,6 +31,31 @@ __global__ void __launch_bounds__(256) wt_transpose_kernel(const bf16_t* __restr
     }
 }
 
+// all convs in one launch: desc.w = prepared weights, desc.out = transposed; a conv owns blocks [block0, next block0), each block
+// walks its conv's elements with a stride of that many blocks
+__global__ void __launch_bounds__(256) wt_transpose_batched_kernel(const ofd_weight_prep_desc* __restrict__ descs, int n, int total_blocks) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ofd_weight_prep_desc d = descs[lo];
+    const int nb = (lo + 1 < n ? descs[lo + 1].block0 : total_blocks) - d.block0, lb = (int)blockIdx.x - d.block0;
+    const bf16_t* w = (const bf16_t*)d.w;
+    bf16_t* wt = (bf16_t*)d.out;
+    const int taps = d.ksize * d.ksize, Cin = d.Cin_pad, Cout = d.Cout;
+    const size_t total = (size_t)taps * Cin * Cout;
+    for (size_t i = (size_t)lb * 256 + threadIdx.x; i < total; i += (size_t)nb * 256) {
+        const int j = (int)(i & 7);
+        const size_t r = i >> 3;
+        const int ci = (int)(r % Cin);
+        const size_t r2 = r / Cin;
+        const int co8 = (int)(r2 % (Cout / 8)), tapp = (int)(r2 / (Cout / 8));
+        const int co = co8 * 8 + j, tap = taps - 1 - tapp;
+        wt[i] = w[(((size_t)tap * (Cin / 8) + ci / 8) * Cout + co) * 8 + (ci & 7)];
+    }
+}
+
 struct WgradParams {
     int B, H, W, Cout, Cin_total, n_src, tiles_x, tiles_y;
     ConvSrcDev src[4];
@@ -661,6 +686,12 @@ int k_channel_sum(const bf16_t* dy, float* out, size_t npix, int C, hipStream_t 
     if (grid > 512) grid = 512;                                             // ... and at most 512 atomics per channel
     if (grid < 1) grid = 1;
     channel_sum_kernel<<<(unsigned)grid, 256, 0, s>>>(dy, out, npix, C);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+int k_wt_transpose_batched(const ofd_weight_prep_desc* d_descs, int n, int total_blocks, hipStream_t s) {
+    wt_transpose_batched_kernel<<<total_blocks, 256, 0, s>>>(d_descs, n, total_blocks);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "conv_params.h"
+#include "blocks.h"
 
 namespace ofd {
 
@@ -1014,9 +1015,9 @@ static int launch_conv_ws(const ConvParams& P, hipStream_t s) {
 }
 
 // ---- weight preparation: OIHW fp32 -> [tap][Cin_pad/8][Cout][8] bf16 (+ weight standardisation)
-__global__ void __launch_bounds__(256) conv_weight_prep_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout,
-                                                               int Cin, int Cin_pad, int ksize, float ws_eps, int unshuffle) {
-    const int o = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void conv_weight_prep_body(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int Cin_pad,
+                                                      int ksize, float ws_eps, int unshuffle, int o) {
+    const int tid = threadIdx.x;
     const int taps = ksize * ksize, n = Cin * taps;
     const float* wo = w + (size_t)o * n;
     __shared__ double sh[256];
@@ -1055,6 +1056,23 @@ __global__ void __launch_bounds__(256) conv_weight_prep_kernel(const float* __re
     }
     if (ksize == 7 && Cin_pad == 8)
         for (int i = tid; i < 7 * 8; i += 256) out[(((size_t)(i / 8) * 8 + 7) * Cout + o) * 8 + (i % 8)] = 0;
+}
+
+__global__ void __launch_bounds__(256) conv_weight_prep_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout,
+                                                               int Cin, int Cin_pad, int ksize, float ws_eps, int unshuffle) {
+    conv_weight_prep_body(w, out, Cout, Cin, Cin_pad, ksize, ws_eps, unshuffle, blockIdx.x);
+}
+
+// every conv of a UNet in ONE launch (the training step re-prepares all weights after each optimizer step: 95 launches of ~8 us
+// otherwise): block -> descriptor by binary search over the first-block table
+__global__ void __launch_bounds__(256) conv_weight_prep_batched_kernel(const ofd_weight_prep_desc* __restrict__ descs, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ofd_weight_prep_desc d = descs[lo];
+    conv_weight_prep_body(d.w, (bf16_t*)d.out, d.Cout, d.Cin, d.Cin_pad, d.ksize, d.ws_eps, d.unshuffle, (int)blockIdx.x - d.block0);
 }
 
 // nearest-x2 up-sample followed by a 3x3 conv (DD:89-93) = four 2x2 convs on the LOW-RES input, one per output phase
@@ -1220,6 +1238,14 @@ extern "C" int ofd_conv_weight_prep(const float* w_oihw, void* w_out, int Cout, 
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
+
+namespace ofd {
+int k_conv_weight_prep_batched(const ofd_weight_prep_desc* d_descs, int n, int total_blocks, hipStream_t s) {
+    conv_weight_prep_batched_kernel<<<total_blocks, 256, 0, s>>>(d_descs, n);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+}  // namespace ofd
 
 extern "C" int ofd_conv_upsample_phase_weight_prep(const float* w_oihw, void* w_out, int Cout, int Cin, void* stream) {
     OFD_CHECK_ARG(w_oihw && w_out && Cout > 0 && Cin > 0 && Cin % 8 == 0, "upsample_phase_weight_prep: bad argument");

@@ -522,6 +522,8 @@ extern "C" void ofd_unet_destroy(ofd_unet* u) {
     if (u->d_labuf) hipFree(u->d_labuf);
     if (u->d_wtbuf) hipFree(u->d_wtbuf);
     if (u->d_wacc) hipFree(u->d_wacc);
+    if (u->d_prep) hipFree(u->d_prep);
+    if (u->d_tr) hipFree(u->d_tr);
     drop_graphs(u);
     for (auto e : u->pool) hipEventDestroy(e);
     delete u;
@@ -559,15 +561,31 @@ extern "C" int ofd_unet_prepare(ofd_unet* u, void* stream) {
             set_error("unet_prepare: parameter %s was never set", p.name.c_str());
             return OFD_ERR_STATE;
         }
-    for (auto& c : u->convs) {
-        int rc = ofd_conv_weight_prep(u->P(c.wname), u->d_wbuf + c.w_off, c.Cout, c.Cin, c.Cin_pad, c.ksize, c.ws_eps, c.unshuffle, stream);
-        if (rc != OFD_OK) return rc;
-        if (c.phase_off >= 0) {
-            rc = ofd_conv_upsample_phase_weight_prep(u->P(c.wname), u->d_wbuf + c.phase_off, c.Cout, c.Cin, stream);
-            if (rc != OFD_OK) return rc;
+    // every conv's fp32 OIHW -> prepared bf16 weights in one launch (descriptor table built once: parameter storage does not move)
+    if (!u->d_prep) {
+        std::vector<ofd_weight_prep_desc> h;
+        int blocks = 0;
+        auto add = [&](const ConvDesc& c, size_t off, int cin_pad, int unshuffle) {
+            ofd_weight_prep_desc d{u->P(c.wname), u->d_wbuf + off, c.Cout, c.Cin, cin_pad, c.ksize, c.ws_eps, unshuffle, blocks};
+            h.push_back(d);
+            blocks += c.Cout;
+        };
+        for (auto& c : u->convs) {
+            add(c, c.w_off, c.Cin_pad, c.unshuffle);
+            if (c.pack8_off >= 0) add(c, (size_t)c.pack8_off, 8, 0);
         }
-        if (c.pack8_off >= 0) {
-            rc = ofd_conv_weight_prep(u->P(c.wname), u->d_wbuf + c.pack8_off, c.Cout, c.Cin, 8, 7, c.ws_eps, 0, stream);
+        OFD_HIP(hipMalloc(&u->d_prep, h.size() * sizeof(ofd_weight_prep_desc)));
+        OFD_HIP(hipMemcpy(u->d_prep, h.data(), h.size() * sizeof(ofd_weight_prep_desc), hipMemcpyHostToDevice));
+        u->n_prep = (int)h.size();
+        u->prep_blocks = blocks;
+    }
+    {
+        int rc = k_conv_weight_prep_batched(u->d_prep, u->n_prep, u->prep_blocks, (hipStream_t)stream);
+        if (rc != OFD_OK) return rc;
+    }
+    for (auto& c : u->convs) {
+        if (c.phase_off >= 0) {
+            int rc = ofd_conv_upsample_phase_weight_prep(u->P(c.wname), u->d_wbuf + c.phase_off, c.Cout, c.Cin, stream);
             if (rc != OFD_OK) return rc;
         }
     }

@@ -107,6 +107,9 @@ struct ofd_unet {
     float* d_grads = nullptr;            // bound by the caller (ofd_unet_bind_grad_buffer), not owned
     std::map<std::string, std::pair<size_t, size_t>> prange;   // op prefix -> [begin, end) floats of its parameters
     bf16_t* d_wtbuf = nullptr;
+    ofd_weight_prep_desc* d_prep = nullptr;   // device tables of the batched weight preparation / transposition (built on first use)
+    ofd_weight_prep_desc* d_tr = nullptr;
+    int n_prep = 0, prep_blocks = 0, n_tr = 0, tr_blocks = 0;
     float* d_wacc = nullptr;      // fp32 weight-gradient accumulators of every conv (same offsets as d_wbuf): ONE memset per backward
     bool wt_prepared = false;
     std::vector<TapeRec> tape;

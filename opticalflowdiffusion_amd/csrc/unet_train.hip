@@ -414,9 +414,23 @@ static int prepare_train(ofd_unet* u, hipStream_t s) {
     if (!u->d_wtbuf) OFD_HIP(hipMalloc(&u->d_wtbuf, u->n_wbuf * sizeof(bf16_t)));
     if (!u->d_wacc) OFD_HIP(hipMalloc(&u->d_wacc, u->n_wbuf * sizeof(float)));
     if (!u->wt_prepared) {
-        for (auto& cd : u->convs) {
-            if (cd.ksize == 7) continue;                      // first layer: no data gradient
-            int rc = k_wt_transpose(u->d_wbuf + cd.w_off, u->d_wtbuf + cd.w_off, cd.ksize * cd.ksize, cd.Cin_pad, cd.Cout, s);
+        if (!u->d_tr) {                                       // one launch for all convs: blocks in proportion to the weight count
+            std::vector<ofd_weight_prep_desc> h;
+            int blocks = 0;
+            for (auto& cd : u->convs) {
+                if (cd.ksize == 7) continue;                  // first layer: no data gradient
+                ofd_weight_prep_desc d{(const float*)(u->d_wbuf + cd.w_off), u->d_wtbuf + cd.w_off, cd.Cout, cd.Cin, cd.Cin_pad, cd.ksize, -1.0f, 0, blocks};
+                h.push_back(d);
+                const size_t total = (size_t)cd.ksize * cd.ksize * cd.Cin_pad * cd.Cout;
+                blocks += (int)std::min<size_t>((total + 2047) / 2048, 256);
+            }
+            OFD_HIP(hipMalloc(&u->d_tr, h.size() * sizeof(ofd_weight_prep_desc)));
+            OFD_HIP(hipMemcpy(u->d_tr, h.data(), h.size() * sizeof(ofd_weight_prep_desc), hipMemcpyHostToDevice));
+            u->n_tr = (int)h.size();
+            u->tr_blocks = blocks;
+        }
+        {
+            int rc = k_wt_transpose_batched(u->d_tr, u->n_tr, u->tr_blocks, s);
             if (rc != OFD_OK) return rc;
         }
         u->wt_prepared = true;
