@@ -308,20 +308,36 @@ __global__ void __launch_bounds__(256) grad_add_kernel(bf16_t* __restrict__ dst,
 __global__ void __launch_bounds__(256) block_mlp_bwd_kernel(const float* __restrict__ dss, const float* __restrict__ ts, const float* __restrict__ weight,
                                                             int n_out, int offset, float* __restrict__ dweight, float* __restrict__ dbias,
                                                             float* __restrict__ dts, int B, int tdim, int ss_stride) {
-    const int tid = threadIdx.x, j0 = blockIdx.x * 16, j1 = min(n_out, j0 + 16);
-    for (int k = tid; k < tdim; k += 256) {
-        for (int j = j0; j < j1; ++j) {
-            float a = 0.0f;
-            for (int b = 0; b < B; ++b) a += dss[(size_t)b * ss_stride + offset + j] * ts[(size_t)b * tdim + k];
-            dweight[(size_t)j * tdim + k] += a;
+    // operands first, arithmetic after: the 16 x 16 tile of dss through LDS, a thread's 16 ts values and 16 weight rows in registers
+    // (the nested global loads were a 60 us latency chain per launch, 19 launches per step)
+    __shared__ float ds[16][17];
+    const int tid = threadIdx.x, j0 = blockIdx.x * 16, j1 = min(n_out, j0 + 16), nj = j1 - j0;
+    for (int kb = 0; kb < tdim; kb += 256) {         // uniform trip count (the barriers below); threads past tdim compute on zeros
+        const int k = kb + tid;
+        const bool kv = k < tdim;
+        float wv[16], dw[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { wv[j] = (j < nj && kv) ? weight[(size_t)(j0 + j) * tdim + k] : 0.0f; dw[j] = 0.0f; }
+        for (int b0 = 0; b0 < B; b0 += 16) {
+            __syncthreads();
+            { const int bb = tid >> 4, jj = tid & 15; ds[bb][jj] = (b0 + bb < B && jj < nj) ? dss[(size_t)(b0 + bb) * ss_stride + offset + j0 + jj] : 0.0f; }
+            __syncthreads();
+            float tsv[16];
+#pragma unroll
+            for (int b = 0; b < 16; ++b) tsv[b] = (b0 + b < B && kv) ? ts[(size_t)(b0 + b) * tdim + k] : 0.0f;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                float a = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { dw[j] += ds[b][j] * tsv[b]; a += wv[j] * ds[b][j]; }
+                if (b0 + b < B && kv) atomicAdd(dts + (size_t)(b0 + b) * tdim + k, a);
+            }
         }
-        for (int b = 0; b < B; ++b) {
-            float a = 0.0f;
-            for (int j = j0; j < j1; ++j) a += weight[(size_t)j * tdim + k] * dss[(size_t)b * ss_stride + offset + j];
-            atomicAdd(dts + (size_t)b * tdim + k, a);
-        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < nj && kv) dweight[(size_t)(j0 + j) * tdim + k] += dw[j];
     }
-    if (tid < j1 - j0) {
+    if (tid < nj) {
         float a = 0.0f;
         for (int b = 0; b < B; ++b) a += dss[(size_t)b * ss_stride + offset + j0 + tid];
         dbias[j0 + tid] += a;
