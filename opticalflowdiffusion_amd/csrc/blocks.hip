@@ -208,26 +208,54 @@ __global__ void __launch_bounds__(256) layernorm_c_kernel(const bf16_t* __restri
 
 // combine the partials: ctx[bh][d][e] = sum_c exp(m_c - M) ctx_c / (sum_c exp(m_c - M) l_c) / n
 __global__ void __launch_bounds__(256) la_ctx_combine_kernel(const float* __restrict__ partial, float* __restrict__ ctx, int nparts, float inv_n, float* __restrict__ ml_out) {
-    __shared__ float M[32], Linv[32];
-    const int tid = threadIdx.x, bh = blockIdx.x;
+    // all 256 threads on the maxima / normalisers (thread -> d = tid & 31, parts tid >> 5, + 8, ...), the per-part weights exp(m_c - M)
+    // once into LDS, eight loads in flight in the accumulation: one thread per d and one load at a time made this 57 us per launch
+    __shared__ float M[32], Linv[32], red[8][32];
+    extern __shared__ float w_s[];                      // [nparts][32]
+    const int tid = threadIdx.x, bh = blockIdx.x, dd = tid & 31, grp = tid >> 5;
     const float* base = partial + (size_t)bh * nparts * 1088;
+    float mx = -3.0e38f;
+    for (int c = grp; c < nparts; c += 8) mx = fmaxf(mx, base[(size_t)c * 1088 + dd]);
+    red[grp][dd] = mx;
+    __syncthreads();
     if (tid < 32) {
-        float mx = -3.0e38f;
-        for (int c = 0; c < nparts; ++c) mx = fmaxf(mx, base[(size_t)c * 1088 + tid]);
-        float l = 0.0f;
-        for (int c = 0; c < nparts; ++c) l += base[(size_t)c * 1088 + 32 + tid] * __expf(base[(size_t)c * 1088 + tid] - mx);
-        M[tid] = mx;
-        Linv[tid] = 1.0f / l;
+        float m = red[0][tid];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) m = fmaxf(m, red[g][tid]);
+        M[tid] = m;
+    }
+    __syncthreads();
+    float l = 0.0f;
+    for (int c = grp; c < nparts; c += 8) {
+        const float w = __expf(base[(size_t)c * 1088 + dd] - M[dd]);
+        w_s[c * 32 + dd] = w;
+        l += base[(size_t)c * 1088 + 32 + dd] * w;
+    }
+    __syncthreads();
+    red[grp][dd] = l;
+    __syncthreads();
+    if (tid < 32) {
+        float t = red[0][tid];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += red[g][tid];
+        Linv[tid] = 1.0f / t;
         if (ml_out) {                     // softmax-over-pixels normalisers, kept for the backward
-            ml_out[(size_t)bh * 64 + tid] = mx;
-            ml_out[(size_t)bh * 64 + 32 + tid] = 1.0f / l;
+            ml_out[(size_t)bh * 64 + tid] = M[tid];
+            ml_out[(size_t)bh * 64 + 32 + tid] = 1.0f / t;
         }
     }
     __syncthreads();
     for (int i = tid; i < 1024; i += 256) {
         const int d = i >> 5;
         float a = 0.0f;
-        for (int c = 0; c < nparts; ++c) a += base[(size_t)c * 1088 + 64 + i] * __expf(base[(size_t)c * 1088 + d] - M[d]);
+        for (int c0 = 0; c0 < nparts; c0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = base[(size_t)min(c0 + k, nparts - 1) * 1088 + 64 + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c0 + k < nparts) a += v[k] * w_s[(c0 + k) * 32 + d];
+        }
         ctx[(size_t)bh * 1024 + i] = a * Linv[d] * inv_n;
     }
 }
@@ -445,7 +473,16 @@ int k_layernorm_c(const bf16_t* x, const float* g, const bf16_t* res, bf16_t* ou
     return OFD_OK;
 }
 void launch_la_ctx_combine(const float* partial, float* ctx, int B, int nparts, float inv_n, float* ml_out, hipStream_t s) {
-    la_ctx_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, nparts, inv_n, ml_out);
+    const size_t lds = (size_t)nparts * 32 * sizeof(float);
+    static size_t lds_max = 48 * 1024;
+    if (lds > lds_max) {                      // (B = 1 at 1080p: ~4000 parts never happens -- parts are capped by n / 512 -- but stay safe)
+        if (lds > 150 * 1024 || hipFuncSetAttribute((const void*)la_ctx_combine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+            set_error("la_ctx_combine: %d parts need %zu bytes of LDS", nparts, lds);
+            return;
+        }
+        lds_max = 150 * 1024;
+    }
+    la_ctx_combine_kernel<<<B * 4, 256, lds, s>>>(partial, ctx, nparts, inv_n, ml_out);
 }
 int k_flash_attention(const bf16_t* qkv, bf16_t* out, int B, int n, hipStream_t s, float* lse) {
     flash_attn_d32_kernel<<<dim3(cdiv(n, 128), B * 4), 256, 0, s>>>(qkv, out, n, 0.17677669529663687f, lse);

@@ -393,7 +393,14 @@ __global__ void __launch_bounds__(256) lc_bwd_combine_kernel(const float* __rest
     const int tid = threadIdx.x, bh = blockIdx.x;
     for (int i = tid; i < 1024; i += 256) {
         float a = 0.0f;
-        for (int c = 0; c < nparts; ++c) a += partial[((size_t)bh * nparts + c) * 1024 + i];
+        for (int c0 = 0; c0 < nparts; c0 += 8) {        // eight loads in flight; the sum stays in part order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partial[((size_t)bh * nparts + min(c0 + k, nparts - 1)) * 1024 + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c0 + k < nparts) a += v[k];
+        }
         dctx[(size_t)bh * 1024 + i] = a;
         prod[i] = a * ctx[(size_t)bh * 1024 + i];
     }
