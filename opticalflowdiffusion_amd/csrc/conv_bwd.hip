@@ -10,6 +10,7 @@
 //     per workgroup (workgroups walk many pixel tiles);
 //   * wgrad_finish_kernel: layout back to OIHW and the backward of weight standardisation
 //     (denoising_diffusion.py:109-112).
+#include <cstdlib>
 #include "blocks.h"
 #include "conv_params.h"
 #include "mfma_util.h"
@@ -66,6 +67,7 @@ struct WgradParams {
     // GroupNorm-affine + SiLU prologue): the weight gradient of a block's second conv reads h1 instead of a materialised act1
     const float* in_scale;
     const float* in_shift;
+    int no_dma;          // A/B switch (OFD_WGRAD_NO_DMA): 3x3 dY tiles through registers
 };
 
 // column sums of a staged dY tile [256 pixels][64 co] (128-byte rows): thread -> (co, quarter of the pixels)
@@ -259,7 +261,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad1_qkv_kernel(const bf16_t* _
 // (ci block, co block): 248 flop per byte, against 83 for one kernel row per workgroup.  The halo rows are
 // walked once; a halo row rr feeds output rows rr, rr-1, rr-2 (ky = 0, 1, 2), whose dY fragments stay in a
 // three-row register window: 8 fragment reads per 18 MFMAs.
-template <bool PRO>      // PRO: SiLU(affine) prologue on the staged input (its own instantiation: the plain one keeps its register budget)
+template <bool PRO, bool DMA>      // PRO: SiLU(affine) prologue on the staged input (its own instantiation: the plain one keeps its register budget); DMA: dY tile by global_load_lds
 __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P) {
     constexpr int IWK = 34, XROWS = 10, XPIX = XROWS * IWK, YPIX = 256;
     constexpr int XPT = (XPIX * 8 + 255) / 256, YPT = YPIX * 8 / 256;
@@ -289,6 +291,27 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int b = t / tpi, t_in = t - b * tpi;
         const int oy0 = (t_in / P.tiles_x) * 8, ox0 = (t_in % P.tiles_x) * 32;
+        if constexpr (DMA) {
+            // dY tile straight into LDS (global_load_lds, lane-linear = the pixel-major [pixel][128 B] layout; pixels of a tile overhang
+            // read a clamped address and are zeroed in LDS afterwards), issued FIRST so that it flies with the halo tile's loads,
+            // transform and stores -- through registers it could only start after those (the two tiles do not fit the register file).
+            // piece j of wave w = pixels (row 2w + j/4, columns 8 (j%4) .. +7): one per-lane base, uniform offsets per piece
+            __syncthreads();     // previous tile's operand reads are complete
+            if (oy0 + 8 <= P.H && ox0 + 32 <= P.W) {
+                const bf16_t* base = P.dy + (((size_t)b * P.H + oy0 + wave * 2) * P.W + ox0 + (lane >> 3)) * P.Cout + cob * 64 + (lane & 7) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    __builtin_amdgcn_global_load_lds(base + ((size_t)(j >> 2) * P.W + (j & 3) * 8) * P.Cout,
+                                                     (__attribute__((address_space(3))) void*)(ys + (wave * 8 + j) * 1024), 16, 0, 0);
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < 8; ++j) {
+                    const int oy = min(oy0 + wave * 2 + (j >> 2), P.H - 1), ox = min(ox0 + (j & 3) * 8 + (lane >> 3), P.W - 1);
+                    const bf16_t* src = P.dy + (((size_t)b * P.H + oy) * P.W + ox) * P.Cout + cob * 64 + (lane & 7) * 8;
+                    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(ys + (wave * 8 + j) * 1024), 16, 0, 0);
+                }
+            }
+        }
         u32x4 xr[XPT];
         unsigned xok = 0;
         const bf16_t* xbase = S.ptr + (size_t)b * S.SH * S.SW * S.src_channels + S.ch_offset + kcl * 64 + c8 * 8;
@@ -305,7 +328,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
             else if (S.mode == 2) { sy = 2 * cy + S.p1; sx = 2 * cx + S.p2; }
             xr[i] = *(const u32x4*)(xbase + ((size_t)sy * S.SW + sx) * S.src_channels);
         }
-        __syncthreads();     // previous tile's operand reads are complete
+        if constexpr (!DMA) __syncthreads();     // previous tile's operand reads are complete
         float ps[8], pb[8];
         if constexpr (PRO) {
 #pragma unroll
@@ -332,6 +355,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
             if (p < XPIX) *(u32x4*)(xs + p * 128 + c8 * 16) = v;
         }
         // (dY tile fetched after the halo tile left its registers: both at once do not fit two workgroups per CU)
+        if constexpr (!DMA) {
         u32x4 yr[YPT];
         unsigned yok = 0;
 #pragma unroll
@@ -350,6 +374,16 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
             *(u32x4*)(ys + p * 128 + c8 * 16) = v;
+        }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the dY tile have landed
+            if (oy0 + 8 > P.H || ox0 + 32 > P.W) {                // tile overhang: those pixels contribute nothing
+#pragma unroll 1
+                for (int j = 0; j < 8; ++j) {
+                    const int p = (wave * 8 + j) * 8 + (lane >> 3);
+                    if (oy0 + (p >> 5) >= P.H || ox0 + (p & 31) >= P.W) *(u32x4*)(ys + p * 128 + (lane & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
         }
         __syncthreads();
         if (do_bias) bsum += ytile_colsum(ys, tid);
@@ -631,6 +665,7 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
     P.Cin_total = cin; P.dy = dy; P.dw = dw; P.dbias = dbias;
     OFD_CHECK_ARG(!a->in_scale || (a->in_shift && a->ksize == 3), "conv_wgrad: the input prologue is a 3x3 feature");
     P.in_scale = a->in_scale; P.in_shift = a->in_shift;
+    { static const int nd = getenv("OFD_WGRAD_NO_DMA") ? atoi(getenv("OFD_WGRAD_NO_DMA")) : 0; P.no_dma = nd; }
     const int ntiles = P.tiles_x * P.tiles_y * P.B, combos = (cin / 64) * (a->Cout / 64);
     int gx = cdiv(1024, combos * a->ksize);     // ~4 workgroups per CU in total; each walks ntiles / gx pixel tiles
     if (gx < 1) gx = 1;
@@ -651,15 +686,23 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
         constexpr int LDS = 10 * 34 * 128 + 256 * 128;
         static bool attr = false;
         if (!attr) {
-            OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-            OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
             attr = true;
         }
         gx = cdiv(512, combos);                  // two workgroups per CU fit (75.5 KB LDS each)
         if (gx < 1) gx = 1;
         if (gx > ntiles) gx = ntiles;
-        if (P.in_scale) conv_wgrad3_kernel<true><<<dim3(gx, combos), 256, LDS, s>>>(P);
-        else conv_wgrad3_kernel<false><<<dim3(gx, combos), 256, LDS, s>>>(P);
+        if (P.no_dma) {
+            if (P.in_scale) conv_wgrad3_kernel<true, false><<<dim3(gx, combos), 256, LDS, s>>>(P);
+            else conv_wgrad3_kernel<false, false><<<dim3(gx, combos), 256, LDS, s>>>(P);
+        } else {
+            // (the prologue instantiation is over its register budget either way: 13 spilled registers through registers, 20 with the DMA)
+            if (P.in_scale) conv_wgrad3_kernel<true, false><<<dim3(gx, combos), 256, LDS, s>>>(P);
+            else conv_wgrad3_kernel<false, true><<<dim3(gx, combos), 256, LDS, s>>>(P);
+        }
     } else {
         constexpr int LDS = 8 * 32 * 128 + 256 * 128;
         static bool attr = false;
