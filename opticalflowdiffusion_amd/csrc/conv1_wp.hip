@@ -9,11 +9,13 @@
 //     the tile of step t+1 is in flight while tile t computes -- ONE counted wait and ONE barrier per tile, no staging registers;
 //   * the LDS image is [64-channel unit][pixel][128 B]; the DMA is lane-linear, so the bank swizzle (16-byte chunk ^ (pixel & 7))
 //     is applied to the SOURCE address of each lane and again on the fragment read (cdna guide T2 / rule 21);
-//   * the epilogue's second input (h2) is fetched one tile ahead with loads the compiler does not see (inline asm), so that its
-//     own vmcnt bookkeeping cannot drain the DMA that is in flight; the waits are counted by hand: per tile and wave the VMEM
-//     issue order is [DMA(t+1)] [h2(t+1)] [stores(t)], the top-of-tile wait is vmcnt(#stores).
-// Persistent: a workgroup walks a contiguous range of tiles.  Tiles are always full (the host checks H*W % TILE == 0), stores are
-// never predicated: the hand-counted waits depend on it.
+//   * the epilogue's second input (h2) is fetched one tile ahead with loads the compiler does not see (inline asm) into ONE register
+//     set that is re-issued right after its last use, so that the compiler's vmcnt bookkeeping cannot drain the DMA in flight; the
+//     fragment reads are inline-asm ds_read_b128 for the same reason (a visible LDS load waits for ALL outstanding LDS-DMA).  The
+//     waits are counted by hand: per tile and wave the VMEM issue order is [DMA(t+1)] ... [h2(t+1)] [stores(t)], the top-of-tile
+//     wait is vmcnt(#h2 + #stores), the wait before the epilogue vmcnt(#stores + #DMA).
+// Persistent: workgroup w walks tiles w, w + G, ... (P.interleave; all resident workgroups inside one moving window of memory).
+// Tiles are always full (the host checks H*W % TILE == 0), stores are never predicated: the hand-counted waits depend on it.
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
