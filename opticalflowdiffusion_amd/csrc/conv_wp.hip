@@ -336,7 +336,7 @@ static int launch(const ConvParams& P, hipStream_t s) {
 
 // 3x3, stride 1, sources of mode 0 (same size) or 1 (nearest x2): called from conv_forward_impl
 int launch_conv3x3_wp(const ConvParams& P0, bool wide, hipStream_t s) {
-    static const int cy_fast = getenv("OFD_CONV_WP_CYFAST") ? atoi(getenv("OFD_CONV_WP_CYFAST")) : 0;
+    static const int cy_fast = getenv("OFD_CONV_WP_CYFAST") ? atoi(getenv("OFD_CONV_WP_CYFAST")) : 1;
     ConvParams P = P0;
     P.cy_fast = cy_fast && P.Cout / (wide ? 128 : 64) > 1;
     // 256-channel blocks (8 waves over one staged tile: half the tile loads, LDS writes and prologue arithmetic per MFMA): OFD_CONV_WP_BN256=1
