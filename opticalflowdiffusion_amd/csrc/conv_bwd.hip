@@ -572,20 +572,41 @@ __global__ void __launch_bounds__(256) wgrad_finish_kernel(const float* __restri
         const double var = block_sum(v) / n;
         mean = (float)m;
         rstd = rsqrtf((float)var + ws_eps);
+        // (the accumulator reads are one 4-byte element every Cout floats: eight of them in flight per thread)
         double a = 0.0, b2 = 0.0;
-        for (int i = tid; i < n; i += 256) {
-            const double g = (double)gval(i);
-            a += g;
-            b2 += g * (double)((wo[i] - mean) * rstd);
+        for (int i0 = tid; i0 < n; i0 += 256 * 8) {
+            float gv[8], wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u * 256, n - 1);
+                gv[u] = gval(i);
+                wv[u] = wo[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * 256 < n) {
+                    const double g = (double)gv[u];
+                    a += g;
+                    b2 += g * (double)((wv[u] - mean) * rstd);
+                }
         }
         mg = (float)(block_sum(a) / n);
         mgw = (float)(block_sum(b2) / n);
     }
-    for (int i = tid; i < n; i += 256) {
-        float g = gval(i);
-        if (ws_eps >= 0.0f) g = rstd * (g - mg - (wo[i] - mean) * rstd * mgw);
-        float* d = dst + (size_t)o * n + i;
-        *d = accumulate ? (*d + g) : g;
+    for (int i0 = tid; i0 < n; i0 += 256 * 8) {
+        float gv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gv[u] = gval(min(i0 + u * 256, n - 1));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            if (i < n) {
+                float g = gv[u];
+                if (ws_eps >= 0.0f) g = rstd * (g - mg - (wo[i] - mean) * rstd * mgw);
+                float* d = dst + (size_t)o * n + i;
+                *d = accumulate ? (*d + g) : g;
+            }
+        }
     }
 }
 
