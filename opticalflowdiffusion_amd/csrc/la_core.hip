@@ -278,9 +278,17 @@ __global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __re
 //   dv     = dctx^T . k / n                                               (MFMA rows e, A = dctx^T)
 constexpr int LB_PITCH = 1024 + 16;       // qkv row (768 B) | dout row (256 B) | pad
 constexpr int LB_LDS = 3 * 4 * 32 * 80 + 3 * 128 * 4 + 32 * LB_PITCH;
+constexpr int LB_LDS_FUSE = LB_LDS + 32 * 128;      // + the xn tile [32 pixels][64 channels]
+// FUSE (C = 64): the backward of the to_qkv 1x1 conv (DD:222) is done here, on the dqkv tile while it is in LDS -- dxn = W^T dqkv
+// (waves 0, 1: one 32-channel block each, 24 k-steps over the 384 qkv channels; A fragments = the data-gradient weights [48][64][8]
+// from L2) and dW[ci][co] += xn^T dqkv (all waves: 64 ci x 96 co each, contraction over the 32 pixels through transposing LDS reads,
+// accumulated in registers over the whole launch, added to `dw` with atomics at the end).  The 5.5 GB dqkv tensor of a full-resolution
+// block is then never written, nor read twice by the two 1x1 backward kernels: 25.8 GB -> 9.2 GB of traffic for the three steps.
+template <bool FUSE>
 __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ ctx,
                                                            const float* __restrict__ dctx, const float* __restrict__ ml, const float* __restrict__ S,
-                                                           bf16_t* __restrict__ dqkv, int n) {
+                                                           bf16_t* __restrict__ dqkv, int n, const bf16_t* __restrict__ xn, const bf16_t* __restrict__ wt,
+                                                           float* __restrict__ dw, bf16_t* __restrict__ dxn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
     unsigned char* cA = lb_smem;
     unsigned char* dA = cA + 4 * 32 * 80;
@@ -289,7 +297,17 @@ __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restr
     float* Li = Ms + 128;
     float* Ss = Li + 128;
     unsigned char* st = (unsigned char*)(Ss + 128);    // [32 pixels][qkv 768 B | dout 256 B | pad]; dqkv overwrites qkv in place
+    unsigned char* xt = st + 32 * LB_PITCH;            // FUSE: [32 pixels][128 B] xn tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5, b = blockIdx.y;
+    f32x16 wacc[FUSE ? 2 : 1][FUSE ? 3 : 1];           // FUSE: dW tiles (ci block a) x (co block wave * 96 + 32 j)
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) wacc[a][j][r] = 0.0f;
+    }
     lc_stage_matrix(cA, ctx + (size_t)b * 4096, false, tid);
     lc_stage_matrix(dA, dctx + (size_t)b * 4096, false, tid);
     lc_stage_matrix(dT, dctx + (size_t)b * 4096, true, tid);
@@ -307,6 +325,10 @@ __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restr
             const size_t p = (size_t)b * n + min(p0 + px, n - 1);
             const bf16_t* src = lane < 48 ? qkv + p * 384 + lane * 8 : dout + p * 128 + (lane - 48) * 8;
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(st + px * LB_PITCH), 16, 0, 0);
+        }
+        if constexpr (FUSE) {              // xn rows 8 wave .. 8 wave + 7 of the tile: lane -> row lane >> 3, 16-byte unit lane & 7
+            const size_t p = (size_t)b * n + min(p0 + wave * 8 + (lane >> 3), n - 1);
+            __builtin_amdgcn_global_load_lds(xn + p * 64 + (lane & 7) * 8, (__attribute__((address_space(3))) void*)(xt + wave * 1024), 16, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -377,12 +399,67 @@ __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restr
             qo[g] = make_uint2(f2bf2(acc[4 * g] * inv_n, acc[4 * g + 1] * inv_n), f2bf2(acc[4 * g + 2] * inv_n, acc[4 * g + 3] * inv_n));
         lc_store_head((bf16_t*)row + 256 + h * 32, qo, half, true);
         __syncthreads();
-        // copy-out: 32 pixels x 48 units of dqkv, consecutive lanes = consecutive 16-byte units (pixel rows are contiguous)
+        if constexpr (!FUSE) {
+            // copy-out: 32 pixels x 48 units of dqkv, consecutive lanes = consecutive 16-byte units (pixel rows are contiguous)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int id = tid + k * 256, px = id / 48, u = id - px * 48;
-            if (p0 + px < n) *(u32x4*)(dqkv + ((size_t)b * n + p0 + px) * 384 + u * 8) = *(const u32x4*)(st + px * LB_PITCH + u * 16);
+            for (int k = 0; k < 6; ++k) {
+                const int id = tid + k * 256, px = id / 48, u = id - px * 48;
+                if (p0 + px < n) *(u32x4*)(dqkv + ((size_t)b * n + p0 + px) * 384 + u * 8) = *(const u32x4*)(st + px * LB_PITCH + u * 16);
+            }
+        } else {
+            // pixels past the end of the sample carry the clamped last row: they must not reach dW (dxn rows are simply not stored)
+            if (p0 + 32 > n) {
+                for (int id = tid; id < 32 * 48; id += 256) {
+                    const int px = id / 48, u = id - px * 48;
+                    if (p0 + px >= n) *(u32x4*)(st + px * LB_PITCH + u * 16) = u32x4{0u, 0u, 0u, 0u};
+                }
+                __syncthreads();
+            }
+            // ---- dW += xn^T dqkv: rows = ci, cols = co; k = pixel (two k-steps of 16)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 xf[2], yf[3];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) xf[a] = tr_frag(xt + (ks * 16) * 128 + a * 64, 128, lane);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) yf[j] = tr_frag(st + (ks * 16) * LB_PITCH + (wave * 96 + j * 32) * 2, LB_PITCH, lane);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) wacc[a][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a], yf[j], wacc[a][j], 0, 0, 0);
+            }
+            // ---- dxn = W^T dqkv: rows = ci (block `wave`), cols = pixel; k = the 384 qkv channels
+            if (wave < 2) {
+                f32x16 dacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dacc[r] = 0.0f;
+                const bf16_t* wrow = wt + ((size_t)half * 64 + wave * 32 + l31) * 8;
+                const unsigned char* drow = st + l31 * LB_PITCH + half * 16;
+#pragma unroll 6
+                for (int ks = 0; ks < 24; ++ks) {
+                    const bf16x8 wf = *(const bf16x8*)(wrow + (size_t)ks * 2 * 64 * 8);
+                    const bf16x8 df = *(const bf16x8*)(drow + ks * 32);
+                    dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, df, dacc, 0, 0, 0);
+                }
+                uint2 qd[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) qd[g] = make_uint2(f2bf2(dacc[4 * g], dacc[4 * g + 1]), f2bf2(dacc[4 * g + 2], dacc[4 * g + 3]));
+                lc_store_head(dxn + ((size_t)b * n + min(p0 + l31, n - 1)) * 64 + wave * 32, qd, half, p0 + l31 < n);
+            }
         }
+    }
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float* d = dw + ((size_t)a * 32) * 384 + wave * 96 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    atomicAdd(d + (size_t)ci * 384, wacc[a][j][r]);
+                }
+            }
     }
 }
 
@@ -440,7 +517,7 @@ int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_
 size_t la_bwd_workspace_floats(int B, int n) { return (size_t)B * 4 * ((size_t)la_parts(B, n) * 1024 + 1024 + 32); }
 
 int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const float* ctx, const float* ml, bf16_t* dqkv, float* workspace, int B, int n,
-                                hipStream_t s) {
+                                hipStream_t s, const bf16_t* xn, const bf16_t* wt, float* dw, bf16_t* dxn) {
     int nparts, span;
     lc_parts(B, n, nparts, span);
     float* partial = workspace;
@@ -451,8 +528,17 @@ int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const flo
     int gx = cdiv(n, 32);
     if (gx > 2048) gx = 2048;
     static bool attr = false;
-    if (!attr) { OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS)); attr = true; }
-    lc_bwd_apply_kernel<<<dim3(gx, B), 256, LB_LDS, s>>>(qkv, dout, ctx, dctx, ml, S, dqkv, n);
+    if (!attr) {
+        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS));
+        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_FUSE));
+        attr = true;
+    }
+    if (xn) {       // 64-channel block: the to_qkv backward fused in; fewer, longer-lived workgroups (each adds a 64 x 384 dW tile with atomics)
+        if (gx > 512) gx = 512;
+        lc_bwd_apply_kernel<true><<<dim3(gx, B), 256, LB_LDS_FUSE, s>>>(qkv, dout, ctx, dctx, ml, S, nullptr, n, xn, wt, dw, dxn);
+    } else {
+        lc_bwd_apply_kernel<false><<<dim3(gx, B), 256, LB_LDS, s>>>(qkv, dout, ctx, dctx, ml, S, dqkv, n, nullptr, nullptr, nullptr, nullptr);
+    }
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

@@ -210,14 +210,16 @@ static void resblock_backward(Bwd& b, const TapeRec& r, float* dss, float* dts) 
     scatter_to_sources(b, D, r.srcs);
 }
 
-static void attn_tail_backward(Bwd& b, const TapeRec& r, const std::string& qkv_prefix, const std::string& norm_g, const bf16_t* dy) {
-    // shared by both attention blocks: to_qkv conv backward, then PreNorm's LayerNorm, x.g (+)= dy + LN'(dxn)
+static void attn_tail_backward(Bwd& b, const TapeRec& r, const std::string& qkv_prefix, const std::string& norm_g, const bf16_t* dy,
+                               const Tensor* dxn_done = nullptr) {
+    // shared by both attention blocks: to_qkv conv backward (unless the core backward has done it: dxn_done), then PreNorm's LayerNorm,
+    // x.g (+)= dy + LN'(dxn)
     Ctx& c = b.c;
     ofd_unet* u = c.u;
     const int H = r.x.H, W = r.x.W, C = r.x.C;
     const size_t npix = (size_t)c.B * H * W;
     SrcSpec sx; sx.t = r.xn;
-    Tensor Dx = conv_backward(b, qkv_prefix, {sx}, r.qkv.g, H, W, true, nullptr);
+    Tensor Dx = dxn_done ? *dxn_done : conv_backward(b, qkv_prefix, {sx}, r.qkv.g, H, W, true, nullptr);
     if (c.rc != OFD_OK) return;
     c.begin(PC_LN, 0, (double)npix * C * 10, r.name + " prenorm bwd");
     RUN(k_layernorm_c_bwd(r.x.p, u->P(norm_g), Dx.p, r.x.g, u->G(norm_g), npix, C, site_eps(u, r.name + ".fn.norm"), b.has(r.x) ? 1 : 0, c.s, dy));
@@ -241,6 +243,20 @@ static void linattn_backward(Bwd& b, const TapeRec& r) {
     SrcSpec sao; sao.t = r.ao;
     Tensor Dao = conv_backward(b, name + ".fn.fn.to_out.0", {sao}, r.o2.g, H, W, true, nullptr);
     if (c.rc != OFD_OK) return;
+    static const int fuse_qkv = getenv("OFD_LA_BWD_FUSE_QKV") ? atoi(getenv("OFD_LA_BWD_FUSE_QKV")) : 1;
+    if (C == 64 && fuse_qkv) {
+        // the to_qkv backward rides on the core backward's dqkv tile (la_core.hip lc_bwd_apply_kernel<true>): no dqkv tensor
+        const ConvDesc& d = u->convs[u->cindex.at(name + ".fn.fn.to_qkv")];
+        float* acc = u->d_wacc + d.w_off;
+        Tensor Dx = b.stmp(C, H, W);
+        if (c.rc != OFD_OK) return;
+        c.begin(PC_LABWD, npix * (4.0 * 4 * 32 * 32 * 2 + 4.0 * 384 * 64), (double)npix * (384 + 128 + 64 + 64) * 2, name + " core + to_qkv bwd");
+        RUN(k_linear_attention_core_bwd(r.qkv.p, Dao.p, r.ctx, r.ml, nullptr, ws, B, n, c.s, r.xn.p, u->d_wtbuf + d.w_off, acc, Dx.p));
+        RUN(k_wgrad_finish(acc, u->P(d.wname), u->G(d.wname), d.Cout, d.Cin, d.Cin_pad, d.ksize, d.ws_eps, d.unshuffle, 0, c.s));
+        c.end();
+        attn_tail_backward(b, r, name + ".fn.fn.to_qkv", name + ".fn.norm.g", dy, &Dx);
+        return;
+    }
     c.begin(PC_LABWD, npix * 4.0 * 4 * 32 * 32 * 2, (double)npix * (384 * 2 + 128) * 2, name + " core bwd");
     RUN(k_linear_attention_core_bwd(r.qkv.p, Dao.p, r.ctx, r.ml, r.qkv.g, ws, B, n, c.s));
     c.end();
