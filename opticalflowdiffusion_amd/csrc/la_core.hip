@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __re
 //   dv     = dctx^T . k / n                                               (MFMA rows e, A = dctx^T)
 constexpr int LB_PITCH = 1024 + 16;       // qkv row (768 B) | dout row (256 B) | pad
 constexpr int LB_LDS = 3 * 4 * 32 * 80 + 3 * 128 * 4 + 32 * LB_PITCH;
-constexpr int LB_LDS_FUSE = LB_LDS + 32 * 128;      // + the xn tile [32 pixels][64 channels]
+constexpr int LB_LDS_FUSE = LB_LDS + 32 * 128 + 2 * 16 * 64 * 4;      // + the xn tile [32 pixels][64 channels] + the data-gradient partial tiles of waves 2, 3
 // FUSE (C = 64): the backward of the to_qkv 1x1 conv (DD:222) is done here, on the dqkv tile while it is in LDS -- dxn = W^T dqkv
 // (waves 0, 1: one 32-channel block each, 24 k-steps over the 384 qkv channels; A fragments = the data-gradient weights [48][64][8]
 // from L2) and dW[ci][co] += xn^T dqkv (all waves: 64 ci x 96 co each, contraction over the 32 pixels through transposing LDS reads,
@@ -428,23 +428,35 @@ __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restr
 #pragma unroll
                     for (int j = 0; j < 3; ++j) wacc[a][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a], yf[j], wacc[a][j], 0, 0, 0);
             }
-            // ---- dxn = W^T dqkv: rows = ci (block `wave`), cols = pixel; k = the 384 qkv channels
-            if (wave < 2) {
+            // ---- dxn = W^T dqkv: rows = ci (block wave & 1), cols = pixel; k = the 384 qkv channels, split between the wave pairs
+            //      (waves 2, 3 take k-steps 12..23 and hand their partial tile to waves 0, 1 through LDS)
+            {
+                const int mt = wave & 1, kh = wave >> 1;
                 f32x16 dacc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dacc[r] = 0.0f;
-                const bf16_t* wrow = wt + ((size_t)half * 64 + wave * 32 + l31) * 8;
-                const unsigned char* drow = st + l31 * LB_PITCH + half * 16;
-#pragma unroll 6
-                for (int ks = 0; ks < 24; ++ks) {
+                const bf16_t* wrow = wt + ((size_t)(kh * 24 + half) * 64 + mt * 32 + l31) * 8;
+                const unsigned char* drow = st + l31 * LB_PITCH + half * 16 + kh * 12 * 32;
+#pragma unroll
+                for (int ks = 0; ks < 12; ++ks) {
                     const bf16x8 wf = *(const bf16x8*)(wrow + (size_t)ks * 2 * 64 * 8);
                     const bf16x8 df = *(const bf16x8*)(drow + ks * 32);
                     dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, df, dacc, 0, 0, 0);
                 }
-                uint2 qd[4];
+                float* part = (float*)(xt + 32 * 128) + (size_t)mt * 16 * 64;        // [m-tile][register][lane]
+                if (kh == 1) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) qd[g] = make_uint2(f2bf2(dacc[4 * g], dacc[4 * g + 1]), f2bf2(dacc[4 * g + 2], dacc[4 * g + 3]));
-                lc_store_head(dxn + ((size_t)b * n + min(p0 + l31, n - 1)) * 64 + wave * 32, qd, half, p0 + l31 < n);
+                    for (int r = 0; r < 16; ++r) part[r * 64 + lane] = dacc[r];
+                }
+                __syncthreads();
+                if (kh == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dacc[r] += part[r * 64 + lane];
+                    uint2 qd[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) qd[g] = make_uint2(f2bf2(dacc[4 * g], dacc[4 * g + 1]), f2bf2(dacc[4 * g + 2], dacc[4 * g + 3]));
+                    lc_store_head(dxn + ((size_t)b * n + min(p0 + l31, n - 1)) * 64 + mt * 32, qd, half, p0 + l31 < n);
+                }
             }
         }
     }
