@@ -41,7 +41,8 @@ int k_gn_finalize(const float* partial, int B, int H, int W, int C, const float*
 int k_resblock_out(const bf16_t* h, const float* a, const float* sft, const bf16_t* x, bf16_t* out, int B, int H, int W, int C, hipStream_t s);
 int k_layernorm_c(const bf16_t* x, const float* g, const bf16_t* res, bf16_t* out, size_t npix, int C, float eps, hipStream_t s);
 int la_parts(int B, int n);
-int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s, float* ml_out = nullptr);
+int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s, float* ml_out = nullptr,
+                            const bf16_t* wo = nullptr, const float* bo = nullptr, bf16_t* o2 = nullptr, int C = 0);
 int la_fused_blocks(int n);
 int k_la_weight_prep(const float* wqkv, const float* g, const float* wout, bf16_t* wq, bf16_t* wkv, bf16_t* woutp, int C, hipStream_t s);
 int k_linear_attention_fused(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const bf16_t* woutp, const float* bias, const float* g2,

@@ -162,11 +162,25 @@ __device__ __forceinline__ bf16x8 lc_afrag(const unsigned char* lds, int h, int 
 // consecutive 16-byte units of consecutive pixels.  Reading operand fragments straight from global memory (32 bytes per
 // pixel and instruction) ran at ~2.8 TB/s; a padded row pitch keeps the lane-per-pixel LDS reads conflict-free.
 constexpr int LO_PITCH = 256 + 16;        // q part of a pixel row (128 channels) + pad
-__global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ ctx, bf16_t* __restrict__ out, int n) {
+// wo != nullptr (C = 64 or 128): the to_out.0 1x1 conv (DD:225) rides on the head-output tile while it is in LDS -- o2 = Wo ao + bo, wave w
+// owns the 32-channel block w of o2 and keeps its eight A fragments (128 input channels) in registers for the whole launch.  The
+// separate conv launch and its read of ao (1.85 GB at full resolution) go away; ao itself is still written (the backward's to_out
+// weight gradient reads it).
+__global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ ctx, bf16_t* __restrict__ out, int n,
+                                                     const bf16_t* __restrict__ wo, const float* __restrict__ bo, bf16_t* __restrict__ o2, int C) {
     __shared__ __attribute__((aligned(16))) unsigned char ct[4 * 32 * 80];      // ctx^T: rows e, k = d
     __shared__ __attribute__((aligned(16))) unsigned char st[32 * LO_PITCH];    // q rows in, out rows out
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5, b = blockIdx.y;
     lc_stage_matrix(ct, ctx + (size_t)b * 4096, true, tid);
+    const bool proj = wo != nullptr && wave * 32 < C;       // this wave computes a block of o2
+    bf16x8 wof[8];
+    float4 bo4[4];
+    if (proj) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) wof[ks] = *(const bf16x8*)(wo + ((size_t)(ks * 2 + half) * C + wave * 32 + l31) * 8);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bo4[g] = bo ? *(const float4*)(bo + wave * 32 + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const int h = wave;                    // wave = head; the four waves of a workgroup share a 32-pixel tile
     for (int p0 = blockIdx.x * 32; p0 < n; p0 += gridDim.x * 32) {
         __syncthreads();                   // previous tile's copy-out is done (and, first time, ct is staged)
@@ -210,6 +224,19 @@ __global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ 
         for (int k = 0; k < 2; ++k) {
             const int id = tid + k * 256, px = id >> 4, u = id & 15;
             if (p0 + px < n) *(u32x4*)(out + ((size_t)b * n + p0 + px) * 128 + u * 8) = *(const u32x4*)(st + px * LO_PITCH + u * 16);
+        }
+        if (proj) {                        // o2 block of this wave: rows = channel, cols = pixel, k = the 128 head-output channels
+            f32x16 pa;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pa[r] = 0.0f;
+            const unsigned char* arow = st + l31 * LO_PITCH + half * 16;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[ks], *(const bf16x8*)(arow + ks * 32), pa, 0, 0, 0);
+            uint2 po[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                po[g] = make_uint2(f2bf2(pa[4 * g] + bo4[g].x, pa[4 * g + 1] + bo4[g].y), f2bf2(pa[4 * g + 2] + bo4[g].z, pa[4 * g + 3] + bo4[g].w));
+            lc_store_head(o2 + ((size_t)b * n + min(p0 + l31, n - 1)) * C + wave * 32, po, half, p0 + l31 < n);
         }
     }
 }
@@ -514,14 +541,15 @@ int la_parts(int B, int n) { int np, sp; lc_parts(B, n, np, sp); return np; }
 
 void launch_la_ctx_combine(const float* partial, float* ctx, int B, int nparts, float inv_n, float* ml_out, hipStream_t s);   // blocks.hip
 
-int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s, float* ml_out) {
+int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s, float* ml_out,
+                            const bf16_t* wo, const float* bo, bf16_t* o2, int C) {
     int nparts, span;
     lc_parts(B, n, nparts, span);
     lc_ctx_partial_kernel<<<dim3(nparts, B), 256, 0, s>>>(qkv, partial, n, span, nparts);
     launch_la_ctx_combine(partial, ctx, B, nparts, 1.0f / (float)n, ml_out, s);
     int gx = cdiv(n, 32);
     if (gx > 2048) gx = 2048;
-    lc_out_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, ctx, out, n);
+    lc_out_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, ctx, out, n, wo, bo, o2, C);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

@@ -234,10 +234,17 @@ static Tensor linattn(Ctx& c, const std::string& name, Tensor x) {
     SrcSpec s; s.t = xn;
     conv(c, name + ".fn.fn.to_qkv", {s}, qkv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     c.begin(PC_LINATTN, 4.0 * npix * 4 * 32 * 32, (double)npix * (384 + 128 + 128) * 2);
-    RUN(k_linear_attention_core(qkv.p, partial, ctx, ao.p, B, n, c.s, ml));
-    c.end();
-    SrcSpec s2; s2.t = ao;
-    conv(c, name + ".fn.fn.to_out.0", {s2}, o2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    static const int fuse_out = getenv("OFD_LA_FUSE_TO_OUT") ? atoi(getenv("OFD_LA_FUSE_TO_OUT")) : 1;
+    if (C <= 128 && fuse_out) {     // to_out.0 rides on the head-output tile of the core's second pass (la_core.hip lc_out_kernel)
+        const ConvDesc& d = u->convs[u->cindex.at(name + ".fn.fn.to_out.0")];
+        RUN(k_linear_attention_core(qkv.p, partial, ctx, ao.p, B, n, c.s, ml, u->d_wbuf + d.w_off, u->P(name + ".fn.fn.to_out.0.bias"), o2.p, C));
+        c.end();
+    } else {
+        RUN(k_linear_attention_core(qkv.p, partial, ctx, ao.p, B, n, c.s, ml));
+        c.end();
+        SrcSpec s2; s2.t = ao;
+        conv(c, name + ".fn.fn.to_out.0", {s2}, o2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    }
     c.begin(PC_LN, 0, (double)npix * C * 6);
     RUN(k_layernorm_c(o2.p, u->P(name + ".fn.fn.to_out.1.g"), x.p, y.p, npix, C, site_eps(u, name + ".fn.fn.to_out.1"), c.s));
     c.end();
