@@ -242,16 +242,20 @@ __global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ 
 }
 
 // ---- backward pass 1: dctx[d][e] = sum_n qs[n][d] * dout[n][e]; partial per (sample*head, part); grid (nparts, B)
+// FD (C = 64): `dout` is do2 [pixel][64], the gradient of the to_out.0 OUTPUT -- dout = Wo^T do2 is never formed: since
+// dctx = sum_n qs (x) (Wo^T do2) = (sum_n qs (x) do2) Wo, the pixel reduction runs on do2 (partial [32 d][64 c] per head and part) and the
+// 64 x 32 product with Wo is left to the combine kernel.
+template <bool FD>
 __global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, float* __restrict__ partial,
                                                               int n, int span, int nparts) {
     __shared__ __attribute__((aligned(16))) unsigned char qs[LC_CH * 256];     // softmax_d(q) * scale, bf16, pixel-major
-    __shared__ __attribute__((aligned(16))) unsigned char gs[LC_CH * 256];     // dout
+    __shared__ __attribute__((aligned(16))) unsigned char gs[LC_CH * (FD ? 128 : 256)];     // dout | do2
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int part = blockIdx.x, b = blockIdx.y;
     const int n_begin = part * span, n_end = min(n, n_begin + span);
-    f32x16 acc;
+    f32x16 acc, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc1[r] = 0.0f; }
     for (int c0 = n_begin; c0 < n_end; c0 += LC_CH) {
         const int cnt = min(LC_CH, n_end - c0);
         __syncthreads();
@@ -264,8 +268,14 @@ __global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __re
             float q[16];
             lc_unpack8(*(const u32x4*)(qkv + pix * 384 + hh * 32 + hf * 16), &q[0]);
             lc_unpack8(*(const u32x4*)(qkv + pix * 384 + hh * 32 + hf * 16 + 8), &q[8]);
-            u32x4 g0 = *(const u32x4*)(dout + pix * 128 + hh * 32 + hf * 16);
-            u32x4 g1 = *(const u32x4*)(dout + pix * 128 + hh * 32 + hf * 16 + 8);
+            u32x4 g0, g1;
+            if constexpr (FD) {
+                g0 = *(const u32x4*)(dout + pix * 64 + (hh * 2 + hf) * 8);       // 8 items per pixel: one 16-byte unit of the do2 row each
+                g1 = g0;
+            } else {
+                g0 = *(const u32x4*)(dout + pix * 128 + hh * 32 + hf * 16);
+                g1 = *(const u32x4*)(dout + pix * 128 + hh * 32 + hf * 16 + 8);
+            }
             float mx = q[0];
 #pragma unroll
             for (int j = 1; j < 16; ++j) mx = fmaxf(mx, q[j]);
@@ -283,20 +293,38 @@ __global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __re
             }
             *(u32x4*)(qs + p * 256 + hh * 64 + hf * 32) = lc_pack8(&q[0]);
             *(u32x4*)(qs + p * 256 + hh * 64 + hf * 32 + 16) = lc_pack8(&q[8]);
-            *(u32x4*)(gs + p * 256 + hh * 64 + hf * 32) = g0;
-            *(u32x4*)(gs + p * 256 + hh * 64 + hf * 32 + 16) = g1;
+            if constexpr (FD) {
+                *(u32x4*)(gs + p * 128 + (hh * 2 + hf) * 16) = g0;
+            } else {
+                *(u32x4*)(gs + p * 256 + hh * 64 + hf * 32) = g0;
+                *(u32x4*)(gs + p * 256 + hh * 64 + hf * 32 + 16) = g1;
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int sl = 0; sl < LC_CH / 16; ++sl) {
             const bf16x8 qf = tr_frag(qs + sl * 16 * 256 + wave * 64, 256, lane);      // rows = d
-            const bf16x8 gf = tr_frag(gs + sl * 16 * 256 + wave * 64, 256, lane);      // cols = e
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, gf, acc, 0, 0, 0);
+            if constexpr (FD) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, tr_frag(gs + sl * 16 * 128, 128, lane), acc, 0, 0, 0);          // cols = c 0..31
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, tr_frag(gs + sl * 16 * 128 + 64, 128, lane), acc1, 0, 0, 0);   // cols = c 32..63
+            } else {
+                const bf16x8 gf = tr_frag(gs + sl * 16 * 256 + wave * 64, 256, lane);      // cols = e
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, gf, acc, 0, 0, 0);
+            }
         }
     }
-    float* o = partial + ((size_t)(b * 4 + wave) * nparts + part) * 1024;
+    if constexpr (FD) {
+        float* o = partial + ((size_t)(b * 4 + wave) * nparts + part) * 2048;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[r];
+        for (int r = 0; r < 16; ++r) {
+            o[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + l31] = acc[r];
+            o[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + 32 + l31] = acc1[r];
+        }
+    } else {
+        float* o = partial + ((size_t)(b * 4 + wave) * nparts + part) * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[r];
+    }
 }
 
 // ---- backward pass 2: per pixel; grid (gx, B) -----------------------------------------------------------
@@ -311,11 +339,11 @@ constexpr int LB_LDS_FUSE = LB_LDS + 32 * 128 + 2 * 16 * 64 * 4;      // + the x
 // from L2) and dW[ci][co] += xn^T dqkv (all waves: 64 ci x 96 co each, contraction over the 32 pixels through transposing LDS reads,
 // accumulated in registers over the whole launch, added to `dw` with atomics at the end).  The 5.5 GB dqkv tensor of a full-resolution
 // block is then never written, nor read twice by the two 1x1 backward kernels: 25.8 GB -> 9.2 GB of traffic for the three steps.
-template <bool FUSE>
-__global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ ctx,
+template <bool FUSE, bool FD>      // FD (with FUSE): `dout` is do2 [pixel][64]; dout = Wo^T do2 is formed per tile and head (wot: [8][128][8])
+__global__ void __launch_bounds__(256, 2) lc_bwd_apply_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ ctx,
                                                            const float* __restrict__ dctx, const float* __restrict__ ml, const float* __restrict__ S,
                                                            bf16_t* __restrict__ dqkv, int n, const bf16_t* __restrict__ xn, const bf16_t* __restrict__ wt,
-                                                           float* __restrict__ dw, bf16_t* __restrict__ dxn) {
+                                                           float* __restrict__ dw, bf16_t* __restrict__ dxn, const bf16_t* __restrict__ wot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
     unsigned char* cA = lb_smem;
     unsigned char* dA = cA + 4 * 32 * 80;
@@ -345,13 +373,28 @@ __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restr
     }
     const float inv_n = 1.0f / (float)n;
     const int h = wave;                    // wave = head; the four waves of a workgroup share a 32-pixel tile
+    unsigned char* d2t = xt + 32 * 128;    // FD: do2 tile [32 pixels][128 B] (the region the data-gradient partials use at the END of a tile)
     for (int p0 = blockIdx.x * 32; p0 < n; p0 += gridDim.x * 32) {
+        // FD: this head's A fragments of Wo^T (rows e = 32 h .., k = the 64 channels of do2): re-read from L2 per tile (64 bytes per lane, in
+        // flight with the tile's DMA) -- held for the whole launch they push the kernel past 256 registers, i.e. to one wave per SIMD
+        bf16x8 wof[FD ? 4 : 1];
+        if constexpr (FD) {
+            asm volatile("" ::: "memory");     // (keeps the loop-invariant loads below inside the loop)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wof[ks] = *(const bf16x8*)(wot + ((size_t)(ks * 2 + half) * 128 + h * 32 + l31) * 8);
+        }
         __syncthreads();                   // previous tile's copy-out is done (and, first time, the matrices are staged)
         // one direct global->LDS instruction per pixel row: lanes 0..47 fetch the qkv row, lanes 48..63 the dout row
         for (int px = wave; px < 32; px += 4) {
             const size_t p = (size_t)b * n + min(p0 + px, n - 1);
-            const bf16_t* src = lane < 48 ? qkv + p * 384 + lane * 8 : dout + p * 128 + (lane - 48) * 8;
+            const bf16_t* src;
+            if constexpr (FD) src = lane < 48 ? qkv + p * 384 + lane * 8 : qkv + p * 384 + (lane - 48) * 8;     // (lanes 48..63: filler, overwritten by dout below)
+            else src = lane < 48 ? qkv + p * 384 + lane * 8 : dout + p * 128 + (lane - 48) * 8;
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(st + px * LB_PITCH), 16, 0, 0);
+        }
+        if constexpr (FD) {                // do2 rows 8 wave .. 8 wave + 7: lane -> row lane >> 3, 16-byte unit lane & 7
+            const size_t p = (size_t)b * n + min(p0 + wave * 8 + (lane >> 3), n - 1);
+            __builtin_amdgcn_global_load_lds(dout + p * 64 + (lane & 7) * 8, (__attribute__((address_space(3))) void*)(d2t + wave * 1024), 16, 0, 0);
         }
         if constexpr (FUSE) {              // xn rows 8 wave .. 8 wave + 7 of the tile: lane -> row lane >> 3, 16-byte unit lane & 7
             const size_t p = (size_t)b * n + min(p0 + wave * 8 + (lane >> 3), n - 1);
@@ -360,6 +403,18 @@ __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned char* row = st + l31 * LB_PITCH;
+        if constexpr (FD) {                // dout of this head = Wo^T do2: rows e, cols pixel; written to the tile where the loaded dout would be
+            f32x16 da;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) da[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wof[ks], *(const bf16x8*)(d2t + l31 * 128 + (ks * 16 + half * 8) * 2), da, 0, 0, 0);
+            uint2 dq4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dq4[g] = make_uint2(f2bf2(da[4 * g], da[4 * g + 1]), f2bf2(da[4 * g + 2], da[4 * g + 3]));
+            lc_store_head((bf16_t*)row + 384 + h * 32, dq4, half, true);        // (read back below by the same wave: LDS is in order per wave)
+        }
         // everything this wave needs of its head, before any of it is overwritten
         const bf16x8 g0 = *(const bf16x8*)(row + 768 + (h * 32 + half * 8) * 2), g1 = *(const bf16x8*)(row + 768 + (h * 32 + 16 + half * 8) * 2);
         const bf16x8 v0 = *(const bf16x8*)(row + 512 + (h * 32 + half * 8) * 2), v1 = *(const bf16x8*)(row + 512 + (h * 32 + 16 + half * 8) * 2);
@@ -503,22 +558,40 @@ __global__ void __launch_bounds__(256) lc_bwd_apply_kernel(const bf16_t* __restr
 }
 
 // combine of backward pass 1 (also used by the forward's la_ctx_combine in blocks.hip for the ctx partials)
+// wo != nullptr (lc_dctx_partial_kernel<true>): the partials are QD[32 d][64 c] = sum_n qs (x) do2; dctx[d][e] = sum_c QD[d][c] Wo[c][h 32 + e]
+// with Wo the prepared to_out.0 weights ([16 e-octets][64 c][8], bf16 -- the values the separate data-gradient conv multiplied by)
 __global__ void __launch_bounds__(256) lc_bwd_combine_kernel(const float* __restrict__ partial, const float* __restrict__ ctx, float* __restrict__ dctx,
-                                                             float* __restrict__ S, int nparts) {
+                                                             float* __restrict__ S, int nparts, const bf16_t* __restrict__ wo) {
     __shared__ float prod[1024];
-    const int tid = threadIdx.x, bh = blockIdx.x;
-    for (int i = tid; i < 1024; i += 256) {
+    __shared__ float qd[2048];
+    const int tid = threadIdx.x, bh = blockIdx.x, h = bh & 3;
+    const int per = wo ? 2048 : 1024;
+    for (int i = tid; i < per; i += 256) {
         float a = 0.0f;
         for (int c0 = 0; c0 < nparts; c0 += 8) {        // eight loads in flight; the sum stays in part order
             float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = partial[((size_t)bh * nparts + min(c0 + k, nparts - 1)) * 1024 + i];
+            for (int k = 0; k < 8; ++k) v[k] = partial[((size_t)bh * nparts + min(c0 + k, nparts - 1)) * per + i];
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (c0 + k < nparts) a += v[k];
         }
-        dctx[(size_t)bh * 1024 + i] = a;
-        prod[i] = a * ctx[(size_t)bh * 1024 + i];
+        if (wo) {
+            qd[i] = a;
+        } else {
+            dctx[(size_t)bh * 1024 + i] = a;
+            prod[i] = a * ctx[(size_t)bh * 1024 + i];
+        }
+    }
+    if (wo) {
+        __syncthreads();
+        for (int i = tid; i < 1024; i += 256) {
+            const int d = i >> 5, e = h * 32 + (i & 31);
+            float a = 0.0f;
+            for (int c = 0; c < 64; ++c) a += qd[d * 64 + c] * bf2f(wo[((size_t)(e >> 3) * 64 + c) * 8 + (e & 7)]);
+            dctx[(size_t)bh * 1024 + i] = a;
+            prod[i] = a * ctx[(size_t)bh * 1024 + i];
+        }
     }
     __syncthreads();
     if (tid < 32) {
@@ -554,30 +627,35 @@ int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_
     return OFD_OK;
 }
 
-size_t la_bwd_workspace_floats(int B, int n) { return (size_t)B * 4 * ((size_t)la_parts(B, n) * 1024 + 1024 + 32); }
+size_t la_bwd_workspace_floats(int B, int n) { return (size_t)B * 4 * ((size_t)la_parts(B, n) * 2048 + 1024 + 32); }      // (2048: the [32][64] partials of the do2 form)
 
 int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const float* ctx, const float* ml, bf16_t* dqkv, float* workspace, int B, int n,
-                                hipStream_t s, const bf16_t* xn, const bf16_t* wt, float* dw, bf16_t* dxn) {
+                                hipStream_t s, const bf16_t* xn, const bf16_t* wt, float* dw, bf16_t* dxn, const bf16_t* wo_fwd, const bf16_t* wo_t) {
+    // wo_fwd / wo_t != nullptr (only with xn): `dout` is do2 [pixel][64], the gradient of the to_out.0 output (see lc_dctx_partial_kernel<true>)
+    const bool fd = wo_fwd != nullptr && wo_t != nullptr && xn != nullptr;
     int nparts, span;
     lc_parts(B, n, nparts, span);
     float* partial = workspace;
-    float* dctx = partial + (size_t)B * 4 * nparts * 1024;
+    float* dctx = partial + (size_t)B * 4 * nparts * (fd ? 2048 : 1024);
     float* S = dctx + (size_t)B * 4 * 1024;
-    lc_dctx_partial_kernel<<<dim3(nparts, B), 256, 0, s>>>(qkv, dout, partial, n, span, nparts);
-    lc_bwd_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, dctx, S, nparts);
+    if (fd) lc_dctx_partial_kernel<true><<<dim3(nparts, B), 256, 0, s>>>(qkv, dout, partial, n, span, nparts);
+    else lc_dctx_partial_kernel<false><<<dim3(nparts, B), 256, 0, s>>>(qkv, dout, partial, n, span, nparts);
+    lc_bwd_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, dctx, S, nparts, fd ? wo_fwd : nullptr);
     int gx = cdiv(n, 32);
     if (gx > 2048) gx = 2048;
     static bool attr = false;
     if (!attr) {
-        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS));
-        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_FUSE));
+        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS));
+        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_FUSE));
+        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_FUSE));
         attr = true;
     }
     if (xn) {       // 64-channel block: the to_qkv backward fused in; fewer, longer-lived workgroups (each adds a 64 x 384 dW tile with atomics)
         if (gx > 512) gx = 512;
-        lc_bwd_apply_kernel<true><<<dim3(gx, B), 256, LB_LDS_FUSE, s>>>(qkv, dout, ctx, dctx, ml, S, nullptr, n, xn, wt, dw, dxn);
+        if (fd) lc_bwd_apply_kernel<true, true><<<dim3(gx, B), 256, LB_LDS_FUSE, s>>>(qkv, dout, ctx, dctx, ml, S, nullptr, n, xn, wt, dw, dxn, wo_t);
+        else lc_bwd_apply_kernel<true, false><<<dim3(gx, B), 256, LB_LDS_FUSE, s>>>(qkv, dout, ctx, dctx, ml, S, nullptr, n, xn, wt, dw, dxn, nullptr);
     } else {
-        lc_bwd_apply_kernel<false><<<dim3(gx, B), 256, LB_LDS, s>>>(qkv, dout, ctx, dctx, ml, S, dqkv, n, nullptr, nullptr, nullptr, nullptr);
+        lc_bwd_apply_kernel<false, false><<<dim3(gx, B), 256, LB_LDS, s>>>(qkv, dout, ctx, dctx, ml, S, dqkv, n, nullptr, nullptr, nullptr, nullptr, nullptr);
     }
     OFD_LAUNCH_CHECK();
     return OFD_OK;
