@@ -72,7 +72,7 @@ int k_grad_add(bf16_t* dst, const bf16_t* src, size_t elems, int accumulate, hip
 size_t la_bwd_workspace_floats(int B, int n);
 int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const float* ctx, const float* ml, bf16_t* dqkv, float* workspace, int B, int n,
                                 hipStream_t s, const bf16_t* xn = nullptr, const bf16_t* wt = nullptr, float* dw = nullptr, bf16_t* dxn = nullptr,
-                                const bf16_t* wo_fwd = nullptr, const bf16_t* wo_t = nullptr);
+                                const bf16_t* wo_fwd = nullptr, const bf16_t* wo_t = nullptr, float* dwo = nullptr, float* dbo = nullptr);
 int k_flash_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, bf16_t* dqkv, float* delta, int B, int n,
                           hipStream_t s);
 

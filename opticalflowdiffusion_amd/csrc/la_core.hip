@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ 
 // 64 x 32 product with Wo is left to the combine kernel.
 template <bool FD>
 __global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, float* __restrict__ partial,
-                                                              int n, int span, int nparts) {
+                                                              int n, int span, int nparts, float* __restrict__ dbias) {
     __shared__ __attribute__((aligned(16))) unsigned char qs[LC_CH * 256];     // softmax_d(q) * scale, bf16, pixel-major
     __shared__ __attribute__((aligned(16))) unsigned char gs[LC_CH * (FD ? 128 : 256)];     // dout | do2
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __re
     f32x16 acc, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc1[r] = 0.0f; }
+    float bsum = 0.0f;                     // FD: column sums of do2 = the to_out.0 bias gradient (thread -> channel tid & 63, pixels (tid >> 6) * 32 .. + 31)
     for (int c0 = n_begin; c0 < n_end; c0 += LC_CH) {
         const int cnt = min(LC_CH, n_end - c0);
         __syncthreads();
@@ -301,6 +302,12 @@ __global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __re
             }
         }
         __syncthreads();
+        if constexpr (FD) {
+            if (dbias) {
+#pragma unroll 8
+                for (int p = (tid >> 6) * 32; p < (tid >> 6) * 32 + 32; ++p) bsum += bf2f(*(const bf16_t*)(gs + p * 128 + (tid & 63) * 2));
+            }
+        }
 #pragma unroll
         for (int sl = 0; sl < LC_CH / 16; ++sl) {
             const bf16x8 qf = tr_frag(qs + sl * 16 * 256 + wave * 64, 256, lane);      // rows = d
@@ -314,6 +321,7 @@ __global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __re
         }
     }
     if constexpr (FD) {
+        if (dbias) atomicAdd(dbias + (tid & 63), bsum);
         float* o = partial + ((size_t)(b * 4 + wave) * nparts + part) * 2048;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -561,7 +569,7 @@ __global__ void __launch_bounds__(256, 2) lc_bwd_apply_kernel(const bf16_t* __re
 // wo != nullptr (lc_dctx_partial_kernel<true>): the partials are QD[32 d][64 c] = sum_n qs (x) do2; dctx[d][e] = sum_c QD[d][c] Wo[c][h 32 + e]
 // with Wo the prepared to_out.0 weights ([16 e-octets][64 c][8], bf16 -- the values the separate data-gradient conv multiplied by)
 __global__ void __launch_bounds__(256) lc_bwd_combine_kernel(const float* __restrict__ partial, const float* __restrict__ ctx, float* __restrict__ dctx,
-                                                             float* __restrict__ S, int nparts, const bf16_t* __restrict__ wo) {
+                                                             float* __restrict__ S, int nparts, const bf16_t* __restrict__ wo, float* __restrict__ dwo) {
     __shared__ float prod[1024];
     __shared__ float qd[2048];
     const int tid = threadIdx.x, bh = blockIdx.x, h = bh & 3;
@@ -585,6 +593,17 @@ __global__ void __launch_bounds__(256) lc_bwd_combine_kernel(const float* __rest
     }
     if (wo) {
         __syncthreads();
+        // the to_out.0 WEIGHT gradient from the same partials: dWo[c][e] = sum_n do2[n][c] ao[n][e] with ao = ctx^T qs (what the forward's
+        // second pass computed), i.e. sum_d QD[d][c] ctx[d][e] -- no pass over do2 and ao, and the forward need not keep ao at all.
+        // dwo: the fp32 accumulator [ci = e (128)][co = c (64)] of the to_out.0 conv; every (sample, head) adds its 32 x 64 block.
+        if (dwo) {
+            for (int i = tid; i < 2048; i += 256) {
+                const int c = i & 63, e = i >> 6;
+                float a = 0.0f;
+                for (int d = 0; d < 32; ++d) a += qd[d * 64 + c] * ctx[(size_t)bh * 1024 + d * 32 + e];
+                atomicAdd(dwo + (size_t)(h * 32 + e) * 64 + c, a);
+            }
+        }
         for (int i = tid; i < 1024; i += 256) {
             const int d = i >> 5, e = h * 32 + (i & 31);
             float a = 0.0f;
@@ -630,7 +649,8 @@ int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_
 size_t la_bwd_workspace_floats(int B, int n) { return (size_t)B * 4 * ((size_t)la_parts(B, n) * 2048 + 1024 + 32); }      // (2048: the [32][64] partials of the do2 form)
 
 int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const float* ctx, const float* ml, bf16_t* dqkv, float* workspace, int B, int n,
-                                hipStream_t s, const bf16_t* xn, const bf16_t* wt, float* dw, bf16_t* dxn, const bf16_t* wo_fwd, const bf16_t* wo_t) {
+                                hipStream_t s, const bf16_t* xn, const bf16_t* wt, float* dw, bf16_t* dxn, const bf16_t* wo_fwd, const bf16_t* wo_t,
+                                float* dwo, float* dbo) {
     // wo_fwd / wo_t != nullptr (only with xn): `dout` is do2 [pixel][64], the gradient of the to_out.0 output (see lc_dctx_partial_kernel<true>)
     const bool fd = wo_fwd != nullptr && wo_t != nullptr && xn != nullptr;
     int nparts, span;
@@ -638,9 +658,9 @@ int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const flo
     float* partial = workspace;
     float* dctx = partial + (size_t)B * 4 * nparts * (fd ? 2048 : 1024);
     float* S = dctx + (size_t)B * 4 * 1024;
-    if (fd) lc_dctx_partial_kernel<true><<<dim3(nparts, B), 256, 0, s>>>(qkv, dout, partial, n, span, nparts);
-    else lc_dctx_partial_kernel<false><<<dim3(nparts, B), 256, 0, s>>>(qkv, dout, partial, n, span, nparts);
-    lc_bwd_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, dctx, S, nparts, fd ? wo_fwd : nullptr);
+    if (fd) lc_dctx_partial_kernel<true><<<dim3(nparts, B), 256, 0, s>>>(qkv, dout, partial, n, span, nparts, dbo);
+    else lc_dctx_partial_kernel<false><<<dim3(nparts, B), 256, 0, s>>>(qkv, dout, partial, n, span, nparts, nullptr);
+    lc_bwd_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, dctx, S, nparts, fd ? wo_fwd : nullptr, fd ? dwo : nullptr);
     int gx = cdiv(n, 32);
     if (gx > 2048) gx = 2048;
     static bool attr = false;

@@ -243,8 +243,9 @@ static void linattn_backward(Bwd& b, const TapeRec& r) {
     SrcSpec sao; sao.t = r.ao;
     static const int fuse_qkv = getenv("OFD_LA_BWD_FUSE_QKV") ? atoi(getenv("OFD_LA_BWD_FUSE_QKV")) : 1;
     static const int fuse_dao = getenv("OFD_LA_BWD_FUSE_DAO") ? atoi(getenv("OFD_LA_BWD_FUSE_DAO")) : 1;
-    const bool fd = C == 64 && fuse_qkv && fuse_dao;       // the core backward forms dout = Wo^T do2 itself: to_out.0 needs its weight gradient only
-    Tensor Dao = conv_backward(b, name + ".fn.fn.to_out.0", {sao}, r.o2.g, H, W, !fd, nullptr);
+    const bool fd = C == 64 && fuse_qkv && fuse_dao;       // the core backward forms dout = Wo^T do2 itself, and the to_out.0 weight / bias gradients
+    Tensor Dao;                                            // come out of its pixel reduction (la_core.hip lc_bwd_combine_kernel): no to_out.0 backward at all
+    if (!fd) Dao = conv_backward(b, name + ".fn.fn.to_out.0", {sao}, r.o2.g, H, W, true, nullptr);
     if (c.rc != OFD_OK) return;
     if (C == 64 && fuse_qkv) {
         // the to_qkv backward rides on the core backward's dqkv tile (la_core.hip lc_bwd_apply_kernel<true>): no dqkv tensor
@@ -254,8 +255,11 @@ static void linattn_backward(Bwd& b, const TapeRec& r) {
         if (c.rc != OFD_OK) return;
         c.begin(PC_LABWD, npix * (4.0 * 4 * 32 * 32 * 2 + 4.0 * 384 * 64), (double)npix * (384 + 128 + 64 + 64) * 2, name + " core + to_qkv bwd");
         const ConvDesc& dto = u->convs[u->cindex.at(name + ".fn.fn.to_out.0")];
-        if (fd) RUN(k_linear_attention_core_bwd(r.qkv.p, r.o2.g, r.ctx, r.ml, nullptr, ws, B, n, c.s, r.xn.p, u->d_wtbuf + d.w_off, acc, Dx.p,
-                                                u->d_wbuf + dto.w_off, u->d_wtbuf + dto.w_off));
+        if (fd) {
+            RUN(k_linear_attention_core_bwd(r.qkv.p, r.o2.g, r.ctx, r.ml, nullptr, ws, B, n, c.s, r.xn.p, u->d_wtbuf + d.w_off, acc, Dx.p,
+                                            u->d_wbuf + dto.w_off, u->d_wtbuf + dto.w_off, u->d_wacc + dto.w_off, u->G(name + ".fn.fn.to_out.0.bias")));
+            RUN(k_wgrad_finish(u->d_wacc + dto.w_off, u->P(dto.wname), u->G(dto.wname), dto.Cout, dto.Cin, dto.Cin_pad, dto.ksize, dto.ws_eps, dto.unshuffle, 0, c.s));
+        }
         else RUN(k_linear_attention_core_bwd(r.qkv.p, Dao.p, r.ctx, r.ml, nullptr, ws, B, n, c.s, r.xn.p, u->d_wtbuf + d.w_off, acc, Dx.p));
         RUN(k_wgrad_finish(acc, u->P(d.wname), u->G(d.wname), d.Cout, d.Cin, d.Cin_pad, d.ksize, d.ws_eps, d.unshuffle, 0, c.s));
         c.end();
