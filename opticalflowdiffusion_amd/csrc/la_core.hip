@@ -220,10 +220,12 @@ __global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ 
             lc_store_head((bf16_t*)(st + l31 * LO_PITCH) + h * 32, qo, half, true);
         }
         __syncthreads();
+        if (out) {                         // (nullptr: training with the fused backward -- nothing reads the head outputs again)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int id = tid + k * 256, px = id >> 4, u = id & 15;
-            if (p0 + px < n) *(u32x4*)(out + ((size_t)b * n + p0 + px) * 128 + u * 8) = *(const u32x4*)(st + px * LO_PITCH + u * 16);
+            for (int k = 0; k < 2; ++k) {
+                const int id = tid + k * 256, px = id >> 4, u = id & 15;
+                if (p0 + px < n) *(u32x4*)(out + ((size_t)b * n + p0 + px) * 128 + u * 8) = *(const u32x4*)(st + px * LO_PITCH + u * 16);
+            }
         }
         if (proj) {                        // o2 block of this wave: rows = channel, cols = pixel, k = the 128 head-output channels
             f32x16 pa;

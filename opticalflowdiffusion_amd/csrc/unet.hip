@@ -234,10 +234,11 @@ static Tensor linattn(Ctx& c, const std::string& name, Tensor x) {
     SrcSpec s; s.t = xn;
     conv(c, name + ".fn.fn.to_qkv", {s}, qkv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     c.begin(PC_LINATTN, 4.0 * npix * 4 * 32 * 32, (double)npix * (384 + 128 + 128) * 2);
-    static const int fuse_out = getenv("OFD_LA_FUSE_TO_OUT") ? atoi(getenv("OFD_LA_FUSE_TO_OUT")) : 1;
-    if (C <= 128 && fuse_out) {     // to_out.0 rides on the head-output tile of the core's second pass (la_core.hip lc_out_kernel)
+    if (C <= 128 && la_fuse_to_out()) {     // to_out.0 rides on the head-output tile of the core's second pass (la_core.hip lc_out_kernel)
         const ConvDesc& d = u->convs[u->cindex.at(name + ".fn.fn.to_out.0")];
-        RUN(k_linear_attention_core(qkv.p, partial, ctx, ao.p, B, n, c.s, ml, u->d_wbuf + d.w_off, u->P(name + ".fn.fn.to_out.0.bias"), o2.p, C));
+        // training, 64 channels, all fusions on: nothing reads the head outputs again (the backward derives what it needs from ctx and q)
+        bf16_t* ao_out = (c.train && la_train_no_ao(C)) ? nullptr : ao.p;
+        RUN(k_linear_attention_core(qkv.p, partial, ctx, ao_out, B, n, c.s, ml, u->d_wbuf + d.w_off, u->P(name + ".fn.fn.to_out.0.bias"), o2.p, C));
         c.end();
     } else {
         RUN(k_linear_attention_core(qkv.p, partial, ctx, ao.p, B, n, c.s, ml));

@@ -1,6 +1,7 @@
 // Shared declarations of the UNet executor (unet.hip: registry + inference forward; unet_train.hip:
 // training forward tape + backward).  Host code only.
 #pragma once
+#include <cstdlib>
 #include <array>
 #include <map>
 #include <tuple>
@@ -228,6 +229,14 @@ struct Ctx {
         in_region = false;
     }
 };
+
+// switches of the training LinearAttention fusions, shared by the forward (unet.hip) and the backward (unet_train.hip)
+static inline bool la_env_on(const char* name) { const char* e = getenv(name); return e ? atoi(e) != 0 : true; }
+static inline bool la_fuse_to_out() { static const bool v = la_env_on("OFD_LA_FUSE_TO_OUT"); return v; }
+static inline bool la_bwd_fuse_qkv() { static const bool v = la_env_on("OFD_LA_BWD_FUSE_QKV"); return v; }
+static inline bool la_bwd_fuse_dao() { static const bool v = la_env_on("OFD_LA_BWD_FUSE_DAO"); return v; }
+// 64-channel block with every fusion on: the backward needs neither dout nor ao (the forward does not write ao then)
+static inline bool la_train_no_ao(int C) { return C == 64 && la_fuse_to_out() && la_bwd_fuse_qkv() && la_bwd_fuse_dao(); }
 
 #define RUN(expr)                         \
     do {                                  \

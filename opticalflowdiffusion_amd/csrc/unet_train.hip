@@ -241,8 +241,7 @@ static void linattn_backward(Bwd& b, const TapeRec& r) {
                           site_eps(u, name + ".fn.fn.to_out.1"), 0, c.s));
     c.end();
     SrcSpec sao; sao.t = r.ao;
-    static const int fuse_qkv = getenv("OFD_LA_BWD_FUSE_QKV") ? atoi(getenv("OFD_LA_BWD_FUSE_QKV")) : 1;
-    static const int fuse_dao = getenv("OFD_LA_BWD_FUSE_DAO") ? atoi(getenv("OFD_LA_BWD_FUSE_DAO")) : 1;
+    const bool fuse_qkv = la_bwd_fuse_qkv(), fuse_dao = la_bwd_fuse_dao();
     const bool fd = C == 64 && fuse_qkv && fuse_dao;       // the core backward forms dout = Wo^T do2 itself, and the to_out.0 weight / bias gradients
     Tensor Dao;                                            // come out of its pixel reduction (la_core.hip lc_bwd_combine_kernel): no to_out.0 backward at all
     if (!fd) Dao = conv_backward(b, name + ".fn.fn.to_out.0", {sao}, r.o2.g, H, W, true, nullptr);
