@@ -11,7 +11,8 @@ struct MlpDesc {            // one ResnetBlock's time-embedding Linear (DD:193-1
     int offset;             // into the per-sample scale/shift row
 };
 
-int conv_forward_impl(const ofd_conv_args* a, hipStream_t s);
+int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0 = 0);      // cout0: see ConvParams::cout0 (honoured by the streaming 1x1 kernel only
+                                                                                   // for 64 -> 384 with cout0 = 128; everything else computes all channels)
 // conv backward (conv_bwd.hip)
 int k_wt_transpose(const bf16_t* w, bf16_t* wt, int taps, int Cin, int Cout, hipStream_t s);
 int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_t s, float* dbias = nullptr);
@@ -42,7 +43,8 @@ int k_resblock_out(const bf16_t* h, const float* a, const float* sft, const bf16
 int k_layernorm_c(const bf16_t* x, const float* g, const bf16_t* res, bf16_t* out, size_t npix, int C, float eps, hipStream_t s);
 int la_parts(int B, int n);
 int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s, float* ml_out = nullptr,
-                            const bf16_t* wo = nullptr, const float* bo = nullptr, bf16_t* o2 = nullptr, int C = 0);
+                            const bf16_t* wo = nullptr, const float* bo = nullptr, bf16_t* o2 = nullptr, int C = 0, const bf16_t* xn = nullptr,
+                            const bf16_t* wq = nullptr);
 int la_fused_blocks(int n);
 int k_la_weight_prep(const float* wqkv, const float* g, const float* wout, bf16_t* wq, bf16_t* wkv, bf16_t* woutp, int C, hipStream_t s);
 int k_linear_attention_fused(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const bf16_t* woutp, const float* bias, const float* g2,
@@ -72,7 +74,8 @@ int k_grad_add(bf16_t* dst, const bf16_t* src, size_t elems, int accumulate, hip
 size_t la_bwd_workspace_floats(int B, int n);
 int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const float* ctx, const float* ml, bf16_t* dqkv, float* workspace, int B, int n,
                                 hipStream_t s, const bf16_t* xn = nullptr, const bf16_t* wt = nullptr, float* dw = nullptr, bf16_t* dxn = nullptr,
-                                const bf16_t* wo_fwd = nullptr, const bf16_t* wo_t = nullptr, float* dwo = nullptr, float* dbo = nullptr);
+                                const bf16_t* wo_fwd = nullptr, const bf16_t* wo_t = nullptr, float* dwo = nullptr, float* dbo = nullptr,
+                                const bf16_t* wq = nullptr);
 int k_flash_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout, const float* lse, bf16_t* dqkv, float* delta, int B, int n,
                           hipStream_t s);
 

@@ -69,6 +69,7 @@ struct Params {
     const float* res_shift;
     bf16_t* out;
     int B, H, W, Cout, ntiles;
+    int cout0;                 // first output channel computed (the blocks of this launch start there; the tensor keeps its full pixel stride Cout)
     int interleave;            // 1: workgroup w walks tiles w, w + G, ... (the resident workgroups sweep ONE moving window of memory); 0: a contiguous range each
 };
 
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int ns = wave % NSG, pg = wave / NSG;
-    const int n0 = blockIdx.y * 32 * NSG * NCB, cb = n0 + 32 * ns;    // (block k of this workgroup: cb + 32 NSG k)
+    const int n0 = P.cout0 + blockIdx.y * 32 * NSG * NCB, cb = n0 + 32 * ns;    // (block k of this workgroup: cb + 32 NSG k)
 
     // ---- weights: this wave's A fragments, for good
     bf16x8 wf[NCB][KS];
@@ -287,7 +288,7 @@ static int launch(const Params& P, hipStream_t s) {
     int gx = 256 * per_cu;
     if (const char* e = getenv("OFD_CONV1_GRID")) gx = atoi(e) > 0 ? atoi(e) : gx;       // diagnostics / tests: long tile ranges on small inputs
     if (gx > P.ntiles) gx = P.ntiles;
-    conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB><<<dim3(gx, P.Cout / (32 * NSG * NCB)), NTHREADS, LDS, s>>>(P);
+    conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB><<<dim3(gx, (P.Cout - P.cout0) / (32 * NSG * NCB)), NTHREADS, LDS, s>>>(P);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -325,6 +326,8 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
     static const int order = getenv("OFD_CONV1_ORDER") ? atoi(getenv("OFD_CONV1_ORDER")) : 1;
     P.interleave = order;
     const bool narrow = C.Cout == 64;
+    P.cout0 = 0;
+    if (cin == 64 && C.cout0 == 128) { P.cout0 = 128; return launch<4, 64, 128, false, 2>(P, s); }      // ... its k and v blocks only (q recomputed downstream)
     if (cin == 64) return launch<4, 64, 128, false, 3>(P, s);                 // to_qkv of the 64-channel LinearAttention (training)
     if (cin == 128 && C.Cout == 384 && !ra && !C.bias) return launch<4, 128, 128, false, 3>(P, s);
     if (cin == 128) {

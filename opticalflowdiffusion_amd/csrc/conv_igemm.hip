@@ -1115,7 +1115,7 @@ int launch_conv3x3_c64_rw(const ConvParams& P, hipStream_t s);     // conv_rw.hi
 int launch_conv3x3_wp(const ConvParams& P, bool wide, hipStream_t s);   // conv_wp.hip
 int launch_conv1x1_wp(const ConvParams& P, hipStream_t s);              // conv1_wp.hip: 1 = shape not served
 
-int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
+int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0) {
     OFD_CHECK_ARG(a && a->out && a->weight, "conv: null out/weight");
     OFD_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0, "conv: bad shape");
     OFD_CHECK_ARG(a->ksize == 1 || a->ksize == 2 || a->ksize == 3 || a->ksize == 7, "conv: ksize %d unsupported", a->ksize);
@@ -1162,6 +1162,7 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
         P.pad_y = 1 - py; P.pad_x = 1 - px; P.out_oy = py; P.out_ox = px;
         P.phase_all = a->up2_phase == 5;
     }
+    P.cout0 = cout0;
     { static int dbg_env = -1; if (dbg_env < 0) { const char* e = getenv("OFD_CONV_DBG"); dbg_env = e ? atoi(e) : 0; } P.dbg = dbg_env; }
     // 128 output channels per workgroup unless that leaves CUs without work: small images (the reference's default 128 x 128 reaches
     // 16 x 16 at the coarsest level: 32 pixel tiles x 4 channel blocks for 256 CUs) take the 64-channel instantiation: twice the
@@ -1219,7 +1220,7 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s) {
 }  // namespace ofd
 using namespace ofd;
 
-extern "C" int ofd_conv_forward(const ofd_conv_args* a, void* stream) { return conv_forward_impl(a, (hipStream_t)stream); }
+extern "C" int ofd_conv_forward(const ofd_conv_args* a, void* stream) { return conv_forward_impl(a, (hipStream_t)stream, 0); }
 
 extern "C" size_t ofd_conv_gn_partial_count(int B, int H, int W, int Cout) {
     return (size_t)B * cdiv(H, TH) * cdiv(W, TW) * 4 * (Cout / 8) * 2;     // [b][tile][wave][Cout/8][2]

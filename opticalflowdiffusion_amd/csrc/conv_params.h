@@ -36,6 +36,7 @@ struct ConvParams {
     int out_oy, out_ox; // KS == 2: the output is (2H, 2W) and this launch writes pixels (2y + out_oy, 2x + out_ox)
     int phase_all;      // KS == 2: one launch computes the four phases; block j -> XCD j % 8, phase (j / 8) % 4, tile slot j / 32 (the phases of a
                         // tile run on one XCD at the same time: its input tile comes from that L2 three times out of four)
+    int cout0;          // 1x1 streaming kernel: output channels below cout0 are not computed (training to_qkv with q recomputed downstream); 0 = all
     int cy_fast;        // conv_wp: 1-D grid, the channel blocks of a pixel tile adjacent in dispatch order and on one XCD (A/B switch)
     int dbg;            // diagnostic ablation bits (OFD_CONV_DBG), 0 in production
 };

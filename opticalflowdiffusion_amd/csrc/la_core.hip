@@ -161,13 +161,16 @@ __device__ __forceinline__ bf16x8 lc_afrag(const unsigned char* lds, int h, int 
 // direct global->LDS path (one 1 KB / 256 B instruction per pixel row, no staging registers) and results leave as
 // consecutive 16-byte units of consecutive pixels.  Reading operand fragments straight from global memory (32 bytes per
 // pixel and instruction) ran at ~2.8 TB/s; a padded row pitch keeps the lane-per-pixel LDS reads conflict-free.
-constexpr int LO_PITCH = 256 + 16;        // q part of a pixel row (128 channels) + pad
+constexpr int LO_PITCH = 256 + 128 + 16;  // q part of a pixel row (128 channels) | xn row (64 channels, q recomputed from it) | pad
 // wo != nullptr (C = 64 or 128): the to_out.0 1x1 conv (DD:225) rides on the head-output tile while it is in LDS -- o2 = Wo ao + bo, wave w
 // owns the 32-channel block w of o2 and keeps its eight A fragments (128 input channels) in registers for the whole launch.  The
 // separate conv launch and its read of ao (1.85 GB at full resolution) go away; ao itself is still written (the backward's to_out
 // weight gradient reads it).
+// wq != nullptr (C = 64): q is RECOMPUTED from xn (q = Wq xn, four MFMAs per head and tile with the head's A fragments in registers for
+// the launch; rounded to bf16 like the stored tensor) -- the to_qkv conv need not write q and this pass reads 64 channels instead of 128.
 __global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ ctx, bf16_t* __restrict__ out, int n,
-                                                     const bf16_t* __restrict__ wo, const float* __restrict__ bo, bf16_t* __restrict__ o2, int C) {
+                                                     const bf16_t* __restrict__ wo, const float* __restrict__ bo, bf16_t* __restrict__ o2, int C,
+                                                     const bf16_t* __restrict__ xn, const bf16_t* __restrict__ wq) {
     __shared__ __attribute__((aligned(16))) unsigned char ct[4 * 32 * 80];      // ctx^T: rows e, k = d
     __shared__ __attribute__((aligned(16))) unsigned char st[32 * LO_PITCH];    // q rows in, out rows out
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5, b = blockIdx.y;
@@ -182,9 +185,17 @@ __global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ 
         for (int g = 0; g < 4; ++g) bo4[g] = bo ? *(const float4*)(bo + wave * 32 + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int h = wave;                    // wave = head; the four waves of a workgroup share a 32-pixel tile
+    bf16x8 wqf[4];                         // recompute: A fragments of Wq for this head (rows d, k = the 64 channels of xn)
+    if (wq) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wqf[ks] = *(const bf16x8*)(wq + ((size_t)(ks * 2 + half) * 384 + h * 32 + l31) * 8);
+    }
     for (int p0 = blockIdx.x * 32; p0 < n; p0 += gridDim.x * 32) {
         __syncthreads();                   // previous tile's copy-out is done (and, first time, ct is staged)
-        {   // 32 pixels x 16 units of q: 512 units, two per thread, consecutive lanes = consecutive units of a pixel row
+        if (wq) {   // 32 pixels x 8 units of xn: one per thread
+            const int px = tid >> 3, u = tid & 7;
+            *(u32x4*)(st + px * LO_PITCH + 256 + u * 16) = *(const u32x4*)(xn + ((size_t)b * n + min(p0 + px, n - 1)) * 64 + u * 8);
+        } else {    // 32 pixels x 16 units of q: 512 units, two per thread, consecutive lanes = consecutive units of a pixel row
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int id = tid + k * 256, px = id >> 4, u = id & 15;
@@ -195,6 +206,19 @@ __global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ 
         __syncthreads();
         const unsigned char* row = st + l31 * LO_PITCH;
         float q[16];
+        if (wq) {                          // operand-layout q (channel 16 s + 8 half + j of the head) from accumulator-layout MFMA output
+            f32x16 qa;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qa[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wqf[ks], *(const bf16x8*)(row + 256 + (ks * 16 + half * 8) * 2), qa, 0, 0, 0);
+            // the softmax below is layout-agnostic (all 32 d of a pixel sit in its two half-lanes either way); the MFMA operand built from
+            // q afterwards (lc_frag) wants channel 8 half + j (+16): go through the tile like the stored tensor would
+            uint2 qq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) qq[g] = make_uint2(f2bf2(qa[4 * g], qa[4 * g + 1]), f2bf2(qa[4 * g + 2], qa[4 * g + 3]));
+            lc_store_head((bf16_t*)(st + l31 * LO_PITCH) + h * 32, qq, half, true);
+        }
         lc_unpack8(*(const u32x4*)(row + (h * 32 + half * 8) * 2), &q[0]);
         lc_unpack8(*(const u32x4*)(row + (h * 32 + 16 + half * 8) * 2), &q[8]);
         float mx = q[0];
@@ -337,6 +361,84 @@ __global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __re
     }
 }
 
+// ---- backward pass 1 with q RECOMPUTED from xn and dout in its do2 form (C = 64, every training fusion on): the chunk's xn and do2 rows
+// are staged (128 pixels x 128 B each), a wave (= head) forms q = Wq xn for the four 32-pixel tiles (A fragments in registers for the
+// launch), the softmax over d runs in the accumulator layout, and the scaled result goes to the pixel-major `qs` tile the transposing
+// reads want.  Output: the [32 d][64 c] partials of lc_dctx_partial_kernel<true>.
+constexpr int RQ_CH = 64;            // pixels per chunk of the recompute pass (32 KB of LDS: four workgroups per CU)
+__global__ void __launch_bounds__(256) lc_dctx_partial_rq_kernel(const bf16_t* __restrict__ xn, const bf16_t* __restrict__ wq, const bf16_t* __restrict__ do2,
+                                                                 float* __restrict__ partial, int n, int span, int nparts, float* __restrict__ dbias) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dq_smem[];
+    unsigned char* qs = dq_smem;                      // [128 pixels][256 B] softmax_d(q) * scale
+    unsigned char* gs = qs + RQ_CH * 256;             // [128 pixels][128 B] do2
+    unsigned char* xs = gs + RQ_CH * 128;             // [128 pixels][128 B] xn
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5, h = wave;
+    const int part = blockIdx.x, b = blockIdx.y;
+    const int n_begin = part * span, n_end = min(n, n_begin + span);
+    bf16x8 wqf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wqf[ks] = *(const bf16x8*)(wq + ((size_t)(ks * 2 + half) * 384 + h * 32 + l31) * 8);
+    f32x16 acc, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc1[r] = 0.0f; }
+    float bsum = 0.0f;
+    for (int c0 = n_begin; c0 < n_end; c0 += RQ_CH) {
+        const int cnt = min(RQ_CH, n_end - c0);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RQ_CH / 32; ++i) {        // RQ_CH pixels x 8 units of each tensor
+            const int id = tid + i * 256, p = id >> 3, u = id & 7;
+            const size_t pix = (size_t)b * n + c0 + min(p, cnt - 1);
+            u32x4 g = *(const u32x4*)(do2 + pix * 64 + u * 8);
+            if (p >= cnt) g = u32x4{0u, 0u, 0u, 0u};  // pixels past the end contribute nothing
+            *(u32x4*)(gs + p * 128 + u * 16) = g;
+            *(u32x4*)(xs + p * 128 + u * 16) = *(const u32x4*)(xn + pix * 64 + u * 8);
+        }
+        __syncthreads();
+        if (dbias) {
+#pragma unroll 8
+            for (int p = (tid >> 6) * (RQ_CH / 4); p < (tid >> 6) * (RQ_CH / 4) + RQ_CH / 4; ++p) bsum += bf2f(*(const bf16_t*)(gs + p * 128 + (tid & 63) * 2));
+        }
+#pragma unroll
+        for (int pt = 0; pt < RQ_CH / 32; ++pt) {
+            const int p = pt * 32 + l31;
+            f32x16 qa;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qa[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wqf[ks], *(const bf16x8*)(xs + p * 128 + (ks * 16 + half * 8) * 2), qa, 0, 0, 0);
+            float q[16];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { q[j] = bf2f(f2bf(qa[j])); mx = fmaxf(mx, q[j]); }      // (bf16: what the stored q tensor held)
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { q[j] = __expf(q[j] - mx); sum += q[j]; }
+            sum += __shfl_xor(sum, 32, 64);
+            const float k = p < cnt ? LC_SCALE * __builtin_amdgcn_rcpf(sum) : 0.0f;
+            uint2 qq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) qq[g] = make_uint2(f2bf2(q[4 * g] * k, q[4 * g + 1] * k), f2bf2(q[4 * g + 2] * k, q[4 * g + 3] * k));
+            lc_store_head((bf16_t*)(qs + p * 256) + h * 32, qq, half, true);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < RQ_CH / 16; ++sl) {
+            const bf16x8 qf = tr_frag(qs + sl * 16 * 256 + wave * 64, 256, lane);      // rows = d
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, tr_frag(gs + sl * 16 * 128, 128, lane), acc, 0, 0, 0);          // cols = c 0..31
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, tr_frag(gs + sl * 16 * 128 + 64, 128, lane), acc1, 0, 0, 0);   // cols = c 32..63
+        }
+    }
+    if (dbias) atomicAdd(dbias + (tid & 63), bsum);
+    float* o = partial + ((size_t)(b * 4 + wave) * nparts + part) * 2048;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        o[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + l31] = acc[r];
+        o[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + 32 + l31] = acc1[r];
+    }
+}
+
 // ---- backward pass 2: per pixel; grid (gx, B) -----------------------------------------------------------
 //   dq_raw = sm(q) * (dq - <sm(q), dq>), dq = scale * ctx . dout          (MFMA rows d, A = ctx)
 //   dk_raw = k * (dctx . v / n - S),    k = exp(k_raw - M) / L            (MFMA rows d, A = dctx)
@@ -349,11 +451,12 @@ constexpr int LB_LDS_FUSE = LB_LDS + 32 * 128 + 2 * 16 * 64 * 4;      // + the x
 // from L2) and dW[ci][co] += xn^T dqkv (all waves: 64 ci x 96 co each, contraction over the 32 pixels through transposing LDS reads,
 // accumulated in registers over the whole launch, added to `dw` with atomics at the end).  The 5.5 GB dqkv tensor of a full-resolution
 // block is then never written, nor read twice by the two 1x1 backward kernels: 25.8 GB -> 9.2 GB of traffic for the three steps.
-template <bool FUSE, bool FD>      // FD (with FUSE): `dout` is do2 [pixel][64]; dout = Wo^T do2 is formed per tile and head (wot: [8][128][8])
+// RQ (with FUSE): q is recomputed from the xn tile (q = Wq xn, wq: the prepared to_qkv weights [8][384][8]); the q part of the qkv rows is not read
+template <bool FUSE, bool FD, bool RQ>      // FD (with FUSE): `dout` is do2 [pixel][64]; dout = Wo^T do2 is formed per tile and head (wot: [8][128][8])
 __global__ void __launch_bounds__(256, 2) lc_bwd_apply_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ ctx,
                                                            const float* __restrict__ dctx, const float* __restrict__ ml, const float* __restrict__ S,
                                                            bf16_t* __restrict__ dqkv, int n, const bf16_t* __restrict__ xn, const bf16_t* __restrict__ wt,
-                                                           float* __restrict__ dw, bf16_t* __restrict__ dxn, const bf16_t* __restrict__ wot) {
+                                                           float* __restrict__ dw, bf16_t* __restrict__ dxn, const bf16_t* __restrict__ wot, const bf16_t* __restrict__ wq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lb_smem[];
     unsigned char* cA = lb_smem;
     unsigned char* dA = cA + 4 * 32 * 80;
@@ -398,7 +501,8 @@ __global__ void __launch_bounds__(256, 2) lc_bwd_apply_kernel(const bf16_t* __re
         for (int px = wave; px < 32; px += 4) {
             const size_t p = (size_t)b * n + min(p0 + px, n - 1);
             const bf16_t* src;
-            if constexpr (FD) src = lane < 48 ? qkv + p * 384 + lane * 8 : qkv + p * 384 + (lane - 48) * 8;     // (lanes 48..63: filler, overwritten by dout below)
+            if constexpr (RQ) src = qkv + p * 384 + (lane < 16 || lane >= 48 ? 128 + (lane & 15) * 8 : lane * 8);  // (q part and dout part: filler = the k units)
+            else if constexpr (FD) src = lane < 48 ? qkv + p * 384 + lane * 8 : qkv + p * 384 + (lane - 48) * 8;     // (lanes 48..63: filler, overwritten by dout below)
             else src = lane < 48 ? qkv + p * 384 + lane * 8 : dout + p * 128 + (lane - 48) * 8;
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(st + px * LB_PITCH), 16, 0, 0);
         }
@@ -429,7 +533,19 @@ __global__ void __launch_bounds__(256, 2) lc_bwd_apply_kernel(const bf16_t* __re
         const bf16x8 g0 = *(const bf16x8*)(row + 768 + (h * 32 + half * 8) * 2), g1 = *(const bf16x8*)(row + 768 + (h * 32 + 16 + half * 8) * 2);
         const bf16x8 v0 = *(const bf16x8*)(row + 512 + (h * 32 + half * 8) * 2), v1 = *(const bf16x8*)(row + 512 + (h * 32 + 16 + half * 8) * 2);
         float q[16], kc[16], kk[16];
-        lc_load_head((const bf16_t*)row + h * 32, half, q);               // accumulator layout
+        if constexpr (RQ) {                // q of this head from the xn tile: the MFMA output IS the accumulator layout; bf16-rounded like the stored tensor
+            f32x16 qa;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qa[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                qa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(wq + ((size_t)(ks * 2 + half) * 384 + h * 32 + l31) * 8),
+                                                             *(const bf16x8*)(xt + l31 * 128 + (ks * 16 + half * 8) * 2), qa, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) q[j] = bf2f(f2bf(qa[j]));
+        } else {
+            lc_load_head((const bf16_t*)row + h * 32, half, q);           // accumulator layout
+        }
         lc_load_head((const bf16_t*)row + 128 + h * 32, half, kc);
         lc_unpack8(*(const u32x4*)(row + 256 + (h * 32 + half * 8) * 2), &kk[0]);      // operand layout
         lc_unpack8(*(const u32x4*)(row + 256 + (h * 32 + 16 + half * 8) * 2), &kk[8]);
@@ -636,14 +752,14 @@ int la_parts(int B, int n) { int np, sp; lc_parts(B, n, np, sp); return np; }
 void launch_la_ctx_combine(const float* partial, float* ctx, int B, int nparts, float inv_n, float* ml_out, hipStream_t s);   // blocks.hip
 
 int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s, float* ml_out,
-                            const bf16_t* wo, const float* bo, bf16_t* o2, int C) {
+                            const bf16_t* wo, const float* bo, bf16_t* o2, int C, const bf16_t* xn, const bf16_t* wq) {
     int nparts, span;
     lc_parts(B, n, nparts, span);
     lc_ctx_partial_kernel<<<dim3(nparts, B), 256, 0, s>>>(qkv, partial, n, span, nparts);
     launch_la_ctx_combine(partial, ctx, B, nparts, 1.0f / (float)n, ml_out, s);
     int gx = cdiv(n, 32);
     if (gx > 2048) gx = 2048;
-    lc_out_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, ctx, out, n, wo, bo, o2, C);
+    lc_out_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, ctx, out, n, wo, bo, o2, C, xn, wq);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -652,7 +768,7 @@ size_t la_bwd_workspace_floats(int B, int n) { return (size_t)B * 4 * ((size_t)l
 
 int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const float* ctx, const float* ml, bf16_t* dqkv, float* workspace, int B, int n,
                                 hipStream_t s, const bf16_t* xn, const bf16_t* wt, float* dw, bf16_t* dxn, const bf16_t* wo_fwd, const bf16_t* wo_t,
-                                float* dwo, float* dbo) {
+                                float* dwo, float* dbo, const bf16_t* wq) {
     // wo_fwd / wo_t != nullptr (only with xn): `dout` is do2 [pixel][64], the gradient of the to_out.0 output (see lc_dctx_partial_kernel<true>)
     const bool fd = wo_fwd != nullptr && wo_t != nullptr && xn != nullptr;
     int nparts, span;
@@ -660,24 +776,31 @@ int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const flo
     float* partial = workspace;
     float* dctx = partial + (size_t)B * 4 * nparts * (fd ? 2048 : 1024);
     float* S = dctx + (size_t)B * 4 * 1024;
-    if (fd) lc_dctx_partial_kernel<true><<<dim3(nparts, B), 256, 0, s>>>(qkv, dout, partial, n, span, nparts, dbo);
+    if (fd && wq) {
+        constexpr int DQ_LDS = RQ_CH * (256 + 128 + 128);
+        static bool a2 = false;
+        if (!a2) { OFD_HIP(hipFuncSetAttribute((const void*)lc_dctx_partial_rq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS)); a2 = true; }
+        lc_dctx_partial_rq_kernel<<<dim3(nparts, B), 256, DQ_LDS, s>>>(xn, wq, dout, partial, n, span, nparts, dbo);
+    } else if (fd) lc_dctx_partial_kernel<true><<<dim3(nparts, B), 256, 0, s>>>(qkv, dout, partial, n, span, nparts, dbo);
     else lc_dctx_partial_kernel<false><<<dim3(nparts, B), 256, 0, s>>>(qkv, dout, partial, n, span, nparts, nullptr);
     lc_bwd_combine_kernel<<<B * 4, 256, 0, s>>>(partial, ctx, dctx, S, nparts, fd ? wo_fwd : nullptr, fd ? dwo : nullptr);
     int gx = cdiv(n, 32);
     if (gx > 2048) gx = 2048;
     static bool attr = false;
     if (!attr) {
-        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS));
-        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_FUSE));
-        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_FUSE));
+        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS));
+        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_FUSE));
+        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_FUSE));
+        OFD_HIP(hipFuncSetAttribute((const void*)lc_bwd_apply_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_FUSE));
         attr = true;
     }
     if (xn) {       // 64-channel block: the to_qkv backward fused in; fewer, longer-lived workgroups (each adds a 64 x 384 dW tile with atomics)
         if (gx > 512) gx = 512;
-        if (fd) lc_bwd_apply_kernel<true, true><<<dim3(gx, B), 256, LB_LDS_FUSE, s>>>(qkv, dout, ctx, dctx, ml, S, nullptr, n, xn, wt, dw, dxn, wo_t);
-        else lc_bwd_apply_kernel<true, false><<<dim3(gx, B), 256, LB_LDS_FUSE, s>>>(qkv, dout, ctx, dctx, ml, S, nullptr, n, xn, wt, dw, dxn, nullptr);
+        if (fd && wq) lc_bwd_apply_kernel<true, true, true><<<dim3(gx, B), 256, LB_LDS_FUSE, s>>>(qkv, dout, ctx, dctx, ml, S, nullptr, n, xn, wt, dw, dxn, wo_t, wq);
+        else if (fd) lc_bwd_apply_kernel<true, true, false><<<dim3(gx, B), 256, LB_LDS_FUSE, s>>>(qkv, dout, ctx, dctx, ml, S, nullptr, n, xn, wt, dw, dxn, wo_t, nullptr);
+        else lc_bwd_apply_kernel<true, false, false><<<dim3(gx, B), 256, LB_LDS_FUSE, s>>>(qkv, dout, ctx, dctx, ml, S, nullptr, n, xn, wt, dw, dxn, nullptr, nullptr);
     } else {
-        lc_bwd_apply_kernel<false, false><<<dim3(gx, B), 256, LB_LDS, s>>>(qkv, dout, ctx, dctx, ml, S, dqkv, n, nullptr, nullptr, nullptr, nullptr, nullptr);
+        lc_bwd_apply_kernel<false, false, false><<<dim3(gx, B), 256, LB_LDS, s>>>(qkv, dout, ctx, dctx, ml, S, dqkv, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     }
     OFD_LAUNCH_CHECK();
     return OFD_OK;

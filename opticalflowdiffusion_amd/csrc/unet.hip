@@ -121,7 +121,7 @@ static void build_registry(ofd_unet* u) {
 
 void conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& srcs, Tensor out, const float* in_scale,
                  const float* in_shift, const bf16_t* residual, const bf16_t* res_act, const float* res_scale,
-                 const float* res_shift, float* gn_partial) {
+                 const float* res_shift, float* gn_partial, int cout0) {
     if (c.rc != OFD_OK) return;
     const ConvDesc& d = c.u->convs[c.u->cindex.at(prefix)];
     ofd_conv_args a{};
@@ -151,7 +151,7 @@ void conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& srcs, T
     const int cls3 = pp ? PC_CONV3_PP : (d.Cout % 128 == 0 ? PC_CONV3 : PC_CONV3_64);
     c.begin(d.ksize == 3 ? cls3 : (d.ksize == 1 ? PC_CONV1 : PC_CONV7), flops, bytes,
             prefix + " " + std::to_string(d.Cin) + "->" + std::to_string(d.Cout) + " @" + std::to_string(out.H) + "x" + std::to_string(out.W));
-    RUN(conv_forward_impl(&a, c.s));
+    RUN(conv_forward_impl(&a, c.s, cout0));
     c.end();
 }
 
@@ -232,13 +232,18 @@ static Tensor linattn(Ctx& c, const std::string& name, Tensor x) {
     RUN(k_layernorm_c(x.p, u->P(name + ".fn.norm.g"), nullptr, xn.p, npix, C, site_eps(u, name + ".fn.norm"), c.s));
     c.end();
     SrcSpec s; s.t = xn;
-    conv(c, name + ".fn.fn.to_qkv", {s}, qkv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    // training, 64 channels, every fusion on and OFD_LA_RECOMPUTE_Q: the passes that need q re-derive it from xn -- only k and v are computed
+    const bool rq_conv = c.train && la_train_no_ao(C) && la_recompute_q();
+    conv(c, name + ".fn.fn.to_qkv", {s}, qkv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rq_conv ? 128 : 0);
     c.begin(PC_LINATTN, 4.0 * npix * 4 * 32 * 32, (double)npix * (384 + 128 + 128) * 2);
     if (C <= 128 && la_fuse_to_out()) {     // to_out.0 rides on the head-output tile of the core's second pass (la_core.hip lc_out_kernel)
         const ConvDesc& d = u->convs[u->cindex.at(name + ".fn.fn.to_out.0")];
         // training, 64 channels, all fusions on: nothing reads the head outputs again (the backward derives what it needs from ctx and q)
         bf16_t* ao_out = (c.train && la_train_no_ao(C)) ? nullptr : ao.p;
-        RUN(k_linear_attention_core(qkv.p, partial, ctx, ao_out, B, n, c.s, ml, u->d_wbuf + d.w_off, u->P(name + ".fn.fn.to_out.0.bias"), o2.p, C));
+        const bool rq = c.train && la_train_no_ao(C) && la_recompute_q();      // q re-derived from xn in every pass that needs it
+        const ConvDesc& dq = u->convs[u->cindex.at(name + ".fn.fn.to_qkv")];
+        RUN(k_linear_attention_core(qkv.p, partial, ctx, ao_out, B, n, c.s, ml, u->d_wbuf + d.w_off, u->P(name + ".fn.fn.to_out.0.bias"), o2.p, C,
+                                    rq ? xn.p : nullptr, rq ? u->d_wbuf + dq.w_off : nullptr));
         c.end();
     } else {
         RUN(k_linear_attention_core(qkv.p, partial, ctx, ao.p, B, n, c.s, ml));

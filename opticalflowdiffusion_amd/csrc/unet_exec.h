@@ -235,6 +235,7 @@ static inline bool la_env_on(const char* name) { const char* e = getenv(name); r
 static inline bool la_fuse_to_out() { static const bool v = la_env_on("OFD_LA_FUSE_TO_OUT"); return v; }
 static inline bool la_bwd_fuse_qkv() { static const bool v = la_env_on("OFD_LA_BWD_FUSE_QKV"); return v; }
 static inline bool la_bwd_fuse_dao() { static const bool v = la_env_on("OFD_LA_BWD_FUSE_DAO"); return v; }
+static inline bool la_recompute_q() { static const bool v = la_env_on("OFD_LA_RECOMPUTE_Q"); return v; }
 // 64-channel block with every fusion on: the backward needs neither dout nor ao (the forward does not write ao then)
 static inline bool la_train_no_ao(int C) { return C == 64 && la_fuse_to_out() && la_bwd_fuse_qkv() && la_bwd_fuse_dao(); }
 
@@ -251,7 +252,7 @@ static inline bool la_train_no_ao(int C) { return C == 64 && la_fuse_to_out() &&
 
 float site_eps(const ofd_unet* u, const std::string& site);
 void conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& srcs, Tensor out, const float* in_scale, const float* in_shift,
-          const bf16_t* residual, const bf16_t* res_act, const float* res_scale, const float* res_shift, float* gn_partial);
+          const bf16_t* residual, const bf16_t* res_act, const float* res_scale, const float* res_shift, float* gn_partial, int cout0 = 0);
 size_t persist_bytes(const ofd_unet* u, int B, int H, int W);
 size_t scratch_bytes(const ofd_unet* u, int B, int H, int W);
 size_t small_bytes(const ofd_unet* u, int B);

@@ -256,7 +256,8 @@ static void linattn_backward(Bwd& b, const TapeRec& r) {
         const ConvDesc& dto = u->convs[u->cindex.at(name + ".fn.fn.to_out.0")];
         if (fd) {
             RUN(k_linear_attention_core_bwd(r.qkv.p, r.o2.g, r.ctx, r.ml, nullptr, ws, B, n, c.s, r.xn.p, u->d_wtbuf + d.w_off, acc, Dx.p,
-                                            u->d_wbuf + dto.w_off, u->d_wtbuf + dto.w_off, u->d_wacc + dto.w_off, u->G(name + ".fn.fn.to_out.0.bias")));
+                                            u->d_wbuf + dto.w_off, u->d_wtbuf + dto.w_off, u->d_wacc + dto.w_off, u->G(name + ".fn.fn.to_out.0.bias"),
+                                            (la_train_no_ao(C) && la_recompute_q()) ? u->d_wbuf + d.w_off : nullptr));
             RUN(k_wgrad_finish(u->d_wacc + dto.w_off, u->P(dto.wname), u->G(dto.wname), dto.Cout, dto.Cin, dto.Cin_pad, dto.ksize, dto.ws_eps, dto.unshuffle, 0, c.s));
         }
         else RUN(k_linear_attention_core_bwd(r.qkv.p, Dao.p, r.ctx, r.ml, nullptr, ws, B, n, c.s, r.xn.p, u->d_wtbuf + d.w_off, acc, Dx.p));
