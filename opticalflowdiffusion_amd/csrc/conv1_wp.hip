@@ -61,7 +61,7 @@ struct Unit {            // 64 input channels of one source; output pixel (b, y,
 };
 
 struct Params {
-    Unit unit[6];
+    Unit unit[8];
     const bf16_t* weight;      // [Cin/8][Cout][8]
     const float* bias;
     const bf16_t* res_act;
@@ -302,8 +302,8 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
     if (C.res_act && !(C.res_scale && C.res_shift)) return 1;
     const int cin = C.Cin_total, plane = C.H * C.W;
     const bool ra = C.res_act != nullptr;
-    if (cin % 64 != 0 || cin > 384 || cin == 320 || (cin < 128 && !(cin == 64 && C.Cout == 384 && !ra && !C.bias)) || (C.Cout != 64 && C.Cout % 128 != 0)) return 1;
-    const int tile = (cin <= 128) ? 128 : (cin == 384 ? 32 : 64);
+    if (cin % 64 != 0 || (cin > 384 && !(cin == 512 && !ra)) || cin == 320 || (cin < 128 && !(cin == 64 && C.Cout == 384 && !ra && !C.bias)) || (C.Cout != 64 && C.Cout % 128 != 0)) return 1;
+    const int tile = (cin <= 128) ? 128 : (cin >= 384 ? 32 : 64);
     if (plane % tile != 0 || (size_t)C.B * plane * (size_t)(C.Cout > cin ? C.Cout : cin) * 2 >= (1ull << 40)) return 1;
     Params P{};
     int nu = 0;
@@ -312,7 +312,7 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
         if (S.mode == 1) return 1;
         if (S.mode == 2 && (C.W % tile != 0)) return 1;
         for (int k = 0; k < S.chunks; ++k) {
-            if (nu >= 6) return 1;
+            if (nu >= 8) return 1;
             Unit& U = P.unit[nu++];
             U.ptr = S.ptr + S.ch_offset + k * 64;
             U.stride = S.src_channels;
@@ -338,6 +338,7 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
         if (narrow) return 1;
         return ra ? launch<4, 192, 64, true>(P, s) : launch<4, 192, 64, false>(P, s);
     }
+    if (cin == 512) return narrow ? 1 : launch<4, 512, 32, false>(P, s);        // to_qkv 512 -> 384, down-sample 512 -> 256
     if (cin == 384) {
         if (narrow) return 1;
         return ra ? launch<4, 384, 32, true>(P, s) : launch<4, 384, 32, false>(P, s);

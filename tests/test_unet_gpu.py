@@ -197,6 +197,18 @@ def test_conv1x1_variants(L, B, H, W, grid, monkeypatch):
     out, _ = run_conv(L, B, H, W, 1, [dict(t=to_nhwc(x3)), dict(t=to_nhwc(x1))], 256, prep_weight(L, w, 1), bias=b2,
                       res_act=to_nhwc(h3), res_scale=a3, res_shift=s3)
     check_close(from_nhwc(out), ref, what="res_conv 384 -> 256 + silu(affine)")
+    # mid-block to_qkv 512 -> 384 and the level-2 Downsample (4 x 128 -> 256)
+    x5 = q(torch.randn(B, 512, H, W))
+    w = torch.randn(384, 512, 1, 1) / math.sqrt(512)
+    out, _ = run_conv(L, B, H, W, 1, [dict(t=to_nhwc(x5))], 384, prep_weight(L, w, 1))
+    check_close(from_nhwc(out), F.conv2d(x5, q(w)), what="qkv 1x1, 512 -> 384")
+    xs2 = q(torch.randn(B, 128, 2 * H, 2 * W))
+    w = torch.randn(256, 512, 1, 1) / math.sqrt(512)
+    P2 = {"m.1.weight": w, "m.1.bias": b2}
+    t2 = to_nhwc(xs2)
+    srcs2 = [dict(t=t2, unshuffle=1, p1=sub >> 1, p2=sub & 1) for sub in range(4)]
+    out, _ = run_conv(L, B, H, W, 1, srcs2, 256, prep_weight(L, w, 1, unshuffle=1), bias=b2)
+    check_close(from_nhwc(out), R.downsample(P2, "m", xs2, R.q_bf16), what="downsample 512 -> 256")
     # Downsample = pixel-unshuffle + 1x1 (DD:95-99)
     xs = q(torch.randn(B, 64, 2 * H, 2 * W))
     for co in (128, 64):
