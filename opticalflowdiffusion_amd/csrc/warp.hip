@@ -37,7 +37,13 @@ __device__ __forceinline__ bool pyr_plain(float fltX, float fltY, int L, int H, 
     return fltX >= (float)(L - 1) && fltX < (float)W - 1.0f && fltY >= (float)(L - 1) && fltY < (float)H - 1.0f;
 }
 
-constexpr int S_TH = 64, S_TW = 64, S_CG = 4, S_NT = 1024;
+#ifndef OFD_SPLAT_TH
+#define OFD_SPLAT_TH 64
+#endif
+#ifndef OFD_SPLAT_NT
+#define OFD_SPLAT_NT 1024
+#endif
+constexpr int S_TH = OFD_SPLAT_TH, S_TW = 64, S_CG = 4, S_NT = OFD_SPLAT_NT;
 constexpr int SKIPPED = -(1 << 30);
 
 // ---- grid_sample backward warp (WP:95-119): exact op order of the reference expression -------
@@ -304,7 +310,10 @@ __global__ void __launch_bounds__(S_NT) splat_tile_kernel(const float* __restric
 //           the four channels of a corner as straight-line code.  A product is v * w in double (exact), scaled and added as a
 //           64-bit integer exactly as above; it differs from the reference's fp32-rounded product by < 2^-24 of itself, far inside
 //           what the order of the reference's float atomics moves.
-constexpr int SF_CAP = 6144;                               // survivor list entries (u16 window coordinates); overflow is handled inline
+#ifndef OFD_SPLAT_CAP
+#define OFD_SPLAT_CAP 6144
+#endif
+constexpr int SF_CAP = OFD_SPLAT_CAP;                               // survivor list entries (u16 window coordinates); overflow is handled inline
 constexpr int SF_LDS_BYTES = S_LDS_BYTES + SF_CAP * 2 + 16;
 
 __device__ __forceinline__ void sf_accumulate(unsigned long long (*acc)[S_TH][S_TW], unsigned int (*flags)[S_TW], const float (&v)[S_CG],
