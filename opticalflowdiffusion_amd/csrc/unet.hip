@@ -485,14 +485,15 @@ static void upload_mlp_descs(ofd_unet* u) {
         d.offset = u->ss_offset.at(name);
         descs.push_back(d);
     }
-    hipMemcpy(u->d_mlp, descs.data(), descs.size() * sizeof(MlpDesc), hipMemcpyHostToDevice);
+    if (hipMemcpy(u->d_mlp, descs.data(), descs.size() * sizeof(MlpDesc), hipMemcpyHostToDevice) != hipSuccess)
+        set_error("unet: uploading the time-projection descriptors failed");      // (surfaces at the first launch that reads them)
 }
 
 extern "C" int ofd_unet_bind_param_buffer(ofd_unet* u, float* dev_params, size_t floats) {
     OFD_CHECK_ARG(u && dev_params, "unet_bind_param_buffer: null argument");
     OFD_CHECK_ARG(floats >= u->n_param_floats, "unet_bind_param_buffer: %zu floats, need %zu", floats, u->n_param_floats);
     OFD_CHECK_ARG(((uintptr_t)dev_params & 15) == 0, "unet_bind_param_buffer: buffer must be 16-byte aligned");
-    if (u->owns_params && u->d_params) hipFree(u->d_params);
+    if (u->owns_params && u->d_params) (void)hipFree(u->d_params);
     drop_graphs(u);
     u->d_params = dev_params;
     u->owns_params = false;
@@ -521,7 +522,11 @@ extern "C" int ofd_unet_create(const ofd_unet_config* cfg, ofd_unet** out) {
         ofd_unet_destroy(u);
         return OFD_ERR_HIP;
     }
-    hipMemset(u->d_params, 0, u->n_param_floats * sizeof(float));
+    if (hipMemset(u->d_params, 0, u->n_param_floats * sizeof(float)) != hipSuccess) {
+        set_error("unet_create: hipMemset failed");
+        ofd_unet_destroy(u);
+        return OFD_ERR_HIP;
+    }
     upload_mlp_descs(u);
     *out = u;
     return OFD_OK;
@@ -529,16 +534,16 @@ extern "C" int ofd_unet_create(const ofd_unet_config* cfg, ofd_unet** out) {
 
 extern "C" void ofd_unet_destroy(ofd_unet* u) {
     if (!u) return;
-    if (u->d_params && u->owns_params) hipFree(u->d_params);
-    if (u->d_wbuf) hipFree(u->d_wbuf);
-    if (u->d_mlp) hipFree(u->d_mlp);
-    if (u->d_labuf) hipFree(u->d_labuf);
-    if (u->d_wtbuf) hipFree(u->d_wtbuf);
-    if (u->d_wacc) hipFree(u->d_wacc);
-    if (u->d_prep) hipFree(u->d_prep);
-    if (u->d_tr) hipFree(u->d_tr);
+    if (u->d_params && u->owns_params) (void)hipFree(u->d_params);
+    if (u->d_wbuf) (void)hipFree(u->d_wbuf);
+    if (u->d_mlp) (void)hipFree(u->d_mlp);
+    if (u->d_labuf) (void)hipFree(u->d_labuf);
+    if (u->d_wtbuf) (void)hipFree(u->d_wtbuf);
+    if (u->d_wacc) (void)hipFree(u->d_wacc);
+    if (u->d_prep) (void)hipFree(u->d_prep);
+    if (u->d_tr) (void)hipFree(u->d_tr);
     drop_graphs(u);
-    for (auto e : u->pool) hipEventDestroy(e);
+    for (auto e : u->pool) (void)hipEventDestroy(e);
     delete u;
 }
 
@@ -628,10 +633,10 @@ extern "C" size_t ofd_unet_workspace_bytes(const ofd_unet* u, int B, int H, int 
 
 static void drop_graphs(ofd_unet* u) {
     for (auto& g : u->graphs) {
-        if (g.state == 2) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
+        if (g.state == 2) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     }
     u->graphs.clear();
-    if (u->cap_stream) { hipStreamDestroy(u->cap_stream); u->cap_stream = nullptr; }
+    if (u->cap_stream) { (void)hipStreamDestroy(u->cap_stream); u->cap_stream = nullptr; }
 }
 
 extern "C" int ofd_unet_set_graph(ofd_unet* u, int enabled) {
@@ -699,7 +704,7 @@ extern "C" int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float
             hipGraph_t g = nullptr;
             const hipError_t er = hipStreamEndCapture(u->cap_stream, &g);
             if (rc != OFD_OK || er != hipSuccess || !g) {
-                if (g) hipGraphDestroy(g);
+                if (g) (void)hipGraphDestroy(g);
                 if (rc == OFD_OK) { set_error("unet_forward: stream capture failed: %s", hipGetErrorString(er)); rc = OFD_ERR_HIP; }
                 return rc;
             }

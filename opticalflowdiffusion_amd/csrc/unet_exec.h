@@ -217,13 +217,13 @@ struct Ctx {
         hipEvent_t e1 = next_event();
         if (!e0 || !e1) return;
         ProfRec r{cls, e0, e1, flops, bytes, label};
-        if (!chain_ok) hipEventRecord(r.e0, s);
+        if (!chain_ok) (void)hipEventRecord(r.e0, s);
         u->recs.push_back(r);
         in_region = true;
     }
     void end() {
         if (!u->profiling || dry || u->recs.empty() || !in_region) return;
-        hipEventRecord(u->recs.back().e1, s);
+        (void)hipEventRecord(u->recs.back().e1, s);
         last_end = u->recs.back().e1;
         chain_ok = true;
         in_region = false;
