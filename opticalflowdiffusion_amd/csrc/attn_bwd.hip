@@ -229,7 +229,7 @@ int k_flash_attention_bwd(const bf16_t* qkv, const bf16_t* o, const bf16_t* dout
 }  // namespace ofd
 using namespace ofd;
 
-extern "C" size_t ofd_la_workspace_floats(int B, int n) { return (size_t)B * 4 * (size_t)la_parts(B, n) * 1088; }
+extern "C" size_t ofd_la_workspace_floats(int B, int n) { return (size_t)B * 4 * (size_t)la_fwd_parts(B, n) * 1088; }
 extern "C" size_t ofd_la_bwd_workspace_floats(int B, int n) { return la_bwd_workspace_floats(B, n); }
 extern "C" int ofd_linear_attention_core(const void* qkv, void* out, float* ctx, float* ml, float* workspace, int B, int n, void* stream) {
     OFD_CHECK_ARG(qkv && out && ctx && ml && workspace && B > 0 && n > 0, "linear_attention_core: bad argument");

@@ -239,14 +239,14 @@ __global__ void __launch_bounds__(256) la_ctx_combine_kernel(const float* __rest
 #pragma unroll
         for (int g = 1; g < 8; ++g) t += red[g][tid];
         Linv[tid] = 1.0f / t;
-        if (ml_out) {                     // softmax-over-pixels normalisers, kept for the backward
+        if (ml_out && blockIdx.y == 0) {  // softmax-over-pixels normalisers, kept for the backward
             ml_out[(size_t)bh * 64 + tid] = M[tid];
             ml_out[(size_t)bh * 64 + 32 + tid] = 1.0f / t;
         }
     }
     __syncthreads();
-    for (int i = tid; i < 1024; i += 256) {
-        const int d = i >> 5;
+    {   // grid (B * 4, 4): this workgroup's quarter of the 32 x 32 context (the normalisers above are recomputed by each of the four)
+        const int i = blockIdx.y * 256 + tid, d = i >> 5;
         float a = 0.0f;
         for (int c0 = 0; c0 < nparts; c0 += 8) {
             float v[8];
@@ -482,7 +482,7 @@ void launch_la_ctx_combine(const float* partial, float* ctx, int B, int nparts, 
         }
         lds_max = 150 * 1024;
     }
-    la_ctx_combine_kernel<<<B * 4, 256, lds, s>>>(partial, ctx, nparts, inv_n, ml_out);
+    la_ctx_combine_kernel<<<dim3(B * 4, 4), 256, lds, s>>>(partial, ctx, nparts, inv_n, ml_out);
 }
 int k_flash_attention(const bf16_t* qkv, bf16_t* out, int B, int n, hipStream_t s, float* lse) {
     flash_attn_d32_kernel<<<dim3(cdiv(n, 128), B * 4), 256, 0, s>>>(qkv, out, n, 0.17677669529663687f, lse);

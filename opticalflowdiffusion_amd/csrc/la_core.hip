@@ -6,6 +6,7 @@
 //   pass 2 (per pixel): the PIXEL sits on the MFMA column (= lane), so every per-pixel softmax reduction is
 //           in-lane plus one cross-half shuffle, and the 32x32 context matrices are the A operands.
 // qkv / dqkv: [B][n][384] bf16 (q | k | v, 4 heads x 32); out / dout: [B][n][128].
+#include <cstdlib>
 #include "blocks.h"
 #include "mfma_util.h"
 
@@ -748,14 +749,20 @@ static inline void lc_parts(int B, int n, int& nparts, int& span) {
     nparts = cdiv(n, span);
 }
 int la_parts(int B, int n) { int np, sp; lc_parts(B, n, np, sp); return np; }
+// parts of the forward's first pass (whichever of its two kernels runs): sizes the partial buffer
+int la_fwd_parts(int B, int n) { const int a = la_parts(B, n), f = la_fused_blocks(n) * 4; return a > f ? a : f; }
 
 void launch_la_ctx_combine(const float* partial, float* ctx, int B, int nparts, float inv_n, float* ml_out, hipStream_t s);   // blocks.hip
+int launch_la_ctx_stored(const bf16_t* qkv, float* partial, int B, int n, hipStream_t s);                                       // la_fused.hip
 
 int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s, float* ml_out,
                             const bf16_t* wo, const float* bo, bf16_t* o2, int C, const bf16_t* xn, const bf16_t* wq) {
     int nparts, span;
     lc_parts(B, n, nparts, span);
-    lc_ctx_partial_kernel<<<dim3(nparts, B), 256, 0, s>>>(qkv, partial, n, span, nparts);
+    // pass 1: the accumulator-layout kernel on the stored k, v (la_fused.hip la_ctx_stored_kernel); OFD_LA_CTX_STORED=0: the LDS-scan kernel above
+    static const int stored = getenv("OFD_LA_CTX_STORED") ? atoi(getenv("OFD_LA_CTX_STORED")) : 1;
+    if (stored) nparts = launch_la_ctx_stored(qkv, partial, B, n, s);
+    else lc_ctx_partial_kernel<<<dim3(nparts, B), 256, 0, s>>>(qkv, partial, n, span, nparts);
     launch_la_ctx_combine(partial, ctx, B, nparts, 1.0f / (float)n, ml_out, s);
     int gx = cdiv(n, 32);
     if (gx > 2048) gx = 2048;

@@ -15,6 +15,8 @@
 
 namespace ofd {
 
+int la_fused_blocks(int n);
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -158,6 +160,97 @@ __global__ void __launch_bounds__(256, 2) la_ctx_fused_kernel(const bf16_t* __re
         for (int g = 0; g < 4; ++g)   // lane = d (column), registers = e rows
             *(float4*)(o + 64 + l31 * 32 + 8 * g + 4 * half) = make_float4(ctxT[hd][4 * g], ctxT[hd][4 * g + 1], ctxT[hd][4 * g + 2], ctxT[hd][4 * g + 3]);
     }
+}
+
+// ---- pass 1 on STORED k, v (the training forward: qkv is materialised for the backward): the online-softmax body of the kernel above,
+// with the projection MFMAs replaced by a layout change -- a k (v) tile read as an A operand (lane = pixel, 8 consecutive channels: one
+// 16-byte load) times the 32 x 32 identity gives the accumulator tile [rows = pixels][col = d] exactly (bf16 x 1.0, fp32 accumulate), which is
+// what the context MFMA wants as operands.  Replaces lc_ctx_partial_kernel (la_core.hip), whose per-channel max / exp scans walk an LDS tile
+// two bytes at a time: 1.3 ms -> 0.4 ms per full-resolution block.  Same partial format ([m 32 | l 32 | ctx 32 x 32] per (sample, head, part)).
+__global__ void __launch_bounds__(256, 2) la_ctx_stored_kernel(const bf16_t* __restrict__ qkv, float* __restrict__ partial, int n) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.y, wave_id = blockIdx.x * 4 + wave, nw = gridDim.x * 4, ntiles = (n + 31) / 32;
+    bf16x8 ident[2];                       // B operand of the identity: k index 16 s + 8 half + j, column l31
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ident[s2][j] = (__bf16)((16 * s2 + 8 * half + j == l31) ? 1.0f : 0.0f);
+    f32x16 ctxT[4];
+    float m[4], l[4];
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+        m[hd] = -3.0e38f;
+        l[hd] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ctxT[hd][r] = 0.0f;
+    }
+    const bf16_t* qb = qkv + (size_t)b * n * 384;
+    // this lane's k (v) units of a tile: head hd, k-step s2 -> channels 128 (256) + 32 hd + 16 s2 + 8 half .. + 7 of pixel tile * 32 + l31.
+    // No cross-tile prefetch: with it the kernel needs 265 registers (9 spilled); the second resident workgroup covers the load latency.
+    for (int tile = wave_id; tile < ntiles; tile += nw) {
+        u32x4 kr[8], vr[8];
+        {
+            const bf16_t* row = qb + (size_t)min(tile * 32 + l31, n - 1) * 384 + 128 + 8 * half;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kr[i] = *(const u32x4*)(row + 16 * i);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vr[i] = *(const u32x4*)(row + 128 + 16 * i);
+        }
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd) {
+            f32x16 ka, va;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ka[r] = 0.0f; va[r] = 0.0f; }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                ka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kr[hd * 2 + s2]), ident[s2], ka, 0, 0, 0);   // rows = pixels, col = d
+                va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vr[hd * 2 + s2]), ident[s2], va, 0, 0, 0);   // rows = pixels, col = e
+            }
+            float mt = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (tile * 32 + acc_row(r, half) >= n) ka[r] = -3.0e38f;
+                mt = fmaxf(mt, ka[r]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float m_new = fmaxf(m[hd], mt);
+            const float f = __expf(m[hd] - m_new);
+            m[hd] = m_new;
+            float ps = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = bf2f(f2bf(__expf(ka[r] - m_new)));      // the value the context MFMA multiplies by: the normaliser sums the same
+                ka[r] = p;
+                ps += p;
+            }
+            l[hd] = l[hd] * f + ps;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ctxT[hd][r] *= f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)   // ctx^T[e][d] += sum_pix v[pix][e] p[pix][d]
+                ctxT[hd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(va, s2), acc_frag(ka, s2), ctxT[hd], 0, 0, 0);
+        }
+    }
+    const int nparts = nw;
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+        float* o = partial + ((size_t)(b * 4 + hd) * nparts + wave_id) * 1088;
+        const float l_tot = l[hd] + __shfl_xor(l[hd], 32, 64);
+        if (half == 0) {
+            o[l31] = m[hd];
+            o[32 + l31] = l_tot;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)   // lane = d (column), registers = e rows
+            *(float4*)(o + 64 + l31 * 32 + 8 * g + 4 * half) = make_float4(ctxT[hd][4 * g], ctxT[hd][4 * g + 1], ctxT[hd][4 * g + 2], ctxT[hd][4 * g + 3]);
+    }
+}
+
+// pass 1 of the unfused (training) path on the stored qkv tensor: returns the number of parts written per (sample, head)
+int launch_la_ctx_stored(const bf16_t* qkv, float* partial, int B, int n, hipStream_t s) {
+    const int gx = la_fused_blocks(n);
+    la_ctx_stored_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, partial, n);
+    return gx * 4;
 }
 
 // combine partials -> context as pass 2's A fragments:

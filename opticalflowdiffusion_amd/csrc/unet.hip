@@ -222,7 +222,7 @@ static Tensor linattn(Ctx& c, const std::string& name, Tensor x) {
         return y;
     }
     Tensor xn = c.tmp(C, H, W), qkv = c.tmp(384, H, W), ao = c.tmp(128, H, W), o2 = c.tmp(C, H, W);
-    const int nparts = la_parts(B, n);
+    const int nparts = la_fwd_parts(B, n);
     float* partial = c.tmpf((size_t)B * 4 * nparts * 1088);
     float* ctx = c.train ? c.keepf((size_t)B * 4 * 1024) : c.tmpf((size_t)B * 4 * 1024);
     float* ml = c.train ? c.keepf((size_t)B * 4 * 64) : nullptr;
