@@ -26,6 +26,7 @@ namespace ofd {
 
 struct SplatGeom {
     int B, C, H, W, Ho, Wo, scale, ox, oy, radius, ntx, nty;
+    int tw, th;   // output tile of the general tile kernel (the scale-1 fast kernel and the pyramid kernels use S_TW x S_TH)
     int grid;     // 1: targets are grid_sample's un-normalised coordinates (adjoint of warp_backward_flow), scale 1
     int pyr_L;    // > 0: only the source pixels that are "plain" for every offset of pyramid level pyr_L take part (splat_pyramid)
 };
@@ -159,20 +160,23 @@ __global__ void __launch_bounds__(S_NT) splat_tile_kernel(const float* __restric
                                                           unsigned int* __restrict__ far_count, unsigned int far_cap,
                                                           const unsigned int* __restrict__ absmax, SplatGeom g, int c0, int cg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_lds[];
-    unsigned long long(*acc)[S_TH][S_TW] = (unsigned long long(*)[S_TH][S_TW])s_lds;          // [S_CG][S_TH][S_TW]
-    unsigned int(*flags)[S_TW] = (unsigned int(*)[S_TW])(s_lds + S_CG * S_TH * S_TW * 8);     // 3 bits per channel: nan, +inf, -inf
+    // output tile of g.th x g.tw pixels (64 x 64 at scale 1; smaller at coarser scales, where a 64 x 64 tile's source footprint is
+    // 64 scale pixels wide and the whole level is a handful of tiles): flat [S_CG][th][tw] accumulators, [th][tw] flags
+    const int tw = g.tw, th = g.th, tpx = tw * th;
+    unsigned long long* acc = (unsigned long long*)s_lds;                     // [S_CG][th][tw]
+    unsigned int* flags = (unsigned int*)(s_lds + (size_t)S_CG * tpx * 8);   // 3 bits per channel: nan, +inf, -inf
     __shared__ float k_s[S_CG];
     __shared__ double kinv_s[S_CG];
     const int tid = threadIdx.x;
     const int tx = blockIdx.x, ty = blockIdx.y, n = blockIdx.z;
-    const int X0 = tx * S_TW, Y0 = ty * S_TH;
+    const int X0 = tx * tw, Y0 = ty * th;
 
-    for (int i = tid; i < S_CG * S_TH * S_TW; i += S_NT) (&acc[0][0][0])[i] = 0ull;
-    for (int i = tid; i < S_TH * S_TW; i += S_NT) (&flags[0][0])[i] = 0u;
+    for (int i = tid; i < S_CG * tpx; i += S_NT) acc[i] = 0ull;
+    for (int i = tid; i < tpx; i += S_NT) flags[i] = 0u;
 
     int fx0, fx1, fy0, fy1;
-    footprint(tx, g.ntx, S_TW, g.scale, g.W, fx0, fx1);
-    footprint(ty, g.nty, S_TH, g.scale, g.H, fy0, fy1);
+    footprint(tx, g.ntx, tw, g.scale, g.W, fx0, fx1);
+    footprint(ty, g.nty, th, g.scale, g.H, fy0, fy1);
     const int wx0 = max(0, fx0 - g.radius), wx1 = min(g.W, fx1 + g.radius);
     const int wy0 = max(0, fy0 - g.radius), wy1 = min(g.H, fy1 + g.radius);
     const int ww = wx1 - wx0, wh = wy1 - wy0;
@@ -226,7 +230,7 @@ __global__ void __launch_bounds__(S_NT) splat_tile_kernel(const float* __restric
             const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
             const bool own = (x >= fx0) && (x < fx1) && (y >= fy0) && (y < fy1);
             const int lx0 = x0 - X0, ly0 = y0 - Y0;
-            const bool touches = (lx0 >= -1) && (lx0 < S_TW) && (ly0 >= -1) && (ly0 < S_TH);
+            const bool touches = (lx0 >= -1) && (lx0 < tw) && (ly0 >= -1) && (ly0 < th);
             if (!touches && !own) continue;
             float w[4];
             corner_weights(fx, fy, x0, y0, w);
@@ -235,7 +239,7 @@ __global__ void __launch_bounds__(S_NT) splat_tile_kernel(const float* __restric
                 for (int k = 0; k < 4; ++k) {
                     const int lx = lx0 + (k & 1), ly = ly0 + (k >> 1);
                     const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
-                    if (lx >= 0 && lx < S_TW && ly >= 0 && ly < S_TH && cx < g.Wo && cy < g.Ho) {
+                    if (lx >= 0 && lx < tw && ly >= 0 && ly < th && cx < g.Wo && cy < g.Ho) {
 #pragma unroll
                         for (int c = 0; c < S_CG; ++c)
                             if (c < cg) {
@@ -245,11 +249,11 @@ __global__ void __launch_bounds__(S_NT) splat_tile_kernel(const float* __restric
                                         // round(val * 2^sh) as a 64-bit integer without a float->int64 conversion (a ~20
                                         // instruction expansion on gfx950): the 1.5*2^52 trick, exact for |x| < 2^51
                                         const double d = __builtin_fma((double)val, kd[c], 6755399441055744.0);
-                                        atomicAdd(&acc[c][ly][lx], (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll));
+                                        atomicAdd(&acc[(c * th + ly) * tw + lx], (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll));
                                     }
                                 } else {
                                     const unsigned bit = (val != val) ? 1u : (val > 0.0f ? 2u : 4u);
-                                    atomicOr(&flags[ly][lx], bit << (3 * c));
+                                    atomicOr(&flags[ly * tw + lx], bit << (3 * c));
                                 }
                             }
                     }
@@ -266,9 +270,9 @@ __global__ void __launch_bounds__(S_NT) splat_tile_kernel(const float* __restric
                     const int cx = x0 + (k & 1), cy = y0 + (k >> 1);
                     if (cx < 0 || cx >= g.Wo || cy < 0 || cy >= g.Ho) continue;
                     int lo, hi;
-                    footprint(cx / S_TW, g.ntx, S_TW, g.scale, g.W, lo, hi);
+                    footprint(cx / tw, g.ntx, tw, g.scale, g.W, lo, hi);
                     bool near = (x >= lo - g.radius) && (x < hi + g.radius);
-                    footprint(cy / S_TH, g.nty, S_TH, g.scale, g.H, lo, hi);
+                    footprint(cy / th, g.nty, th, g.scale, g.H, lo, hi);
                     near = near && (y >= lo - g.radius) && (y < hi + g.radius);
                     if (!near) mask |= 1u << k;
                 }
@@ -283,12 +287,12 @@ __global__ void __launch_bounds__(S_NT) splat_tile_kernel(const float* __restric
 
     const size_t oplane = (size_t)g.Ho * g.Wo;
     float* out_n = out + ((size_t)n * g.C + c0) * oplane;
-    for (int i = tid; i < cg * S_TH * S_TW; i += S_NT) {
-        const int c = i / (S_TH * S_TW), r = (i / S_TW) % S_TH, col = i % S_TW;
+    for (int i = tid; i < cg * tpx; i += S_NT) {
+        const int c = i / tpx, r = (i / tw) % th, col = i % tw;
         const int oy_ = Y0 + r, ox_ = X0 + col;
         if (oy_ < g.Ho && ox_ < g.Wo) {
-            float v = (float)((double)(long long)acc[c][r][col] * kinv_s[c]);
-            const unsigned f = (flags[r][col] >> (3 * c)) & 7u;
+            float v = (float)((double)(long long)acc[i] * kinv_s[c]);
+            const unsigned f = (flags[r * tw + col] >> (3 * c)) & 7u;
             if (f) {       // IEEE: NaN dominates, inf - inf = NaN, otherwise the infinity
                 const float inf = __builtin_huge_valf();
                 v = ((f & 1u) || (f & 6u) == 6u) ? __builtin_nanf("") : ((f & 2u) ? inf : -inf);
@@ -1391,9 +1395,13 @@ static int make_geom(SplatGeom& g, int B, int C, int H, int W, int scale, int ox
     OFD_CHECK_ARG(scale >= 1 && H / scale > 0 && W / scale > 0, "splat: bad scale %d for %dx%d", scale, H, W);
     OFD_CHECK_ARG(ox >= 0 && oy >= 0 && ox < scale && oy < scale, "splat: offset (%d,%d) must be in [0,scale)", ox, oy);
     OFD_CHECK_ARG((size_t)B * H * W < (1ull << 31), "splat: B*H*W must be < 2^31");
-    g = SplatGeom{B, C, H, W, H / scale, W / scale, scale, ox, oy, radius < 0 ? 0 : radius, 0, 0, 0, 0};
-    g.ntx = cdiv(g.Wo, S_TW);
-    g.nty = cdiv(g.Ho, S_TH);
+    g = SplatGeom{B, C, H, W, H / scale, W / scale, scale, ox, oy, radius < 0 ? 0 : radius, 0, 0, S_TW, S_TH, 0, 0};
+    // coarser scales: smaller output tiles, so that a tile's source footprint stays ~64 .. 128 pixels wide and the level has enough tiles
+    // to fill the chip (at scale 16 a 448 x 1024 image is ONE 64 x 64 tile per sample)
+    static const int small_tiles = getenv("OFD_SPLAT_SMALL_TILES") ? atoi(getenv("OFD_SPLAT_SMALL_TILES")) : 1;
+    if (scale > 1 && small_tiles) { int t = S_TW / scale; if (t < 8) t = 8; g.tw = t < S_TW ? t : S_TW; g.th = t < S_TH ? t : S_TH; }
+    g.ntx = cdiv(g.Wo, g.tw);
+    g.nty = cdiv(g.Ho, g.th);
     return OFD_OK;
 }
 
@@ -1455,7 +1463,7 @@ static int splat_launch(const float* in, const float* flow, float* out, const Sp
     for (int c0 = 0; c0 < C; c0 += S_CG) {
         const int cg = (C - c0 < S_CG) ? (C - c0) : S_CG;
         if (fast) splat_tile_fast_kernel<<<g.ntx * g.nty * B, S_NT, SF_LDS_BYTES, s>>>(in, flow, out, list, count, cap, absmax, g, c0, cg);
-        else splat_tile_kernel<<<dim3(g.ntx, g.nty, B), S_NT, S_LDS_BYTES, s>>>(in, flow, out, list, count, cap, absmax, g, c0, cg);
+        else splat_tile_kernel<<<dim3(g.ntx, g.nty, B), S_NT, (size_t)g.tw * g.th * (S_CG * 8 + 4), s>>>(in, flow, out, list, count, cap, absmax, g, c0, cg);
     }
     splat_far_kernel<<<256, 256, 0, s>>>(in, flow, out, list, count, cap, g);
     OFD_LAUNCH_CHECK();
