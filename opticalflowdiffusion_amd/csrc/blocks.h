@@ -45,7 +45,7 @@ int la_parts(int B, int n);
 int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_t* out, int B, int n, hipStream_t s, float* ml_out = nullptr,
                             const bf16_t* wo = nullptr, const float* bo = nullptr, bf16_t* o2 = nullptr, int C = 0, const bf16_t* xn = nullptr,
                             const bf16_t* wq = nullptr);
-int la_fused_blocks(int n);
+int la_fused_blocks(int n, int B);
 int la_fwd_parts(int B, int n);
 int k_la_weight_prep(const float* wqkv, const float* g, const float* wout, bf16_t* wq, bf16_t* wkv, bf16_t* woutp, int C, hipStream_t s);
 int k_linear_attention_fused(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const bf16_t* woutp, const float* bias, const float* g2,

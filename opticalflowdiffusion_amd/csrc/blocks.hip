@@ -225,10 +225,11 @@ __global__ void __launch_bounds__(256) la_ctx_combine_kernel(const float* __rest
         M[tid] = m;
     }
     __syncthreads();
+    const bool use_ws = nparts <= 256;               // (the launcher sizes w_s for at most 256 parts; beyond that the weights are recomputed)
     float l = 0.0f;
     for (int c = grp; c < nparts; c += 8) {
         const float w = __expf(base[(size_t)c * 1088 + dd] - M[dd]);
-        w_s[c * 32 + dd] = w;
+        if (use_ws) w_s[c * 32 + dd] = w;
         l += base[(size_t)c * 1088 + 32 + dd] * w;
     }
     __syncthreads();
@@ -252,9 +253,15 @@ __global__ void __launch_bounds__(256) la_ctx_combine_kernel(const float* __rest
             float v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = base[(size_t)min(c0 + k, nparts - 1) * 1088 + 64 + i];
+            if (use_ws) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (c0 + k < nparts) a += v[k] * w_s[(c0 + k) * 32 + d];
+                for (int k = 0; k < 8; ++k)
+                    if (c0 + k < nparts) a += v[k] * w_s[(c0 + k) * 32 + d];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c0 + k < nparts) a += v[k] * __expf(base[(size_t)(c0 + k) * 1088 + d] - M[d]);
+            }
         }
         ctx[(size_t)bh * 1024 + i] = a * Linv[d] * inv_n;
     }
@@ -473,15 +480,7 @@ int k_layernorm_c(const bf16_t* x, const float* g, const bf16_t* res, bf16_t* ou
     return OFD_OK;
 }
 void launch_la_ctx_combine(const float* partial, float* ctx, int B, int nparts, float inv_n, float* ml_out, hipStream_t s) {
-    const size_t lds = (size_t)nparts * 32 * sizeof(float);
-    static size_t lds_max = 48 * 1024;
-    if (lds > lds_max) {                      // (B = 1 at 1080p: ~4000 parts never happens -- parts are capped by n / 512 -- but stay safe)
-        if (lds > 150 * 1024 || hipFuncSetAttribute((const void*)la_ctx_combine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
-            set_error("la_ctx_combine: %d parts need %zu bytes of LDS", nparts, lds);
-            return;
-        }
-        lds_max = 150 * 1024;
-    }
+    const size_t lds = (size_t)(nparts <= 256 ? nparts : 1) * 32 * sizeof(float);
     la_ctx_combine_kernel<<<dim3(B * 4, 4), 256, lds, s>>>(partial, ctx, nparts, inv_n, ml_out);
 }
 int k_flash_attention(const bf16_t* qkv, bf16_t* out, int B, int n, hipStream_t s, float* lse) {

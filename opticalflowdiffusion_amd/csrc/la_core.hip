@@ -750,7 +750,7 @@ static inline void lc_parts(int B, int n, int& nparts, int& span) {
 }
 int la_parts(int B, int n) { int np, sp; lc_parts(B, n, np, sp); return np; }
 // parts of the forward's first pass (whichever of its two kernels runs): sizes the partial buffer
-int la_fwd_parts(int B, int n) { const int a = la_parts(B, n), f = la_fused_blocks(n) * 4; return a > f ? a : f; }
+int la_fwd_parts(int B, int n) { const int a = la_parts(B, n), f = la_fused_blocks(n, B); return a > f ? a : f; }
 
 void launch_la_ctx_combine(const float* partial, float* ctx, int B, int nparts, float inv_n, float* ml_out, hipStream_t s);   // blocks.hip
 int launch_la_ctx_stored(const bf16_t* qkv, float* partial, int B, int n, hipStream_t s);                                       // la_fused.hip

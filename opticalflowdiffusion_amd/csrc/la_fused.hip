@@ -15,7 +15,7 @@
 
 namespace ofd {
 
-int la_fused_blocks(int n);
+int la_fused_blocks(int n, int B);
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -76,6 +76,49 @@ __device__ __forceinline__ void norm_x(const XRaw<C>& r, float eps, bf16x8 (&xs)
     for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) xs[s][j] = (__bf16)(v[s][j] * rstd);
+}
+
+// ---- end of pass 1: the workgroup's four waves merge their online-softmax states (m, l, ctx relative to m) of one head through LDS and
+// write ONE part: a quarter of the partial traffic, and a grid of 256+ workgroups (small batches) stays within the combine's 256 parts.
+// Part format unchanged: [m 32 | l 32 | ctx[d][e] 32 x 32].  LDS: 4 x LA_PART_PITCH floats (rows padded to 36 floats).
+constexpr int LA_PART_PITCH = 64 + 32 * 36;
+__device__ __forceinline__ void la_store_part(float* lds, float* __restrict__ o, float m, float l, const f32x16& ctxT, int tid, int wave, int l31,
+                                              int half) {
+    float* mine = lds + wave * LA_PART_PITCH;
+    const float l_tot = l + __shfl_xor(l, 32, 64);
+    if (half == 0) {
+        mine[l31] = m;
+        mine[32 + l31] = l_tot;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)   // lane = d (column), registers = e rows
+        *(float4*)(mine + 64 + l31 * 36 + 8 * g + 4 * half) = make_float4(ctxT[4 * g], ctxT[4 * g + 1], ctxT[4 * g + 2], ctxT[4 * g + 3]);
+    __syncthreads();
+    const int d = tid >> 3, e0 = (tid & 7) * 4;
+    float mw[4], M = -3.0e38f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        mw[w] = lds[w * LA_PART_PITCH + d];
+        M = fmaxf(M, mw[w]);
+    }
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float ls = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float wt = __expf(mw[w] - M);
+        const float4 v = *(const float4*)(lds + w * LA_PART_PITCH + 64 + d * 36 + e0);
+        a.x += v.x * wt;
+        a.y += v.y * wt;
+        a.z += v.z * wt;
+        a.w += v.w * wt;
+        ls += lds[w * LA_PART_PITCH + 32 + d] * wt;
+    }
+    *(float4*)(o + 64 + d * 32 + e0) = a;
+    if ((tid & 7) == 0) {
+        o[d] = M;
+        o[32 + d] = ls;
+    }
+    __syncthreads();
 }
 
 // ---- pass 1 ---------------------------------------------------------------------------------------
@@ -147,19 +190,10 @@ __global__ void __launch_bounds__(256, 2) la_ctx_fused_kernel(const bf16_t* __re
                 ctxT[hd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(va, s2), acc_frag(ka, s2), ctxT[hd], 0, 0, 0);
         }
     }
-    const int nparts = nw;
+    __syncthreads();                          // every wave is done with the weight fragments: the LDS becomes the combine buffer
 #pragma unroll
-    for (int hd = 0; hd < 4; ++hd) {
-        float* o = partial + ((size_t)(b * 4 + hd) * nparts + wave_id) * 1088;
-        const float l_tot = l[hd] + __shfl_xor(l[hd], 32, 64);
-        if (half == 0) {
-            o[l31] = m[hd];
-            o[32 + l31] = l_tot;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)   // lane = d (column), registers = e rows
-            *(float4*)(o + 64 + l31 * 32 + 8 * g + 4 * half) = make_float4(ctxT[hd][4 * g], ctxT[hd][4 * g + 1], ctxT[hd][4 * g + 2], ctxT[hd][4 * g + 3]);
-    }
+    for (int hd = 0; hd < 4; ++hd)
+        la_store_part((float*)smem, partial + ((size_t)(b * 4 + hd) * gridDim.x + blockIdx.x) * 1088, m[hd], l[hd], ctxT[hd], tid, wave, l31, half);
 }
 
 // ---- pass 1 on STORED k, v (the training forward: qkv is materialised for the backward): the online-softmax body of the kernel above,
@@ -231,26 +265,17 @@ __global__ void __launch_bounds__(256, 2) la_ctx_stored_kernel(const bf16_t* __r
                 ctxT[hd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(va, s2), acc_frag(ka, s2), ctxT[hd], 0, 0, 0);
         }
     }
-    const int nparts = nw;
+    __shared__ __attribute__((aligned(16))) float part_s[4 * LA_PART_PITCH];
 #pragma unroll
-    for (int hd = 0; hd < 4; ++hd) {
-        float* o = partial + ((size_t)(b * 4 + hd) * nparts + wave_id) * 1088;
-        const float l_tot = l[hd] + __shfl_xor(l[hd], 32, 64);
-        if (half == 0) {
-            o[l31] = m[hd];
-            o[32 + l31] = l_tot;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)   // lane = d (column), registers = e rows
-            *(float4*)(o + 64 + l31 * 32 + 8 * g + 4 * half) = make_float4(ctxT[hd][4 * g], ctxT[hd][4 * g + 1], ctxT[hd][4 * g + 2], ctxT[hd][4 * g + 3]);
-    }
+    for (int hd = 0; hd < 4; ++hd)
+        la_store_part(part_s, partial + ((size_t)(b * 4 + hd) * gridDim.x + blockIdx.x) * 1088, m[hd], l[hd], ctxT[hd], tid, wave, l31, half);
 }
 
 // pass 1 of the unfused (training) path on the stored qkv tensor: returns the number of parts written per (sample, head)
 int launch_la_ctx_stored(const bf16_t* qkv, float* partial, int B, int n, hipStream_t s) {
-    const int gx = la_fused_blocks(n);
+    const int gx = la_fused_blocks(n, B);
     la_ctx_stored_kernel<<<dim3(gx, B), 256, 0, s>>>(qkv, partial, n);
-    return gx * 4;
+    return gx;
 }
 
 // combine partials -> context as pass 2's A fragments:
@@ -264,7 +289,14 @@ __global__ void __launch_bounds__(256) la_ctx_combine_frag_kernel(const float* _
     const int tid = threadIdx.x, bh = blockIdx.x, dd = tid & 31, grp = tid >> 5;
     const float* base = partial + (size_t)bh * nparts * 1088;
     float mx = -3.0e38f;
-    for (int c = grp; c < nparts; c += 8) mx = fmaxf(mx, base[(size_t)c * 1088 + dd]);
+    // (four parts' loads in flight per thread in both scans: with few workgroups -- small batches -- these loops are latency chains)
+    for (int c0 = grp; c0 < nparts; c0 += 32) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = base[(size_t)min(c0 + 8 * k, nparts - 1) * 1088 + dd];     // (clamped: a repeated part does not change a max)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx = fmaxf(mx, t[k]);
+    }
     red[grp][dd] = mx;
     __syncthreads();
     if (tid < 32) {
@@ -274,11 +306,23 @@ __global__ void __launch_bounds__(256) la_ctx_combine_frag_kernel(const float* _
         M[tid] = m;
     }
     __syncthreads();
+    const bool use_ws = nparts <= LA_MAX_PARTS;      // more parts (small batches: one part per wave of a grid sized for the chip): weights recomputed below
     float l = 0.0f;
-    for (int c = grp; c < nparts; c += 8) {
-        const float w = __expf(base[(size_t)c * 1088 + dd] - M[dd]);
-        w_s[c][dd] = w;
-        l += base[(size_t)c * 1088 + 32 + dd] * w;
+    for (int c0 = grp; c0 < nparts; c0 += 32) {
+        float tm[4], tl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t o = (size_t)min(c0 + 8 * k, nparts - 1) * 1088;
+            tm[k] = base[o + dd];
+            tl[k] = base[o + 32 + dd];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c0 + 8 * k < nparts) {
+                const float w = __expf(tm[k] - M[dd]);
+                if (use_ws) w_s[c0 + 8 * k][dd] = w;
+                l += tl[k] * w;
+            }
     }
     __syncthreads();
     red[grp][dd] = l;
@@ -300,9 +344,18 @@ __global__ void __launch_bounds__(256) la_ctx_combine_frag_kernel(const float* _
         float v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = base[(size_t)min(c0 + k, nparts - 1) * 1088 + 64 + d * 32 + e];
+        if (use_ws) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (c0 + k < nparts) a += v[k] * w_s[c0 + k][d];
+            for (int k = 0; k < 8; ++k)
+                if (c0 + k < nparts) a += v[k] * w_s[c0 + k][d];
+        } else {
+            float mc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mc[k] = base[(size_t)min(c0 + k, nparts - 1) * 1088 + d];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c0 + k < nparts) a += v[k] * __expf(mc[k] - M[d]);
+        }
     }
     ctxfrag[(size_t)bh * 1024 + i] = f2bf(a * Linv[d] * inv_n);
 }
@@ -473,23 +526,31 @@ static int launch_la(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const
         OFD_HIP(hipFuncSetAttribute((const void*)la_out_fused_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
         attr = true;
     }
-    const int gx = la_fused_blocks(n);
+    const int gx = la_fused_blocks(n, B);
     la_ctx_fused_kernel<C><<<dim3(gx, B), 256, LDS1, s>>>(x, wkv, partial, n, eps_pre);
-    la_ctx_combine_frag_kernel<<<dim3(B * 4, 4), 256, 0, s>>>(partial, ctxfrag, gx * 4, 1.0f / (float)n);
+    la_ctx_combine_frag_kernel<<<dim3(B * 4, 4), 256, 0, s>>>(partial, ctxfrag, gx, 1.0f / (float)n);
     int gx2 = cdiv(cdiv(n, 32), 4 * 4);     // >= 4 tiles per wave amortise the weight staging
     if (gx2 < 1) gx2 = 1;
     static int gx2_cap = -1;
     if (gx2_cap < 0) { const char* e = getenv("OFD_LA_GX2"); gx2_cap = e ? atoi(e) : 128; }
-    if (gx2 > gx2_cap) gx2 = gx2_cap;
+    const int cap2 = (gx2_cap * B < 1024) ? 1024 / B : gx2_cap;          // small batches: enough workgroups for the chip
+    if (gx2 > cap2) gx2 = cap2;
     la_out_fused_kernel<C><<<dim3(gx2, B), 256, LDS2, s>>>(x, wq, woutp, ctxfrag, bias, g2, y, n, eps_pre, eps_post, 0.17677669529663687f);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
 
-int la_fused_blocks(int n) {
+// workgroups per sample of the first pass (= parts per (sample, head): each workgroup writes one): 64 at the batch sizes that fill the chip by
+// themselves, up to OFD_LA_GX1_TOTAL (default 256: one per CU; 128 / 192 / 384 / 512 measured slower at B = 1 1080p --
+// beyond 256 the combine's chain over the parts costs more than the first pass gains) over the batch for small ones -- at B = 1 (1080p: BASELINE configs[4] per
+// GPU) 64 workgroups were a quarter of the CUs
+int la_fused_blocks(int n, int B) {
+    static const int total = getenv("OFD_LA_GX1_TOTAL") ? atoi(getenv("OFD_LA_GX1_TOTAL")) : 256;
     int gx = cdiv(cdiv(n, 32), 8);
+    int cap = total / (B < 1 ? 1 : B);
+    if (cap < 64) cap = 64;
     if (gx < 1) gx = 1;
-    if (gx > 64) gx = 64;
+    if (gx > cap) gx = cap;
     return gx;
 }
 

@@ -207,7 +207,7 @@ static Tensor linattn(Ctx& c, const std::string& name, Tensor x) {
     auto fit = u->la_fused.find(name);
     if (fit != u->la_fused.end() && !c.train) {
         // fused two-pass block (la_fused.hip): no LayerNorm / qkv / head-output tensors in HBM
-        const int nparts = la_fused_blocks(n) * 4;
+        const int nparts = la_fused_blocks(n, B);
         float* partial = c.tmpf((size_t)B * 4 * nparts * 1088);
         bf16_t* ctxfrag = (bf16_t*)c.tmpf((size_t)B * 2048);
         Tensor y = c.keep(C, H, W);
@@ -461,7 +461,7 @@ size_t scratch_bytes(const ofd_unet* u, int B, int H, int W) {
     const int C = u->dims[0];
     size_t act = px * 2 * (size_t)(3 * C + C + 384 + 128 + C);
     // mid level widest: 512 ch at 1/64 of the pixels is far smaller; small buffers:
-    size_t small = 4 * ofd_conv_gn_partial_count(B, H, W, u->dims[4]) * 4 + (size_t)B * 4 * ((size_t)(la_parts(B, H * W) > 256 ? la_parts(B, H * W) : 256) * 1088 + 1024) * 4 +
+    size_t small = 4 * ofd_conv_gn_partial_count(B, H, W, u->dims[4]) * 4 + (size_t)B * 4 * ((size_t)(la_fwd_parts(B, H * W) > 256 ? la_fwd_parts(B, H * W) : 256) * 1088 + 1024) * 4 +
                    16 * (size_t)B * u->dims[4] * 4 + 64 * 1024;
     return act + small + 64 * 256;
 }
