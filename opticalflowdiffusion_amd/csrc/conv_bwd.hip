@@ -256,6 +256,107 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad1_qkv_kernel(const bf16_t* _
         }
 }
 
+// The same idea for the other 1x1 layers (res_conv of the concatenating blocks, to_out.0; Cout = 64 / 128 / 192 / 256, bias, several
+// sources): a workgroup owns one 64-channel ci block and ALL Cout output channels, so dY is read once per ci block instead of once per
+// (ci, co) block pair and X once instead of once per co block -- these kernels are pure traffic (32 flop per staged byte in the generic
+// form: `res_conv` 256 -> 128 at half resolution moved 3.7 GB for 1.4 GB of tensors).
+//   WCO = 4: wave -> 64 ci x Cout / 4 co (Cout = 128, 256);  WCO = 2: wave -> 32 ci x Cout / 2 co (Cout = 64, 192)
+template <int CO, int WCO>
+__global__ void __launch_bounds__(256, 2) conv_wgrad1_wide_kernel(const WgradParams P, size_t npix) {
+    constexpr int YP = CO * 2 + 64, SPAN = CO / WCO, NJ = SPAN / 32, NA = WCO == 4 ? 2 : 1, YU = CO / 8, YPT = WQ_PX * YU / 256;
+    static_assert(SPAN % 32 == 0 && (WQ_PX * YU) % 256 == 0, "wave tiling");
+    __shared__ __attribute__((aligned(16))) unsigned char xs[WQ_PX * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char ys[WQ_PX * YP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int kc = blockIdx.y;
+    const int cw = WCO == 4 ? wave : wave >> 1, a0 = WCO == 4 ? 0 : wave & 1;
+    int si = 0, first = 0;
+    while (si + 1 < P.n_src && kc >= first + P.src[si].chunks) { first += P.src[si].chunks; ++si; }
+    const bf16_t* x = P.src[si].ptr + P.src[si].ch_offset + (kc - first) * 64;
+    const int x_stride = P.src[si].src_channels;
+    const bool do_bias = P.dbias && kc == 0;
+    float bsum = 0.0f;
+    f32x16 acc[NA][NJ];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.0f;
+    const size_t ntiles = (npix + WQ_PX - 1) / WQ_PX;
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const size_t p0 = t * WQ_PX;
+        u32x4 xr[2], yr[YPT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                     // X tile: 64 pixels x 8 units
+            const int u = tid + i * 256, p = u >> 3, c8 = u & 7;
+            const size_t gp = min(p0 + p, npix - 1);
+            xr[i] = *(const u32x4*)(x + gp * x_stride + c8 * 8);
+            if (p0 + p >= npix) xr[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < YPT; ++i) {                   // dY tile: 64 pixels x CO / 8 units
+            const int u = tid + i * 256, p = u / YU, c8 = u - p * YU;
+            const size_t gp = min(p0 + p, npix - 1);
+            yr[i] = *(const u32x4*)(P.dy + gp * CO + c8 * 8);
+            if (p0 + p >= npix) yr[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+        __syncthreads();                                  // previous tile's fragment reads are complete
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = tid + i * 256;
+            *(u32x4*)(xs + (u >> 3) * 128 + (u & 7) * 16) = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < YPT; ++i) {
+            const int u = tid + i * 256, p = u / YU, c8 = u - p * YU;
+            *(u32x4*)(ys + p * YP + c8 * 16) = yr[i];
+        }
+        __syncthreads();
+        if (do_bias && tid < CO) {
+#pragma unroll 8
+            for (int p = 0; p < WQ_PX; ++p) bsum += bf2f(*(const bf16_t*)(ys + p * YP + tid * 2));
+        }
+#pragma unroll
+        for (int ks = 0; ks < WQ_PX / 16; ++ks) {
+            bf16x8 xf[NA], yf[NJ];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) xf[a] = tr_frag(xs + (ks * 16) * 128 + (a0 + a) * 64, 128, lane);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) yf[j] = tr_frag(ys + (ks * 16) * YP + (cw * SPAN + j * 32) * 2, YP, lane);
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[a][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a], yf[j], acc[a][j], 0, 0, 0);   // rows = ci, cols = co
+        }
+    }
+    if (do_bias && tid < CO) atomicAdd(P.dbias + tid, bsum);
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float* d = P.dw + ((size_t)kc * 64 + (a0 + a) * 32) * CO + cw * SPAN + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
+                atomicAdd(d + (size_t)ci * CO, acc[a][j][r]);
+            }
+        }
+}
+
+template <int CO, int WCO>
+static void launch_wgrad1_wide(const WgradParams& P, size_t npix, int ncib, hipStream_t s) {
+    // workgroups over all ci blocks: two per CU; four for Cout = 64, whose 20 KB / 62-register workgroups are short of loads in flight at two
+    // (full-resolution res_conv 128 -> 64: 0.76 / 0.61 / 0.66 ms at 512 / 1024 / 2048; 256 -> 128 at half resolution: 0.355 / 0.378 / 0.343)
+    static const int total_env = getenv("OFD_WGRAD1_WIDE_WGS") ? atoi(getenv("OFD_WGRAD1_WIDE_WGS")) : 0;
+    const int total = total_env > 0 ? total_env : (CO == 64 ? 1024 : 512);
+    int g = cdiv(total, ncib);
+    const size_t nt = (npix + WQ_PX - 1) / WQ_PX;
+    if ((size_t)g > nt) g = (int)nt;
+    conv_wgrad1_wide_kernel<CO, WCO><<<dim3(g, ncib), 256, 0, s>>>(P, npix);
+}
+
 // 3x3: all nine taps in one workgroup.  grid (pixel-tile groups, (Cin/64)*(Cout/64)); 4 waves, wave -> 32 ci x 32 co x 9 taps
 // (144 accumulator registers).  The 10 x 34 halo tile and the 8 x 32 dY tile are read from HBM once per
 // (ci block, co block): 248 flop per byte, against 83 for one kernel row per workgroup.  The halo rows are
@@ -702,6 +803,21 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
         conv_wgrad1_qkv_kernel<<<dim3(g, ncib), 256, 0, s>>>(P.src[0].ptr + P.src[0].ch_offset, P.src[0].src_channels, dy, dw, npix, cin);
         OFD_LAUNCH_CHECK();
         return OFD_OK;
+    }
+    static const bool no_wide = getenv("OFD_NO_WGRAD1_WIDE") && atoi(getenv("OFD_NO_WGRAD1_WIDE"));
+    if (a->ksize == 1 && !no_wide && !P.in_scale && (a->Cout == 64 || a->Cout == 128 || a->Cout == 192 || a->Cout == 256)) {
+        bool plain = true;
+        for (int i = 0; i < a->n_src; ++i) plain = plain && P.src[i].mode == 0;
+        if (plain) {
+            const size_t npix = (size_t)a->B * a->H * a->W;
+            const int ncib = cin / 64;
+            if (a->Cout == 64) launch_wgrad1_wide<64, 2>(P, npix, ncib, s);
+            else if (a->Cout == 128) launch_wgrad1_wide<128, 4>(P, npix, ncib, s);
+            else if (a->Cout == 192) launch_wgrad1_wide<192, 2>(P, npix, ncib, s);
+            else launch_wgrad1_wide<256, 4>(P, npix, ncib, s);
+            OFD_LAUNCH_CHECK();
+            return OFD_OK;
+        }
     }
     if (a->ksize == 3) {
         constexpr int LDS = 10 * 34 * 128 + 256 * 128;

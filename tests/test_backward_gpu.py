@@ -78,6 +78,21 @@ def test_conv3x3_backward(L, B, H, W, Cin, Cout):
     assert rel_l2(out.cpu(), dy.sum(dim=(0, 2, 3))) < 1e-3
 
 
+@pytest.mark.parametrize("Cout,cins", [(64, (64, 64)), (128, (128, 128)), (192, (192, 192)), (256, (256, 256)), (64, (128,)), (256, (64,))])
+def test_conv1x1_weight_gradient_wide_kernel(L, Cout, cins, monkeypatch):
+    """res_conv / to_out.0 shapes (DD:212, DD:226): the kernel that owns a ci block and ALL output channels (conv_wgrad1_wide_kernel), over
+    one or two concatenated sources and a pixel count that is not a multiple of its 64-pixel tile; against autograd."""
+    torch.manual_seed(7)
+    B, H, W = 2, 13, 21
+    xs = [q(torch.randn(B, c, H, W)).requires_grad_(True) for c in cins]
+    cin = sum(cins)
+    w = (torch.randn(Cout, cin, 1, 1) / math.sqrt(cin)).requires_grad_(True)
+    dy = q(torch.randn(B, Cout, H, W))
+    F.conv2d(torch.cat(xs, 1), w + (q(w) - w).detach()).backward(dy)
+    got_w = wgrad(L, B, H, W, 1, [dict(t=to_nhwc(x.detach())) for x in xs], Cout, to_nhwc(dy), w.detach())
+    assert rel_l2(got_w, w.grad) < TOL, rel_l2(got_w, w.grad)
+
+
 def test_conv_backward_source_modes(L):
     """concat, nearest-x2 up-sampling and pixel-unshuffle loaders: weight gradients through the same
     loaders, data gradients through grad_scatter (slice / 2x2 sum / pixel shuffle)."""
