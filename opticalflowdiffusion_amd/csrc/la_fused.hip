@@ -82,6 +82,7 @@ __device__ __forceinline__ void norm_x(const XRaw<C>& r, float eps, bf16x8 (&xs)
 // write ONE part: a quarter of the partial traffic, and a grid of 256+ workgroups (small batches) stays within the combine's 256 parts.
 // Part format unchanged: [m 32 | l 32 | ctx[d][e] 32 x 32].  LDS: 4 x LA_PART_PITCH floats (rows padded to 36 floats).
 constexpr int LA_PART_PITCH = 64 + 32 * 36;
+constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ void la_store_part(float* lds, float* __restrict__ o, float m, float l, const f32x16& ctxT, int tid, int wave, int l31,
                                               int half) {
     float* mine = lds + wave * LA_PART_PITCH;
@@ -166,19 +167,22 @@ __global__ void __launch_bounds__(256, 2) la_ctx_fused_kernel(const bf16_t* __re
                 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[s], wv, va, 0, 0, 0);   // rows = pixels, col = e
             }
             float mt = -3.0e38f;
+            if (tile * 32 + 32 > n) {            // (only a sample's last tile has rows past its end: 32 compares + selects per head otherwise)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (tile * 32 + acc_row(r, half) >= n) ka[r] = -3.0e38f;
-                mt = fmaxf(mt, ka[r]);
+                for (int r = 0; r < 16; ++r)
+                    if (tile * 32 + acc_row(r, half) >= n) ka[r] = -3.0e38f;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, ka[r]);
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float m_new = fmaxf(m[hd], mt);
             const float f = __expf(m[hd] - m_new);
             m[hd] = m_new;
             float ps = 0.0f;
+            const float m2 = m_new * LOG2E;      // exp(k - m) as exp2(k log2e - m log2e): one fma + v_exp per element instead of sub, mul, v_exp
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __expf(ka[r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(ka[r], LOG2E, -m2));
                 ka[r] = p;
                 ps += p;
             }
@@ -241,19 +245,22 @@ __global__ void __launch_bounds__(256, 2) la_ctx_stored_kernel(const bf16_t* __r
                 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vr[hd * 2 + s2]), ident[s2], va, 0, 0, 0);   // rows = pixels, col = e
             }
             float mt = -3.0e38f;
+            if (tile * 32 + 32 > n) {            // (only a sample's last tile has rows past its end: 32 compares + selects per head otherwise)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (tile * 32 + acc_row(r, half) >= n) ka[r] = -3.0e38f;
-                mt = fmaxf(mt, ka[r]);
+                for (int r = 0; r < 16; ++r)
+                    if (tile * 32 + acc_row(r, half) >= n) ka[r] = -3.0e38f;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, ka[r]);
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float m_new = fmaxf(m[hd], mt);
             const float f = __expf(m[hd] - m_new);
             m[hd] = m_new;
             float ps = 0.0f;
+            const float m2 = m_new * LOG2E;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = bf2f(f2bf(__expf(ka[r] - m_new)));      // the value the context MFMA multiplies by: the normaliser sums the same
+                const float p = bf2f(f2bf(__builtin_amdgcn_exp2f(__builtin_fmaf(ka[r], LOG2E, -m2))));      // the value the context MFMA multiplies by: the normaliser sums the same
                 ka[r] = p;
                 ps += p;
             }
