@@ -85,7 +85,9 @@ __global__ void __launch_bounds__(256) fa_bwd_dq_kernel(const bf16_t* __restrict
         qf[s] = *(const bf16x8*)(base + (size_t)qi * 384 + h * 32 + s * 16 + half * 8);
         gf[s] = *(const bf16x8*)(dout + ((size_t)b * n + qi) * 128 + h * 32 + s * 16 + half * 8);
     }
-    const float lse_q = lse[(size_t)bh * n + qi], dl_q = delta[(size_t)bh * n + qi];
+    // P = exp(scale s - lse) as one fma + v_exp (c = scale log2 e, lse in log2 units); dS = P (dP - delta) scale as P * fma(dP, scale, -delta scale)
+    const float c2 = scale * 1.4426950408889634f;
+    const float lse_q = lse[(size_t)bh * n + qi] * 1.4426950408889634f, dl_q = delta[(size_t)bh * n + qi] * scale;
     f32x16 dq_acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq_acc[r] = 0.0f;
@@ -114,10 +116,12 @@ __global__ void __launch_bounds__(256) fa_bwd_dq_kernel(const bf16_t* __restrict
                 p_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, gf[s], p_acc, 0, 0, 0);     // dP^T[key][q]
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float p = (key < n) ? __expf(s_acc[r] * scale - lse_q) : 0.0f;
-                s_acc[r] = p * (p_acc[r] - dl_q) * scale;                                          // dS^T
+            for (int r = 0; r < 16; ++r)
+                s_acc[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r], c2, -lse_q)) * __builtin_fmaf(p_acc[r], scale, -dl_q);      // dS^T
+            if (j0 + FB_T > n) {                     // keys past the end exist in the last tile only
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= n) s_acc[r] = 0.0f;
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -154,6 +158,7 @@ __global__ void __launch_bounds__(256) fa_bwd_dkv_kernel(const bf16_t* __restric
     f32x16 dk_acc, dv_acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk_acc[r] = 0.0f; dv_acc[r] = 0.0f; }
+    const float c2 = scale * 1.4426950408889634f;      // (as in the dQ kernel; lse_s / dl_s are staged in log2 / scaled units)
     for (int i0 = 0; i0 < n; i0 += FB_T) {
         __syncthreads();
         {
@@ -169,8 +174,8 @@ __global__ void __launch_bounds__(256) fa_bwd_dkv_kernel(const bf16_t* __restric
             stage_transposed(qt_lds, u, slot, qv);
             stage_transposed(gt_lds, u, slot, gv);
             if (u == 0) {
-                lse_s[qq] = ok ? lse[(size_t)bh * n + qg] : 3.0e38f;
-                dl_s[qq] = ok ? delta[(size_t)bh * n + qg] : 0.0f;
+                lse_s[qq] = ok ? lse[(size_t)bh * n + qg] * 1.4426950408889634f : 3.0e38f;      // (log2 units; rows past n: P = 0)
+                dl_s[qq] = ok ? delta[(size_t)bh * n + qg] * scale : 0.0f;
             }
         }
         __syncthreads();
@@ -189,9 +194,9 @@ __global__ void __launch_bounds__(256) fa_bwd_dkv_kernel(const bf16_t* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qq = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float p = __expf(s_acc[r] * scale - lse_s[qq]);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[r], c2, -lse_s[qq]));
                 s_acc[r] = p;
-                p_acc[r] = p * (p_acc[r] - dl_s[qq]) * scale;                                      // dS
+                p_acc[r] = p * __builtin_fmaf(p_acc[r], scale, -dl_s[qq]);                           // dS
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {

@@ -322,28 +322,32 @@ __global__ void __launch_bounds__(256) flash_attn_d32_kernel(const bf16_t* __res
                 s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s_acc[kb], 0, 0, 0);
             }
         }
-        // online softmax; key index of register r: j0 + kb*32 + (r&3) + 8*(r>>2) + 4*half
+        // online softmax; key index of register r: j0 + kb*32 + (r&3) + 8*(r>>2) + 4*half.  The running maximum is kept on the RAW scores
+        // (scale > 0) and exp(scale (s - m)) is one fma + v_exp per element, c = scale log2(e); keys past the end exist in the last tile only.
+        // (the kernel is VALU-bound: 8 MFMAs against 32 score elements per lane and tile -- 9 -> 5 VALU instructions per element)
+        if (j0 + FA_KT > n) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= n) s_acc[kb][r] = -3.0e38f;
+        }
         float mx = -3.0e38f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float sv = s_acc[kb][r] * scale;
-                if (key >= n) sv = -3.0e38f;
-                s_acc[kb][r] = sv;
-                mx = fmaxf(mx, sv);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
+        const float c = scale * 1.4426950408889634f, m2 = m_new * c;
+        const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m_run, c, -m2));
         m_run = m_new;
         float psum = 0.0f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __expf(s_acc[kb][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][r], c, -m2));
                 s_acc[kb][r] = p;
                 psum += p;
             }
@@ -364,7 +368,7 @@ __global__ void __launch_bounds__(256) flash_attn_d32_kernel(const bf16_t* __res
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int q = q0 + l31;
-    if (lse && q < n && half == 0) lse[(size_t)bh * n + q] = m_run + __logf(l_tot);     // kept for the backward
+    if (lse && q < n && half == 0) lse[(size_t)bh * n + q] = m_run * scale + __logf(l_tot);     // kept for the backward (m_run: raw scores)
     if (q < n) {
         bf16_t* dst = out + ((size_t)b * n + q) * 128 + h * 32;
 #pragma unroll
