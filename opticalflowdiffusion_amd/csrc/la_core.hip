@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256) lc_out_kernel(const bf16_t* __restrict__ 
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { q[j] = __expf(q[j] - mx); sum += q[j]; }
+        for (int j = 0; j < 16; ++j) { q[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(q[j], 1.4426950408889634f, -mx * 1.4426950408889634f)); sum += q[j]; }
         sum += __shfl_xor(sum, 32, 64);
         const float k = LC_SCALE * __builtin_amdgcn_rcpf(sum);
 #pragma unroll
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __re
             mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
             float sum = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { q[j] = __expf(q[j] - mx); sum += q[j]; }
+            for (int j = 0; j < 16; ++j) { q[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(q[j], 1.4426950408889634f, -mx * 1.4426950408889634f)); sum += q[j]; }
             sum += __shfl_xor(sum, 1, 64);
             const float k = ok ? LC_SCALE * __builtin_amdgcn_rcpf(sum) : 0.0f;      // pixels past the end contribute nothing
 #pragma unroll
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(256) lc_dctx_partial_rq_kernel(const bf16_t* _
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float sum = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { q[j] = __expf(q[j] - mx); sum += q[j]; }
+            for (int j = 0; j < 16; ++j) { q[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(q[j], 1.4426950408889634f, -mx * 1.4426950408889634f)); sum += q[j]; }
             sum += __shfl_xor(sum, 32, 64);
             const float k = p < cnt ? LC_SCALE * __builtin_amdgcn_rcpf(sum) : 0.0f;
             uint2 qq[4];
@@ -564,7 +564,7 @@ __global__ void __launch_bounds__(256, 2) lc_bwd_apply_kernel(const bf16_t* __re
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float sum = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { q[j] = __expf(q[j] - mx); sum += q[j]; }
+            for (int j = 0; j < 16; ++j) { q[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(q[j], 1.4426950408889634f, -mx * 1.4426950408889634f)); sum += q[j]; }
             sum += __shfl_xor(sum, 32, 64);
             const float rs = __builtin_amdgcn_rcpf(sum);
             float t = 0.0f;

@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256, 2) la_out_fused_kernel(const bf16_t* __re
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float sum = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { qa[r] = __expf(qa[r] - mx); sum += qa[r]; }
+            for (int r = 0; r < 16; ++r) { qa[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(qa[r], LOG2E, -mx * LOG2E)); sum += qa[r]; }
             sum += __shfl_xor(sum, 32, 64);
             const float k = scale / sum;
 #pragma unroll
