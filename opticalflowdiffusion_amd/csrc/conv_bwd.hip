@@ -712,8 +712,9 @@ __global__ void __launch_bounds__(256) wgrad_finish_kernel(const float* __restri
 }
 
 // adjoint of the loader's source modes: D [B][H][W][Ctot] (dgrad output) -> gradient of one source
+template <int mode>      // (compile-time: the four loads of the 2x2 sum are issued together; with a run-time trip count each waited for the previous one)
 __global__ void __launch_bounds__(256) grad_scatter_kernel(const bf16_t* __restrict__ D, int Ctot, int ch_off, bf16_t* __restrict__ dst, int C,
-                                                           int B, int H, int W, int mode, int p1, int p2, int accumulate) {
+                                                           int B, int H, int W, int p1, int p2, int accumulate) {
     // mode 0: same size; 1: dst is (H/2, W/2), sum over the 2x2 block; 2: dst is (2H, 2W), writes sub-pixel (p1, p2)
     const int c8n = C / 8;
     const int DH = mode == 1 ? H / 2 : H, DW_ = mode == 1 ? W / 2 : W;     // iteration space
@@ -725,23 +726,29 @@ __global__ void __launch_bounds__(256) grad_scatter_kernel(const bf16_t* __restr
         r /= DW_;
         const int y = (int)(r % DH), b = (int)(r / DH);
         float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int reps = mode == 1 ? 4 : 1;
+        constexpr int reps = mode == 1 ? 4 : 1;
+        uint4 v[reps];
+#pragma unroll
         for (int k = 0; k < reps; ++k) {
             const int sy = mode == 1 ? 2 * y + (k >> 1) : y, sx = mode == 1 ? 2 * x + (k & 1) : x;
-            const uint4 v = *(const uint4*)(D + (((size_t)b * H + sy) * W + sx) * Ctot + ch_off + cu * 8);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            v[k] = *(const uint4*)(D + (((size_t)b * H + sy) * W + sx) * Ctot + ch_off + cu * 8);
+        }
+        uint4 o = make_uint4(0u, 0u, 0u, 0u);
+        size_t dpix;
+        if (mode == 2) dpix = ((size_t)b * (2 * H) + 2 * y + p1) * (2 * W) + 2 * x + p2;
+        else dpix = ((size_t)b * DH + y) * DW_ + x;
+        bf16_t* d = dst + dpix * C + cu * 8;
+        if (accumulate) o = *(const uint4*)d;
+#pragma unroll
+        for (int k = 0; k < reps; ++k) {
+            const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 a[2 * j] += bf2f((bf16_t)(w[j] & 0xffffu));
                 a[2 * j + 1] += bf2f((bf16_t)(w[j] >> 16));
             }
         }
-        size_t dpix;
-        if (mode == 2) dpix = ((size_t)b * (2 * H) + 2 * y + p1) * (2 * W) + 2 * x + p2;
-        else dpix = ((size_t)b * DH + y) * DW_ + x;
-        bf16_t* d = dst + dpix * C + cu * 8;
         if (accumulate) {
-            const uint4 o = *(const uint4*)d;
             const uint32_t w[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -887,7 +894,11 @@ int k_grad_scatter(const bf16_t* D, int Ctot, int ch_off, bf16_t* dst, int C, in
                    hipStream_t s) {
     OFD_CHECK_ARG(C % 8 == 0 && ch_off % 8 == 0, "grad_scatter: channel window");
     const size_t total = (size_t)B * (mode == 1 ? H / 2 : H) * (mode == 1 ? W / 2 : W) * (C / 8);
-    grad_scatter_kernel<<<sgrid_b(total), 256, 0, s>>>(D, Ctot, ch_off, dst, C, B, H, W, mode, p1, p2, accumulate);
+    // (one 16-byte unit per thread: a read + write kernel without a per-thread preamble runs best uncapped)
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (mode == 1) grad_scatter_kernel<1><<<grid, 256, 0, s>>>(D, Ctot, ch_off, dst, C, B, H, W, p1, p2, accumulate);
+    else if (mode == 2) grad_scatter_kernel<2><<<grid, 256, 0, s>>>(D, Ctot, ch_off, dst, C, B, H, W, p1, p2, accumulate);
+    else grad_scatter_kernel<0><<<grid, 256, 0, s>>>(D, Ctot, ch_off, dst, C, B, H, W, p1, p2, accumulate);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

@@ -413,7 +413,7 @@ static inline int tgrid(size_t total, int cap = 4096) {   // cap = 0: uncapped, 
 
 int k_affine_silu(const bf16_t* h, const float* a, const float* s, bf16_t* out, int B, int H, int W, int C, hipStream_t st) {
     const size_t units = (size_t)B * H * W * (C / 8);
-    affine_silu_kernel<<<tgrid(units), 256, 0, st>>>(h, a, s, out, C, (size_t)H * W, units);
+    affine_silu_kernel<<<tgrid(units, 0), 256, 0, st>>>(h, a, s, out, C, (size_t)H * W, units);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -475,7 +475,7 @@ int k_final_conv_bwd(const bf16_t* x, const float* w, const float* dy, bf16_t* d
 }
 
 int k_grad_add(bf16_t* dst, const bf16_t* src, size_t elems, int accumulate, hipStream_t st) {
-    grad_add_kernel<<<tgrid(elems / 8), 256, 0, st>>>(dst, src, elems / 8, accumulate);
+    grad_add_kernel<<<tgrid(elems / 8, 0), 256, 0, st>>>(dst, src, elems / 8, accumulate);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
