@@ -275,8 +275,8 @@ TAPS = (["init_conv"] + [f"downs.{i}.{j}" for i in range(4) for j in (0, 2, 3)] 
 def test_unet_forward_vs_engine_contract_oracle(L, ch, B, H, W):
     """state-dict names/shapes are the reference's; every tapped stage and the output must follow
     the bf16c oracle (which is pinned to the reference in fp32 by tests/test_oracle_unet.py).
-    (1, 128, 160): a single sample large enough that the full-resolution LinearAttention runs with more than 256 partial
-    contexts per head (the small-batch grid of la_fused.hip, whose combine then recomputes its weights)."""
+    (1, 128, 160): a single sample whose full-resolution LinearAttention takes the small-batch grid of la_fused.hip (80 first-pass
+    workgroups for the one sample instead of the 64-per-sample cap of large batches; one merged part per workgroup)."""
     torch.manual_seed(4)
     P = default_init_params(ch)
     x = torch.randn(B, ch - 3, H, W)
