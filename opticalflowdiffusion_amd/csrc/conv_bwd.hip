@@ -544,18 +544,23 @@ __global__ void __launch_bounds__(512) conv7_wgrad_kernel(const bf16_t* __restri
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][k][r] = 0.0f;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // One 8-wave workgroup per CU (170 registers): nothing else hides a tile's loads, so the tile of step t + 1 is fetched into registers
+    // before the MFMAs of step t and written to LDS after them.
+    constexpr int XU = (XPIX * 2 + 511) / 512;             // 16-byte units of the halo tile per thread (3)
+    u32x4 xr[XU], yr[4];
+    auto fetch = [&](int t) {
         const int b = t / tpi, t_in = t - b * tpi;
         const int oy0 = (t_in / tiles_x) * 8, ox0 = (t_in % tiles_x) * 32;
-        __syncthreads();
-        for (int i = tid; i < XPIX * 2; i += 512) {
+#pragma unroll
+        for (int k = 0; k < XU; ++k) {
+            const int i = min(tid + k * 512, XPIX * 2 - 1);
             const int p = i >> 1, u = i & 1, ty = p / XW, tx = p - ty * XW;
             const int iy = oy0 + ty - 3, ix = ox0 + tx - 3;
             const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
             u32x4 v = *(const u32x4*)(x16 + (((size_t)b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * 16 + u * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
-            *(u32x4*)(xs + p * 32 + u * 16) = v;
+            xr[k] = v;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -565,9 +570,24 @@ __global__ void __launch_bounds__(512) conv7_wgrad_kernel(const bf16_t* __restri
             u32x4 v = *(const u32x4*)(dy + (((size_t)b * H + min(oy, H - 1)) * W + min(ox, W - 1)) * 64 + c8 * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
-            *(u32x4*)(ys + p * 128 + c8 * 16) = v;
+            yr[i] = v;
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();                                   // previous step's fragment reads are complete
+#pragma unroll
+        for (int k = 0; k < XU; ++k) {
+            const int i = tid + k * 512;
+            if (i < XPIX * 2) *(u32x4*)(xs + (i >> 1) * 32 + (i & 1) * 16) = xr[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 512;
+            *(u32x4*)(ys + (id >> 3) * 128 + (id & 7) * 16) = yr[i];
         }
         __syncthreads();
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);      // (after the barrier: its fence would wait for the loads)
         if (dbias) {
             const int co = tid & 63, part = tid >> 6;
             for (int p = part * 32; p < part * 32 + 32; ++p) bsum += bf2f(*(const bf16_t*)(ys + p * 128 + co * 2));
