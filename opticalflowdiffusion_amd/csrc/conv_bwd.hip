@@ -68,7 +68,19 @@ struct WgradParams {
     const float* in_scale;
     const float* in_shift;
     int no_dma;          // A/B switch (OFD_WGRAD_NO_DMA): 3x3 dY tiles through registers
+    // 3x3 only: where output pixel (b, oy, ox) of the (H, W) grid lives in dY: pixel b * dy_bs + (oy * dy_s + dy_y0) * dy_w + ox * dy_s + dy_x0
+    // (plain: dy_bs = H W, dy_w = W, dy_s = 1; one phase of an up-sample conv, see conv_wgrad3_kernel: the stride-2 samples of the 2H x 2W tensor)
+    long dy_bs;
+    int dy_w, dy_s, dy_y0, dy_x0;
 };
+
+// Upsample(x2, nearest) + 3x3 (DD:89-93) as the forward runs it: four phases (a, b) of output pixels (2y + a, 2x + b), each a 2x2-tap conv on the
+// LOW-resolution tensor with sums of the 3x3 weights.  Low-resolution row offset that kernel row K reads in phase a: a = 0 -> (-1, 0, 0), a = 1 -> (0, 0, +1).
+__host__ __device__ constexpr int up2_off(int a, int K) { return a == 0 ? (K == 0 ? -1 : 0) : (K == 2 ? 1 : 0); }
+// taps (ky, kx) of the 3x3 low-resolution weight gradient that phase PH = 2 a + b needs (PH < 0: a plain conv, all nine)
+__host__ __device__ constexpr bool wg3_tap_on(int PH, int ky, int kx) {
+    return PH < 0 || (((PH >> 1) == 0 ? ky <= 1 : ky >= 1) && ((PH & 1) == 0 ? kx <= 1 : kx >= 1));
+}
 
 // column sums of a staged dY tile [256 pixels][64 co] (128-byte rows): thread -> (co, quarter of the pixels)
 __device__ __forceinline__ float ytile_colsum(const unsigned char* ys, int tid) {
@@ -362,7 +374,10 @@ static void launch_wgrad1_wide(const WgradParams& P, size_t npix, int ncib, hipS
 // (ci block, co block): 248 flop per byte, against 83 for one kernel row per workgroup.  The halo rows are
 // walked once; a halo row rr feeds output rows rr, rr-1, rr-2 (ky = 0, 1, 2), whose dY fragments stay in a
 // three-row register window: 8 fragment reads per 18 MFMAs.
-template <bool PRO, bool DMA>      // PRO: SiLU(affine) prologue on the staged input (its own instantiation: the plain one keeps its register budget); DMA: dY tile by global_load_lds
+// PH >= 0 (phase 2 a + b of an up-sample conv): X is the low-resolution tensor, (H, W) its grid, dY the stride-2 samples (2y + a, 2x + b) of the
+// full-resolution gradient; only the 2 x 2 taps the phase reads are multiplied (4 / 9 of the MFMAs, and four launches cover every dY pixel once:
+// 2.25x fewer MACs than the same gradient on the virtual up-sampled tensor), and a tap's sum goes to every 3x3 weight the phase folded into it.
+template <bool PRO, bool DMA, int PH = -1>      // PRO: SiLU(affine) prologue on the staged input (its own instantiation: the plain one keeps its register budget); DMA: dY tile by global_load_lds
 __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P) {
     constexpr int IWK = 34, XROWS = 10, XPIX = XROWS * IWK, YPIX = 256;
     constexpr int XPT = (XPIX * 8 + 255) / 256, YPT = YPIX * 8 / 256;
@@ -399,16 +414,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
             // piece j of wave w = pixels (row 2w + j/4, columns 8 (j%4) .. +7): one per-lane base, uniform offsets per piece
             __syncthreads();     // previous tile's operand reads are complete
             if (oy0 + 8 <= P.H && ox0 + 32 <= P.W) {
-                const bf16_t* base = P.dy + (((size_t)b * P.H + oy0 + wave * 2) * P.W + ox0 + (lane >> 3)) * P.Cout + cob * 64 + (lane & 7) * 8;
+                const bf16_t* base = P.dy + ((size_t)b * P.dy_bs + ((size_t)(oy0 + wave * 2) * P.dy_s + P.dy_y0) * P.dy_w + (ox0 + (lane >> 3)) * P.dy_s + P.dy_x0) * P.Cout +
+                                     cob * 64 + (lane & 7) * 8;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    __builtin_amdgcn_global_load_lds(base + ((size_t)(j >> 2) * P.W + (j & 3) * 8) * P.Cout,
+                    __builtin_amdgcn_global_load_lds(base + ((size_t)(j >> 2) * P.dy_s * P.dy_w + (j & 3) * 8 * P.dy_s) * P.Cout,
                                                      (__attribute__((address_space(3))) void*)(ys + (wave * 8 + j) * 1024), 16, 0, 0);
             } else {
 #pragma unroll 1
                 for (int j = 0; j < 8; ++j) {
                     const int oy = min(oy0 + wave * 2 + (j >> 2), P.H - 1), ox = min(ox0 + (j & 3) * 8 + (lane >> 3), P.W - 1);
-                    const bf16_t* src = P.dy + (((size_t)b * P.H + oy) * P.W + ox) * P.Cout + cob * 64 + (lane & 7) * 8;
+                    const bf16_t* src = P.dy + ((size_t)b * P.dy_bs + ((size_t)oy * P.dy_s + P.dy_y0) * P.dy_w + ox * P.dy_s + P.dy_x0) * P.Cout + cob * 64 + (lane & 7) * 8;
                     __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(ys + (wave * 8 + j) * 1024), 16, 0, 0);
                 }
             }
@@ -465,7 +481,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
             const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
             const bool ok = oy < P.H && ox < P.W;
             yok |= (ok ? 1u : 0u) << i;
-            yr[i] = *(const u32x4*)(P.dy + (((size_t)b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1)) * P.Cout + cob * 64 + c8 * 8);
+            yr[i] = *(const u32x4*)(P.dy + ((size_t)b * P.dy_bs + ((size_t)min(oy, P.H - 1) * P.dy_s + P.dy_y0) * P.dy_w + min(ox, P.W - 1) * P.dy_s + P.dy_x0) * P.Cout + cob * 64 + c8 * 8);
         }
 #pragma unroll
         for (int i = 0; i < YPT; ++i) {
@@ -501,10 +517,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
             for (int xb = 0; xb < 2; ++xb)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
+                    if (!(wg3_tap_on(PH, 0, kx) || wg3_tap_on(PH, 1, kx) || wg3_tap_on(PH, 2, kx))) continue;
                     const bf16x8 xf = tr_frag(xs + ((rr * IWK + xb * 16 + kx) * 64 + cit * 32) * 2, 128, lane);
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky)
-                        if (rr - ky >= 0 && rr - ky < 8)
+                        if (rr - ky >= 0 && rr - ky < 8 && wg3_tap_on(PH, ky, kx))
                             acc[ky][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yw[ky][xb], acc[ky][kx], 0, 0, 0);   // rows = ci, cols = co
                 }
         }
@@ -514,11 +531,13 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
+            // (ky, kx): the 3x3 WEIGHT this sum goes to; a phase adds the sum of the low-resolution tap that weight was folded into
+            const int ay = PH < 0 ? ky : up2_off(PH >> 1, ky) + 1, ax = PH < 0 ? kx : up2_off(PH & 1, kx) + 1;
             float* d = P.dw + ((size_t)(ky * 3 + kx) * P.Cin_total + kc * 64 + cit * 32) * P.Cout + cob * 64 + cot * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
-                atomicAdd(d + (size_t)ci * P.Cout, acc[ky][kx][r]);
+                atomicAdd(d + (size_t)ci * P.Cout, acc[ay][ax][r]);
             }
         }
 }
@@ -812,6 +831,7 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
         cin += s_.channels;
     }
     P.Cin_total = cin; P.dy = dy; P.dw = dw; P.dbias = dbias;
+    P.dy_bs = (long)a->H * a->W; P.dy_w = a->W; P.dy_s = 1; P.dy_y0 = 0; P.dy_x0 = 0;
     OFD_CHECK_ARG(!a->in_scale || (a->in_shift && a->ksize == 3), "conv_wgrad: the input prologue is a 3x3 feature");
     P.in_scale = a->in_scale; P.in_shift = a->in_shift;
     { static const int nd = getenv("OFD_WGRAD_NO_DMA") ? atoi(getenv("OFD_WGRAD_NO_DMA")) : 0; P.no_dma = nd; }
@@ -855,6 +875,41 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
             OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
             OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
             attr = true;
+        }
+        static const bool no_phase = getenv("OFD_NO_WGRAD_PHASES") && atoi(getenv("OFD_NO_WGRAD_PHASES"));
+        static const int phase_min_combos = getenv("OFD_WGRAD_PHASE_MIN_COMBOS") ? atoi(getenv("OFD_WGRAD_PHASE_MIN_COMBOS")) : 4;
+        if (!no_phase && !P.no_dma && !P.in_scale && a->n_src == 1 && P.src[0].mode == 1 && a->H % 2 == 0 && a->W % 2 == 0 && combos >= phase_min_combos) {
+            // up-sample conv: four phase passes on the low-resolution grid (see conv_wgrad3_kernel, PH).  The passes stage as many tiles as the
+            // plain form (the low-resolution halo tile once per phase), so only the MFMA share of the time shrinks: 0.99 -> 0.85 ms (192 -> 128 at
+            // 220 x 512), 0.955 -> 0.80 ms (256 -> 192 at 110 x 256), but 0.99 -> 1.07 ms for the two channel-block pairs of 128 -> 64 at full
+            // resolution, which stays on the plain form
+            static bool attr2 = false;
+            if (!attr2) {
+                OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_kernel<false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+                attr2 = true;
+            }
+            WgradParams Q = P;
+            Q.H = a->H / 2; Q.W = a->W / 2;
+            Q.tiles_x = cdiv(Q.W, 32); Q.tiles_y = cdiv(Q.H, 8);
+            Q.src[0].mode = 0;                   // (SH, SW are the low-resolution dimensions already)
+            Q.dy_s = 2;
+            const int nt2 = Q.tiles_x * Q.tiles_y * Q.B;
+            gx = cdiv(512, combos);
+            if (gx < 1) gx = 1;
+            if (gx > nt2) gx = nt2;
+            for (int ph = 0; ph < 4; ++ph) {
+                Q.dy_y0 = ph >> 1; Q.dy_x0 = ph & 1;
+                if (ph > 0) Q.dbias = P.dbias;   // (every phase adds the column sums of its own dY samples)
+                if (ph == 0) conv_wgrad3_kernel<false, true, 0><<<dim3(gx, combos), 256, LDS, s>>>(Q);
+                else if (ph == 1) conv_wgrad3_kernel<false, true, 1><<<dim3(gx, combos), 256, LDS, s>>>(Q);
+                else if (ph == 2) conv_wgrad3_kernel<false, true, 2><<<dim3(gx, combos), 256, LDS, s>>>(Q);
+                else conv_wgrad3_kernel<false, true, 3><<<dim3(gx, combos), 256, LDS, s>>>(Q);
+            }
+            OFD_LAUNCH_CHECK();
+            return OFD_OK;
         }
         gx = cdiv(512, combos);                  // two workgroups per CU fit (75.5 KB LDS each)
         if (gx < 1) gx = 1;

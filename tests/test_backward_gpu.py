@@ -93,6 +93,20 @@ def test_conv1x1_weight_gradient_wide_kernel(L, Cout, cins, monkeypatch):
     assert rel_l2(got_w, w.grad) < TOL, rel_l2(got_w, w.grad)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 36, 88, 128, 128), (1, 80, 144, 256, 64), (2, 16, 64, 192, 192)])     # (>= 4 channel-block pairs: the phase form)
+def test_upsample_conv_weight_gradient_by_phases(L, B, H, W, Cin, Cout):
+    """Upsample(x2, nearest) + 3x3 (DD:89-93): the weight gradient is taken in four 2x2-tap phase passes on the low-resolution tensor
+    (conv_wgrad3_kernel<.., PH>) and folded back onto the 3x3 weights; against autograd through F.interpolate, at sizes with whole
+    tiles, tile overhang and image borders, with and without weight standardisation's finish step."""
+    torch.manual_seed(11)
+    xs = q(torch.randn(B, Cin, H // 2, W // 2)).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)).requires_grad_(True)
+    dy = q(torch.randn(B, Cout, H, W))
+    F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w + (q(w) - w).detach(), padding=1).backward(dy)
+    got_w = wgrad(L, B, H, W, 3, [dict(t=to_nhwc(xs.detach()), upsample=1)], Cout, to_nhwc(dy), w.detach())
+    assert rel_l2(got_w, w.grad) < TOL, rel_l2(got_w, w.grad)
+
+
 def test_conv_backward_source_modes(L):
     """concat, nearest-x2 up-sampling and pixel-unshuffle loaders: weight gradients through the same
     loaders, data gradients through grad_scatter (slice / 2x2 sum / pixel shuffle)."""
