@@ -241,6 +241,11 @@ typedef struct {
 } ofd_conv_args;
 
 int ofd_conv_forward(const ofd_conv_args* a, void* stream);
+/* the same 3x3 convolution with every 2x2 block of output pixels SUMMED in the epilogue: `out` (and `residual`, added there) is the
+ * (H/2, W/2) tensor.  This is the data gradient of Upsample(x2, nearest) + conv (DD:89-93) taken straight into the low-resolution
+ * source's gradient: a = the data-gradient configuration above (source dY at (H, W), tap-flipped transposed weights).  H, W even,
+ * Cout a multiple of 64 and not the 64 -> 64 case, no split output / GroupNorm statistics / activation residual. */
+int ofd_conv_forward_pool2(const ofd_conv_args* a, void* stream);
 size_t ofd_conv_gn_partial_count(int B, int H, int W, int Cout);   /* floats */
 /* OIHW fp32 -> engine bf16 layout [tap][Cin/8][Cout][8]; eps < 0: plain conv, else weight
  * standardisation with that eps (DD:109-112).  cin_pad: Cin rounded up (7x7: 16).

@@ -86,6 +86,7 @@ SIGNATURES = {
     "ofd_unet_prof_reset": (c_int, [c_void_p]),
     "ofd_unet_prof_dump_path": (c_int, [c_void_p, c_char_p]),
     "ofd_conv_forward": (c_int, [ctypes.POINTER(ConvArgs), c_void_p]),
+    "ofd_conv_forward_pool2": (c_int, [ctypes.POINTER(ConvArgs), c_void_p]),
     "ofd_conv_gn_partial_count": (c_size_t, [c_int] * 4),
     "ofd_conv_weight_elems": (c_size_t, [c_int] * 3),
     "ofd_conv_dgrad_weight_prep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -1115,7 +1115,22 @@ int launch_conv3x3_c64_rw(const ConvParams& P, hipStream_t s);     // conv_rw.hi
 int launch_conv3x3_wp(const ConvParams& P, bool wide, hipStream_t s);   // conv_wp.hip
 int launch_conv1x1_wp(const ConvParams& P, hipStream_t s);              // conv1_wp.hip: 1 = shape not served
 
-int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0) {
+static int conv_wp_bits() {
+    static int use_wp = -1;
+    if (use_wp < 0) { const char* e = getenv("OFD_CONV_WP"); use_wp = e ? atoi(e) : 3; }
+    return use_wp;
+}
+// the pooled epilogue exists in conv_wp.hip only: 3x3, even size, one output tensor, no fused GroupNorm statistics / activation residual
+bool conv_pool2_supported(const ofd_conv_args* a) {
+    static const bool off = getenv("OFD_NO_DGRAD_POOL") && atoi(getenv("OFD_NO_DGRAD_POOL"));
+    if (off || !a || a->ksize != 3 || a->H % 2 || a->W % 2 || a->split || a->gn_partial || a->res_act || a->Cout % 64) return false;
+    int cin = 0;
+    for (int i = 0; i < a->n_src; ++i) { if (a->src[i].unshuffle) return false; cin += a->src[i].channels; }
+    const bool c64 = a->Cout == 64 && cin == 64;
+    return !c64 && (conv_wp_bits() & 3) == 3;
+}
+
+int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0, int pool2) {
     OFD_CHECK_ARG(a && a->out && a->weight, "conv: null out/weight");
     OFD_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0, "conv: bad shape");
     OFD_CHECK_ARG(a->ksize == 1 || a->ksize == 2 || a->ksize == 3 || a->ksize == 7, "conv: ksize %d unsupported", a->ksize);
@@ -1163,6 +1178,8 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0) {
         P.phase_all = a->up2_phase == 5;
     }
     P.cout0 = cout0;
+    P.pool2 = pool2;
+    OFD_CHECK_ARG(!pool2 || conv_pool2_supported(a), "conv: the 2x2-pooled epilogue does not serve this configuration");
     { static int dbg_env = -1; if (dbg_env < 0) { const char* e = getenv("OFD_CONV_DBG"); dbg_env = e ? atoi(e) : 0; } P.dbg = dbg_env; }
     // 128 output channels per workgroup unless that leaves CUs without work: small images (the reference's default 128 x 128 reaches
     // 16 x 16 at the coarsest level: 32 pixel tiles x 4 channel blocks for 256 CUs) take the 64-channel instantiation: twice the
@@ -1221,6 +1238,10 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0) {
 using namespace ofd;
 
 extern "C" int ofd_conv_forward(const ofd_conv_args* a, void* stream) { return conv_forward_impl(a, (hipStream_t)stream, 0); }
+extern "C" int ofd_conv_forward_pool2(const ofd_conv_args* a, void* stream) {
+    OFD_CHECK_ARG(conv_pool2_supported(a), "conv_forward_pool2: 3x3, even H and W, Cout a multiple of 64 (not 64 -> 64), no split / GroupNorm statistics / activation residual");
+    return conv_forward_impl(a, (hipStream_t)stream, 0, 1);
+}
 
 extern "C" size_t ofd_conv_gn_partial_count(int B, int H, int W, int Cout) {
     return (size_t)B * cdiv(H, TH) * cdiv(W, TW) * 4 * (Cout / 8) * 2;     // [b][tile][wave][Cout/8][2]

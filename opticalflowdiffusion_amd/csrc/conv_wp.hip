@@ -223,6 +223,54 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
     float4 bias4[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias4[g] = P.bias ? *(const float4*)(P.bias + cb + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.pool2) {
+        // 2x2 sum-pooled output (ConvParams::pool2): rows 2i, 2i + 1 are two accumulator tiles of this wave, pixels l31, l31 ^ 1 neighbouring
+        // lanes; the even lane stores pooled pixel ((oy0 + 8 ph) / 2 + i, (ox0 + l31) / 2) of the (H/2, W/2) tensor (H, W even: a pooled
+        // pixel is inside the image with all four of its pixels or with none)
+        const int PH2 = P.H >> 1, PW2 = P.W >> 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int py = ((oy0 + 8 * ph) >> 1) + i, px = (ox0 + l31) >> 1;
+            const bool ok = py < PH2 && px < PW2 && !(l31 & 1) && !(P.dbg & 16);
+            const size_t pix = ((size_t)b * PH2 + min(py, PH2 - 1)) * PW2 + min(px, PW2 - 1);
+            uint2 q[4], rr[4];
+            if (r_base) {
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    const uint4 t4 = *(const uint4*)(r_base + pix * o_stride + o_c0 + 8 * g + 8 * half);
+                    const auto sx = __builtin_amdgcn_permlane32_swap(t4.x, t4.z, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(t4.y, t4.w, false, false);
+                    rr[g] = make_uint2(sx[0], sy[0]);
+                    rr[g + 1] = make_uint2(sx[1], sy[1]);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = acc[2 * i][4 * g + k] + acc[2 * i + 1][4 * g + k];
+                    v[k] += __shfl_xor(v[k], 1, 64);
+                }
+                v[0] += 4.0f * bias4[g].x; v[1] += 4.0f * bias4[g].y; v[2] += 4.0f * bias4[g].z; v[3] += 4.0f * bias4[g].w;
+                if (r_base) {
+                    const uint2 t = rr[g];
+                    v[0] += bf2f((bf16_t)(t.x & 0xffffu));
+                    v[1] += bf2f((bf16_t)(t.x >> 16));
+                    v[2] += bf2f((bf16_t)(t.y & 0xffffu));
+                    v[3] += bf2f((bf16_t)(t.y >> 16));
+                }
+                q[g] = make_uint2(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]));
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
+                const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
+                if (ok) *(uint4*)(o_base + pix * o_stride + o_c0 + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int oy = oy0 + 8 * ph + r, ox = ox0 + l31;

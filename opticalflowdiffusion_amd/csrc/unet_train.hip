@@ -100,6 +100,25 @@ static Tensor conv_backward(Bwd& b, const std::string& prefix, const std::vector
         D = t0; D.p = t0.g;
         return D;
     }
+    // Upsample(x2) + 3x3: the data gradient w.r.t. the LOW-resolution source = the 2x2 sum-pool of the gradient w.r.t. the virtual up-sampled
+    // tensor; the conv epilogue pools (ConvParams::pool2) and adds into the source's gradient -- no full-resolution tensor, no scatter pass
+    if (to_source && !add && srcs.size() == 1 && srcs[0].upsample && srcs[0].t.g && d.ksize == 3) {
+        const Tensor& t = srcs[0].t;
+        ofd_conv_args a{};
+        a.B = B; a.H = H; a.W = W; a.ksize = 3; a.n_src = 1; a.Cout = cin;
+        a.src[0].src = dy; a.src[0].channels = d.Cout; a.src[0].src_channels = d.Cout;
+        a.weight = u->d_wtbuf + d.w_off;
+        a.residual = b.has(t) ? t.g : nullptr;
+        a.out = t.g;
+        if (conv_pool2_supported(&a)) {
+            c.begin(PC_DGRAD3, 2.0 * px * d.Cout * (double)d.Cin * taps, px * 2.0 * d.Cout + px * 0.5 * cin, prefix + " dgrad (pooled)");
+            RUN(conv_forward_impl(&a, c.s, 0, 1));
+            c.end();
+            b.mark(t);
+            D = t; D.p = t.g;
+            return D;
+        }
+    }
     if (direct) {
         // (+)= into the source's gradient: the conv epilogue adds `residual`, which may alias the output
         const Tensor& t = srcs[0].t;
@@ -341,8 +360,10 @@ static int run_backward(Ctx& c, const float* dout, const TrainLayout& L, float* 
             default: {
                 const bool first = r.name == "init_conv";
                 const bool direct = direct_target(r.srcs);
-                Tensor D = conv_backward(b, r.name, r.srcs, r.out.g, r.out.H, r.out.W, !first, nullptr, false, direct);
-                if (!first && !direct && c.rc == OFD_OK) scatter_to_sources(b, D, r.srcs);
+                const bool up1 = r.srcs.size() == 1 && r.srcs[0].upsample && r.srcs[0].t.g;      // Upsample + conv: pooled epilogue if the kernel serves it
+                Tensor D = conv_backward(b, r.name, r.srcs, r.out.g, r.out.H, r.out.W, !first, nullptr, false, direct || up1);
+                const bool landed = direct || (up1 && D.p == r.srcs[0].t.g);
+                if (!first && !landed && c.rc == OFD_OK) scatter_to_sources(b, D, r.srcs);
             }
         }
         notify(r.name);

@@ -107,6 +107,34 @@ def test_upsample_conv_weight_gradient_by_phases(L, B, H, W, Cin, Cout):
     assert rel_l2(got_w, w.grad) < TOL, rel_l2(got_w, w.grad)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,acc", [(2, 36, 88, 64, 128, 0), (1, 80, 144, 128, 192, 1), (2, 16, 64, 64, 256, 1)])
+def test_upsample_conv_data_gradient_pooled_epilogue(L, B, H, W, Cin, Cout, acc):
+    """Upsample(x2, nearest) + 3x3 (DD:89-93): the gradient w.r.t. the low-resolution source is the 2x2 sum-pool of the gradient w.r.t. the
+    up-sampled tensor; ofd_conv_forward_pool2 pools in the conv epilogue (and adds to an existing gradient: acc).  Here Cin / Cout are those
+    of the DATA-gradient conv (dY has Cin channels, the source Cout); against autograd through F.interpolate."""
+    torch.manual_seed(13)
+    xs = q(torch.randn(B, Cout, H // 2, W // 2)).requires_grad_(True)
+    w = (torch.randn(Cin, Cout, 3, 3) / math.sqrt(Cout * 9)).requires_grad_(True)          # forward conv: Cout (source) -> Cin (dY) channels
+    dy = q(torch.randn(B, Cin, H, W))
+    F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w + (q(w) - w).detach(), padding=1).backward(dy)
+    wt = torch.empty_like(prep_weight(L, w.detach(), 3))
+    L.check(L.lib().ofd_conv_dgrad_weight_prep(L.ptr(prep_weight(L, w.detach(), 3)), L.ptr(wt), Cin, Cout, 3, L.stream()))
+    dyd = to_nhwc(dy)
+    a = conv_args(L, B, H, W, 3, [dict(t=dyd)], Cout)
+    a.weight = wt.data_ptr()
+    prev = (torch.randn(B, H // 2, W // 2, Cout, device="cuda") * 0.5).to(torch.bfloat16) if acc else None
+    out = torch.empty(B, H // 2, W // 2, Cout, dtype=torch.bfloat16, device="cuda")
+    if acc:
+        out.copy_(prev)
+        a.residual = out.data_ptr()
+    a.out = out.data_ptr()
+    L.check(L.lib().ofd_conv_forward_pool2(ctypes.byref(a), L.stream()))
+    torch.cuda.synchronize()
+    got = from_nhwc(out)
+    want = xs.grad + (from_nhwc(prev) if acc else 0.0)
+    assert rel_l2(got, want) < TOL, rel_l2(got, want)
+
+
 def test_conv_backward_source_modes(L):
     """concat, nearest-x2 up-sampling and pixel-unshuffle loaders: weight gradients through the same
     loaders, data gradients through grad_scatter (slice / 2x2 sum / pixel shuffle)."""
