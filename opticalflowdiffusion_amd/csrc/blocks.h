@@ -11,9 +11,10 @@ struct MlpDesc {            // one ResnetBlock's time-embedding Linear (DD:193-1
     int offset;             // into the per-sample scale/shift row
 };
 
-int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0 = 0, int pool2 = 0);      // cout0: see ConvParams::cout0 (honoured by the streaming 1x1 kernel only
+int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0 = 0, int pool2 = 0, const bf16_t* residual_b = nullptr);      // cout0: see ConvParams::cout0 (honoured by the streaming 1x1 kernel only
                                                                                    // for 64 -> 384 with cout0 = 128; everything else computes all channels)
-bool conv_pool2_supported(const ofd_conv_args* a);                                 // pool2: ConvParams::pool2 (3x3 through conv_wp.hip only)
+bool conv_pool2_supported(const ofd_conv_args* a);
+bool conv_residual_b_supported(const ofd_conv_args* a);                            // residual_b: ConvParams::residual_b (3x3 through conv_wp.hip only)                                 // pool2: ConvParams::pool2 (3x3 through conv_wp.hip only)
 // conv backward (conv_bwd.hip)
 int k_wt_transpose(const bf16_t* w, bf16_t* wt, int taps, int Cin, int Cout, hipStream_t s);
 int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_t s, float* dbias = nullptr);

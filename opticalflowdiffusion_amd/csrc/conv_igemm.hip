@@ -1130,7 +1130,15 @@ bool conv_pool2_supported(const ofd_conv_args* a) {
     return !c64 && (conv_wp_bits() & 3) == 3;
 }
 
-int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0, int pool2) {
+bool conv_residual_b_supported(const ofd_conv_args* a) {
+    static const bool off = getenv("OFD_NO_RESIDUAL_B") && atoi(getenv("OFD_NO_RESIDUAL_B"));
+    if (off || !a || a->ksize != 3 || a->split || a->Cout % 64) return false;
+    for (int i = 0; i < a->n_src; ++i)
+        if (a->src[i].unshuffle) return false;
+    return (conv_wp_bits() & 7) == 7 || ((conv_wp_bits() & 3) == 3 && a->residual);      // (with a residual the 64 -> 64 case is conv_wp's too)
+}
+
+int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0, int pool2, const bf16_t* residual_b) {
     OFD_CHECK_ARG(a && a->out && a->weight, "conv: null out/weight");
     OFD_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0, "conv: bad shape");
     OFD_CHECK_ARG(a->ksize == 1 || a->ksize == 2 || a->ksize == 3 || a->ksize == 7, "conv: ksize %d unsupported", a->ksize);
@@ -1179,6 +1187,8 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0, int pool
     }
     P.cout0 = cout0;
     P.pool2 = pool2;
+    P.residual_b = residual_b;
+    OFD_CHECK_ARG(!residual_b || conv_residual_b_supported(a), "conv: a second residual is served by the conv_wp 3x3 kernels only");
     OFD_CHECK_ARG(!pool2 || conv_pool2_supported(a), "conv: the 2x2-pooled epilogue does not serve this configuration");
     { static int dbg_env = -1; if (dbg_env < 0) { const char* e = getenv("OFD_CONV_DBG"); dbg_env = e ? atoi(e) : 0; } P.dbg = dbg_env; }
     // 128 output channels per workgroup unless that leaves CUs without work: small images (the reference's default 128 x 128 reaches

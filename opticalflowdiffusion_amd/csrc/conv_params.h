@@ -38,6 +38,7 @@ struct ConvParams {
                         // tile run on one XCD at the same time: its input tile comes from that L2 three times out of four)
     int cout0;          // 1x1 streaming kernel: output channels below cout0 are not computed (training to_qkv with q recomputed downstream); 0 = all
     int cy_fast;        // conv_wp: 1-D grid, the channel blocks of a pixel tile adjacent in dispatch order and on one XCD (A/B switch)
+    const bf16_t* residual_b;   // conv_wp 3x3: a second plain residual (same shape as `residual`; training: gradient already in the buffer + the identity-residual gradient)
     int pool2;          // conv_wp 3x3: the epilogue sums every 2x2 block of output pixels and writes the (H/2, W/2) tensor (+ residual there): the
                         // data gradient of Upsample(x2, nearest) + conv lands in the low-resolution source's gradient without a full-size tensor
     int dbg;            // diagnostic ablation bits (OFD_CONV_DBG), 0 in production

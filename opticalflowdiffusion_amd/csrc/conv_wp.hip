@@ -277,6 +277,22 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
         const bool ok = oy < P.H && ox < P.W && !(P.dbg & 16);
         const size_t pix = ((size_t)b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1);
         uint2 q[4], ra[4], rr[4];
+        if (P.residual_b) {      // second plain residual: into the accumulators first (its registers are free again before the loads below)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const uint4 t4 = *(const uint4*)(P.residual_b + pix * o_stride + o_c0 + 8 * g + 8 * half);
+                const auto sx = __builtin_amdgcn_permlane32_swap(t4.x, t4.z, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(t4.y, t4.w, false, false);
+                acc[r][4 * g] += bf2f((bf16_t)(sx[0] & 0xffffu));
+                acc[r][4 * g + 1] += bf2f((bf16_t)(sx[0] >> 16));
+                acc[r][4 * g + 2] += bf2f((bf16_t)(sy[0] & 0xffffu));
+                acc[r][4 * g + 3] += bf2f((bf16_t)(sy[0] >> 16));
+                acc[r][4 * g + 4] += bf2f((bf16_t)(sx[1] & 0xffffu));
+                acc[r][4 * g + 5] += bf2f((bf16_t)(sx[1] >> 16));
+                acc[r][4 * g + 6] += bf2f((bf16_t)(sy[1] & 0xffffu));
+                acc[r][4 * g + 7] += bf2f((bf16_t)(sy[1] >> 16));
+            }
+        }
         if (P.res_act) {
 #pragma unroll
             for (int g = 0; g < 4; g += 2) {

@@ -82,6 +82,7 @@ static Tensor conv_backward(Bwd& b, const std::string& prefix, const std::vector
     c.end();
     if (!need_dx) return D;
     const bool direct = to_source && direct_target(srcs);
+    const bf16_t* res_b = nullptr;
     if (direct && srcs.size() == 2) {
         // split epilogue: (+)= into both sources' gradients; `add` (if any) must already be inside them
         if (add) { set_error("conv_backward: split output takes no extra addend"); c.rc = OFD_ERR_STATE; return D; }
@@ -123,7 +124,15 @@ static Tensor conv_backward(Bwd& b, const std::string& prefix, const std::vector
         // (+)= into the source's gradient: the conv epilogue adds `residual`, which may alias the output
         const Tensor& t = srcs[0].t;
         if (b.has(t) && add) {
-            RUN(k_grad_add(t.g, add, (size_t)B * H * W * cin, 1, c.s));
+            // gradient already in the buffer AND an addend (identity residual): both ride on the conv epilogue when the kernel has the second
+            // residual input; otherwise a separate add pass first
+            ofd_conv_args probe{};
+            probe.ksize = d.ksize; probe.n_src = 1; probe.Cout = cin; probe.residual = t.g;
+            if (conv_residual_b_supported(&probe)) {
+                res_b = add;
+            } else {
+                RUN(k_grad_add(t.g, add, (size_t)B * H * W * cin, 1, c.s));
+            }
             add = t.g;
         } else if (b.has(t)) {
             add = t.g;
@@ -141,7 +150,7 @@ static Tensor conv_backward(Bwd& b, const std::string& prefix, const std::vector
     a.residual = add;
     a.out = D.p;
     c.begin(d.ksize == 3 ? PC_DGRAD3 : PC_DGRAD1, 2.0 * px * d.Cout * (double)d.Cin * taps, px * 2.0 * (d.Cout + cin), prefix + " dgrad");
-    RUN(conv_forward_impl(&a, c.s));
+    RUN(conv_forward_impl(&a, c.s, 0, 0, res_b));
     c.end();
     return D;
 }
