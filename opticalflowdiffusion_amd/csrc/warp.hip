@@ -709,7 +709,7 @@ __global__ void __launch_bounds__(256) grid_warp_kernel(const float* __restrict_
             yr0[j] = min(max(y0, 0), H - 1);
             yr1[j] = min(max(y0 + 1, 0), H - 1);
         }
-#pragma unroll
+#pragma unroll CT > 0 ? CT : 1      // (the run-time channel count instantiation keeps its loop)
         for (int c = 0; c < C; ++c) {
             const float* sp = second + (n * C + c) * plane;
             f32x2u top[4], bot[4];
