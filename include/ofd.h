@@ -187,6 +187,13 @@ int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float* cond, int
  * configuration runs eagerly, the second is captured into a graph and every later one is a single hipGraphLaunch.
  * Bit-identical results.  Ignored while profiling is on (per-kernel events need individual launches). */
 int ofd_unet_set_graph(ofd_unet* u, int enabled);
+/* Two half-batch forwards on two streams (even B >= 2; ignored while profiling or graph replay is on).  Samples are independent
+ * in every kernel of the network (GroupNorm, LinearAttention and attention are per sample: DD:172-268), so samples [0, B/2) run on
+ * `stream` and samples [B/2, B) run the same launch sequence on a second, library-owned stream that starts `offset_blocks` blocks
+ * (ResnetBlock / attention block granularity; < 0 keeps the current value) behind the first: the HBM-bound kernels of one half share
+ * the chip with the MFMA-bound kernels of the other.  `stream` waits for both halves before the call's successors run.  Results are
+ * bit-identical to the one-stream forward per sample.  ofd_unet_workspace_bytes already covers the two half contexts. */
+int ofd_unet_set_split_streams(ofd_unet* u, int enabled, int offset_blocks);
 int ofd_unet_read_tap(ofd_unet* u, const char* name, float* dst, size_t numel, void* stream);
 /* per-kernel-class device time of forwards run with profiling enabled (HIP events on the
  * stream the kernels are launched on).  classes: see ofd_unet_prof_name(). */
@@ -342,9 +349,12 @@ int ofd_gn_finalize(const float* partial, int B, int H, int W, int C, const floa
 /* Batched training augmentation in one pass (replaces the per-sample torchvision pipeline of augmentation.py:6-76 behind
  * FlowDiffuser.preprocess(aug=True), flow_diffuser.py:137-138).  img / tgt (B,3,H,W), flow (B,2,H,W) fp32 NCHW; params (B,16) fp32:
  * 0 jitter on, 1 brightness, 2 contrast, 3 saturation, 4 grayscale on, 5 blur on, 6 sigma, 7 h-flip, 8 v-flip, 9 crop on,
- * 10 oy, 11 ox, 12 ch, 13 cw (crop window origin / size as fractions of the image; 1, 1 without a crop).  means_ws: B*2 doubles. */
+ * 10 oy, 11 ox, 12 ch, 13 cw (crop window origin / size as fractions of the image; 1, 1 without a crop).  means_ws: B*2 doubles.
+ * reference_semantics == 0 (default of the plugin): geometrically consistent flow -- a flip negates the component along the flipped
+ * axis, a crop divides each component by its axis' window fraction.  != 0: the reference's own arithmetic on the flow channels --
+ * flips negate the other channel (augmentation.py:37-45), the crop multiplies channel 0 by ch and channel 1 by cw (augmentation.py:47-48). */
 int ofd_augment(const float* img, const float* tgt, const float* flow, const float* params, void* means_ws, float* out_img,
-                float* out_tgt, float* out_flow, int B, int H, int W, int reference_flip_channels, void* stream);
+                float* out_tgt, float* out_flow, int B, int H, int W, int reference_semantics, void* stream);
 
 #ifdef __cplusplus
 }

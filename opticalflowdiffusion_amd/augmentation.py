@@ -11,9 +11,14 @@ and width are treated separately.  Same structure and probabilities:
                the SAME draw is applied to img and tgt (the reference applies one transform object to both halves, 9-13);
   whole_augs : horizontal flip p = 0.3, vertical flip p = 0.3, random resized crop p = 0.15 (scale 0.8-1.0, ratio 0.9-1.1) resized back
                to (H, W) with the flow vectors rescaled by the crop's zoom per axis.
-Flips negate the flow component along the flipped axis (channel 0 = x, channel 1 = y, SS:368).  [The reference negates the OTHER
-channel (augmentation.py:37-45: `batch[:, -1]` on a horizontal flip), which breaks the img -> tgt correspondence; pass
-`reference_flip_channels=True` to reproduce it.]
+Deviations from the reference, all on purpose and all listed in INTEGRATION.md:
+  * flips negate the flow component along the flipped axis (channel 0 = x, channel 1 = y, SS:368); the reference negates the OTHER
+    channel (augmentation.py:37-45: `batch[:, -1]` on a horizontal flip), which breaks the img -> tgt correspondence;
+  * the crop divides each flow component by its axis' window fraction (a window of width fraction cw is zoomed by 1 / cw); the
+    reference MULTIPLIES, and pairs channel -2 with the height and channel -1 with the width (augmentation.py:47-48);
+  * hue jitter is dropped (above); the random factors are drawn per SAMPLE (the reference draws ColorJitter's factors once per call of
+    the transform and applies the transform sample by sample, 58-64 -- per sample as well, but from torchvision's own RNG stream).
+`reference_semantics=True` reproduces the first two (the flow arithmetic); nothing reproduces torchvision's RNG stream.
 """
 import torch
 import torch.nn.functional as F
@@ -25,10 +30,12 @@ class Augmentor:
 
     NP = 16     # columns of the parameter table (include/ofd.h: ofd_augment)
 
-    def __init__(self, seed=None, reference_flip_channels=False):
+    def __init__(self, seed=None, reference_semantics=False, reference_flip_channels=None):
         self.gen = None
         self.seed = seed
-        self.ref_flip = reference_flip_channels
+        if reference_flip_channels is not None:          # old name of the flag (it covered the flips only)
+            reference_semantics = reference_flip_channels
+        self.ref_flip = bool(reference_semantics)        # the reference's flow arithmetic: swapped flip channels AND its crop scaling
 
     def _rand(self, shape, device):
         """uniforms from the device's default generator (so `torch.manual_seed` and a checkpointed RNG state reproduce the
@@ -108,7 +115,10 @@ class Augmentor:
         grid = torch.stack((gx[:, None, :].expand(B, H, W), gy[:, :, None].expand(B, H, W)), dim=-1)
         out = F.grid_sample(stack, grid, mode="bilinear", padding_mode="border", align_corners=False)
         out = torch.where(v4(9) != 0, out, stack)
-        out = torch.cat((out[:, :6], out[:, 6:7] / v4(13), out[:, 7:8] / v4(12)), dim=1)     # a window of width fraction cw is zoomed by 1 / cw
+        if self.ref_flip:          # augmentation.py:47-48: channel -2 times the height fraction, channel -1 times the width fraction
+            out = torch.cat((out[:, :6], out[:, 6:7] * v4(12), out[:, 7:8] * v4(13)), dim=1)
+        else:                      # a window of width fraction cw is zoomed by 1 / cw
+            out = torch.cat((out[:, :6], out[:, 6:7] / v4(13), out[:, 7:8] / v4(12)), dim=1)
         return out[:, :3], out[:, 3:6], out[:, 6:]
 
     def apply_hip(self, img, tgt, flow, P):

@@ -101,12 +101,15 @@ __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ 
             out_f[0] += w * fsrc[yy * W + xx];
             out_f[1] += w * fsrc[plane + yy * W + xx];
         }
-        // flips negate the flow component along the flipped axis (channel 0 = x); ref_flip: the reference's own (swapped) choice
+        // flips negate the flow component along the flipped axis (channel 0 = x) and a crop window of width fraction cw zooms the
+        // x displacement by 1 / cw.  ref_flip (= reference_semantics): the reference's own choices instead -- the flips negate the
+        // OTHER channel (augmentation.py:37-45) and the crop MULTIPLIES channel 0 by the height fraction, channel 1 by the width
+        // fraction (augmentation.py:47-48: batch[:, -2:] / image_size * (h, w))
         const int cx = ref_flip ? 1 : 0, cy = ref_flip ? 0 : 1;
         if (hf) out_f[cx] = -out_f[cx];
         if (vf) out_f[cy] = -out_f[cy];
-        out_f[0] /= cw;
-        out_f[1] /= ch;
+        if (ref_flip) { out_f[0] *= ch; out_f[1] *= cw; }
+        else { out_f[0] /= cw; out_f[1] /= ch; }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             o_img[((size_t)b * 3 + c) * plane + i] = out_rgb[0][c];
@@ -121,7 +124,7 @@ __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ 
 using namespace ofd;
 
 extern "C" int ofd_augment(const float* img, const float* tgt, const float* flow, const float* params, void* means_ws, float* out_img,
-                           float* out_tgt, float* out_flow, int B, int H, int W, int reference_flip_channels, void* stream) {
+                           float* out_tgt, float* out_flow, int B, int H, int W, int reference_semantics, void* stream) {
     OFD_CHECK_ARG(img && tgt && flow && params && means_ws && out_img && out_tgt && out_flow, "augment: null pointer");
     OFD_CHECK_ARG(B > 0 && H > 1 && W > 1 && (long)H * W < (1L << 30), "augment: bad shape");
     hipStream_t s = (hipStream_t)stream;
@@ -130,7 +133,7 @@ extern "C" int ofd_augment(const float* img, const float* tgt, const float* flow
     int gx = (plane + 255) / 256;
     aug_gray_mean_kernel<<<dim3(gx < 64 ? gx : 64, B * 2), 256, 0, s>>>(img, tgt, (double*)means_ws, plane);
     augment_kernel<<<dim3(gx < 512 ? gx : 512, B), 256, 0, s>>>(img, tgt, flow, params, (const double*)means_ws, out_img, out_tgt, out_flow, H, W,
-                                                                  reference_flip_channels);
+                                                                  reference_semantics);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

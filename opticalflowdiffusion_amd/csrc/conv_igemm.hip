@@ -1117,7 +1117,7 @@ int launch_conv1x1_wp(const ConvParams& P, hipStream_t s);              // conv1
 
 static int conv_wp_bits() {
     static int use_wp = -1;
-    if (use_wp < 0) { const char* e = getenv("OFD_CONV_WP"); use_wp = e ? atoi(e) : 3; }
+    if (use_wp < 0) { const char* e = getenv("OFD_CONV_WP"); use_wp = e ? atoi(e) : 7; }
     return use_wp;
 }
 // the pooled epilogue exists in conv_wp.hip only: 3x3, even size, one output tensor, no fused GroupNorm statistics / activation residual
@@ -1199,7 +1199,7 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0, int pool
     // wave-private-weights kernel (conv_wp.hip): OFD_CONV_WP bit 0 = the 128-channel-block layers, bit 1 = the 64-channel-block
     // layers other than 64 -> 64, bit 2 = 64 -> 64 (instead of the ping-pong kernel)
     static int use_wp = -1;
-    if (use_wp < 0) { const char* e = getenv("OFD_CONV_WP"); use_wp = e ? atoi(e) : 3; }
+    if (use_wp < 0) { const char* e = getenv("OFD_CONV_WP"); use_wp = e ? atoi(e) : 7; }
     if (a->ksize == 3 && use_wp) {
         bool modes_ok = true;
         for (int i = 0; i < a->n_src; ++i) modes_ok = modes_ok && P.src[i].mode != 2;

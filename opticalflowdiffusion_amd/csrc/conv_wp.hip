@@ -16,9 +16,17 @@
 //     (0.42 ds_read_b128 per MFMA against 0.75), every read = one base register + immediate.
 // Workgroup = 4 waves = NS channel slices x PH row blocks: <4,1> = 8 x 32 pixels x 128 channels, <2,2> = 16 x 32 pixels x 64 channels.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "conv_params.h"
 #include "mfma_util.h"
+
+#ifndef OFD_WP_PEEL
+#define OFD_WP_PEEL 1
+#endif
+#ifndef OFD_WP_DOT2
+#define OFD_WP_DOT2 1
+#endif
 
 namespace ofd {
 
@@ -41,6 +49,7 @@ struct Cfg {
 __device__ __forceinline__ float silu_f(float y) { return y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ bf16x8 as_frag(u4 v) { return __builtin_bit_cast(bf16x8, v); }
 
@@ -183,10 +192,45 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
     write_x(0, xs, smem);
 
     const int xrow_off = half * C::US + (8 * ph * IW + l31) * 16;
+    // one 32-channel chunk: 144 MFMAs per wave between two workgroup barriers.  LAST (the peeled final chunk) fetches and stages
+    // nothing: there is no next chunk (a 64-channel layer has two chunks -- re-staging the last one, as the un-peeled loop did to stay
+    // one basic block, was a third of its prologue arithmetic and of its input reads; OFD_WP_PEEL=0 builds that form)
+    auto chunk = [&](const int kc, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int kn = LAST ? kc : kc + 1;
+        if constexpr (!LAST) load_x(kn, xs);
+        __syncthreads();                              // tile kc complete; every wave is done reading the other buffer (chunk kc-1)
+        const unsigned char* xrow = smem + (kc & 1) * C::XB + xrow_off;
+        unsigned char* xnext = smem + ((kc + 1) & 1) * C::XB;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            const int ks = g / 3, kx = g % 3;
+            bf16x8 x[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) x[j] = *(const bf16x8*)(xrow + (j * IW + kx) * 16 + ks * 2 * C::US);
+            bf16x8 a[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int fi = g * 3 + ky;
+                a[ky] = as_frag(ring[fi % RING]);
+                if (fi + RING < FRAGS) ring[fi % RING] = load_w(kc, fi + RING);
+                else if constexpr (!LAST) ring[fi % RING] = load_w(kn, fi + RING - FRAGS);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky], x[r + ky], acc[r], 0, 0, 0);
+            if constexpr (!LAST) { if (g == 1) write_x(kn, xs, xnext); }
+        }
+    };
+#if OFD_WP_PEEL
+    for (int kc = 0; kc < n32 - 1; ++kc) chunk(kc, std::false_type{});
+    chunk(n32 - 1, std::true_type{});
+#else
     for (int kc = 0; kc < n32; ++kc) {
         const int kn = min(kc + 1, n32 - 1);          // past the end: the last chunk again (fetched and staged into the buffer nobody reads any more)
         load_x(kn, xs);
-        __syncthreads();                              // tile kc complete; every wave is done reading the other buffer (chunk kc-1)
+        __syncthreads();
         const unsigned char* xrow = smem + (kc & 1) * C::XB + xrow_off;
         unsigned char* xnext = smem + ((kc + 1) & 1) * C::XB;
 #pragma unroll
@@ -209,6 +253,7 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
             if (g == 1) write_x(kn, xs, xnext);
         }
     }
+#endif
 
     // ---- epilogue: bias, residual forms, bf16 16-byte stores (one v_permlane32_swap per dword pairs two register quads),
     //      GroupNorm partial sums of the values as stored
@@ -335,10 +380,18 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
             }
             q[g] = make_uint2(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]));
             if (P.gn_partial && ok) {
+#if OFD_WP_DOT2
+                // sums of the stored (bf16) values by packed dot products: x . (1, 1) and x . x, two elements per instruction
+                const bf16x2 one = __builtin_bit_cast(bf16x2, 0x3f803f80u);
+                const bf16x2 va = __builtin_bit_cast(bf16x2, q[g].x), vb = __builtin_bit_cast(bf16x2, q[g].y);
+                stat[g * 2] = __builtin_amdgcn_fdot2_f32_bf16(vb, one, __builtin_amdgcn_fdot2_f32_bf16(va, one, stat[g * 2], false), false);
+                stat[g * 2 + 1] = __builtin_amdgcn_fdot2_f32_bf16(vb, vb, __builtin_amdgcn_fdot2_f32_bf16(va, va, stat[g * 2 + 1], false), false);
+#else
                 const float q0 = bf2f((bf16_t)(q[g].x & 0xffffu)), q1 = bf2f((bf16_t)(q[g].x >> 16));
                 const float q2 = bf2f((bf16_t)(q[g].y & 0xffffu)), q3 = bf2f((bf16_t)(q[g].y >> 16));
                 stat[g * 2] += (q0 + q1) + (q2 + q3);
                 stat[g * 2 + 1] += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+#endif
             }
         }
 #pragma unroll

@@ -508,6 +508,8 @@ extern "C" int ofd_unet_bind_param_buffer(ofd_unet* u, float* dev_params, size_t
     OFD_CHECK_ARG(((uintptr_t)dev_params & 15) == 0, "unet_bind_param_buffer: buffer must be 16-byte aligned");
     if (u->owns_params && u->d_params) (void)hipFree(u->d_params);
     drop_graphs(u);
+    // the batched weight-preparation table caches u->P(...) pointers into the OLD buffer: rebuild it on the next prepare
+    if (u->d_prep) { (void)hipFree(u->d_prep); u->d_prep = nullptr; u->n_prep = 0; u->prep_blocks = 0; }
     u->d_params = dev_params;
     u->owns_params = false;
     for (auto& p : u->params) p.set = true;          // the caller's buffer holds every parameter
@@ -556,6 +558,10 @@ extern "C" void ofd_unet_destroy(ofd_unet* u) {
     if (u->d_prep) (void)hipFree(u->d_prep);
     if (u->d_tr) (void)hipFree(u->d_tr);
     drop_graphs(u);
+    if (u->s2) {
+        (void)hipStreamDestroy(u->s2);
+        (void)hipEventDestroy(u->ev_fork); (void)hipEventDestroy(u->ev_join); (void)hipEventDestroy(u->ev_phase);
+    }
     for (auto e : u->pool) (void)hipEventDestroy(e);
     delete u;
 }
@@ -592,7 +598,8 @@ extern "C" int ofd_unet_prepare(ofd_unet* u, void* stream) {
             set_error("unet_prepare: parameter %s was never set", p.name.c_str());
             return OFD_ERR_STATE;
         }
-    // every conv's fp32 OIHW -> prepared bf16 weights in one launch (descriptor table built once: parameter storage does not move)
+    // every conv's fp32 OIHW -> prepared bf16 weights in one launch (descriptor table built once per bound parameter buffer:
+    // ofd_unet_bind_param_buffer drops it, ofd_unet_set_param writes into the same storage)
     if (!u->d_prep) {
         std::vector<ofd_weight_prep_desc> h;
         int blocks = 0;
@@ -639,9 +646,18 @@ static size_t staging_bytes(const ofd_unet* u, int B, int H, int W) {
     return al((size_t)B * u->cfg.channels * H * W * 4) + al((size_t)B * 8) + al((size_t)B * u->cfg.out_dim * H * W * 4);
 }
 
+static size_t workspace_bytes_one(const ofd_unet* u, int B, int H, int W) {
+    return persist_bytes(u, B, H, W) + scratch_bytes(u, B, H, W) + small_bytes(u, B) + 1024 + staging_bytes(u, B, H, W);
+}
+
+// two half-batch forwards on two streams (ofd_unet_set_split_streams): each half owns one half of the workspace
+static size_t half_workspace_bytes(const ofd_unet* u, int B, int H, int W) { return (workspace_bytes_one(u, B / 2, H, W) + 255) / 256 * 256; }
+
 extern "C" size_t ofd_unet_workspace_bytes(const ofd_unet* u, int B, int H, int W) {
     if (!u || B <= 0 || H <= 0 || W <= 0) return 0;
-    return persist_bytes(u, B, H, W) + scratch_bytes(u, B, H, W) + small_bytes(u, B) + 1024 + staging_bytes(u, B, H, W);
+    const size_t one = workspace_bytes_one(u, B, H, W);
+    if (B >= 2 && B % 2 == 0) { const size_t two = 2 * half_workspace_bytes(u, B, H, W); return two > one ? two : one; }
+    return one;
 }
 
 static void drop_graphs(ofd_unet* u) {
@@ -670,19 +686,58 @@ extern "C" int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float
         return OFD_ERR_WORKSPACE;
     }
     OFD_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "unet_forward: workspace must be 256-byte aligned");
-    Ctx c;
-    c.u = u; c.s = (hipStream_t)stream; c.B = B;
+    // lays a forward context of batch `b` over `bytes` of workspace at `w_`
+    auto layout = [&](Ctx& c, int b, char* w_, size_t bytes, hipStream_t s_, float*& temb_, float*& temb_silu_) {
+        c.u = u; c.s = s_; c.B = b;
+        const size_t sb = (small_bytes(u, b) + 255) / 256 * 256;
+        float* fsmall = (float*)w_;
+        c.ss = fsmall;
+        temb_ = fsmall + (size_t)b * u->ss_stride;
+        temb_silu_ = temb_ + (size_t)b * u->cfg.dim * 4;
+        c.persist = w_ + sb;
+        c.persist_cap = persist_bytes(u, b, H, W);
+        c.scratch = c.persist + (c.persist_cap + 255) / 256 * 256;
+        c.scratch_cap = bytes - staging_bytes(u, b, H, W) - (size_t)(c.scratch - w_);
+    };
     char* w = (char*)workspace;
-    const size_t sb = (small_bytes(u, B) + 255) / 256 * 256;
-    float* fsmall = (float*)w;
-    c.ss = fsmall;
-    float* temb = fsmall + (size_t)B * u->ss_stride;
-    float* temb_silu = temb + (size_t)B * u->cfg.dim * 4;
-    c.persist = w + sb;
-    c.persist_cap = persist_bytes(u, B, H, W);
-    c.scratch = c.persist + (c.persist_cap + 255) / 256 * 256;
+    // ---- two half-batches on two streams (DESIGN section 4.1 "co-scheduling"): samples are independent in every kernel of the
+    // network (GroupNorm, LinearAttention and attention are per sample), so half 1 runs the same launch sequence on a second stream,
+    // started `split_offset` blocks behind half 0 -- the MFMA-bound 3x3 kernels of one half share the chip with the HBM-bound
+    // 1x1 / normalisation / LinearAttention kernels of the other instead of running strictly in series
+    if (u->split_streams > 0 && B >= 2 && B % 2 == 0 && !u->profiling && !u->graph_enabled) {
+        if (!u->s2) {
+            OFD_HIP(hipStreamCreateWithFlags(&u->s2, hipStreamNonBlocking));
+            OFD_HIP(hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming));
+            OFD_HIP(hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming));
+            OFD_HIP(hipEventCreateWithFlags(&u->ev_phase, hipEventDisableTiming));
+        }
+        const int hb = B / 2;
+        const size_t hbytes = half_workspace_bytes(u, B, H, W);
+        hipStream_t s1 = (hipStream_t)stream;
+        Ctx c0, c1;
+        float *te0, *ts0, *te1, *ts1;
+        layout(c0, hb, w, hbytes, s1, te0, ts0);
+        layout(c1, hb, w + hbytes, hbytes, u->s2, te1, ts1);
+        const size_t plane = (size_t)H * W;
+        c0.signal_at = u->split_offset; c0.signal_ev = u->ev_phase;
+        OFD_HIP(hipEventRecord(u->ev_fork, s1));                       // the inputs are ready on the caller's stream
+        OFD_HIP(hipStreamWaitEvent(u->s2, u->ev_fork, 0));
+        int rc = run_forward(c0, x, Cx, cond, Cc, t, out, H, W, te0, ts0);
+        if (!c0.signalled) OFD_HIP(hipEventRecord(u->ev_phase, s1));
+        u->taps_half0 = u->taps;
+        OFD_HIP(hipStreamWaitEvent(u->s2, u->ev_phase, 0));
+        int rc1 = run_forward(c1, x + (size_t)hb * Cx * plane, Cx, cond ? cond + (size_t)hb * Cc * plane : nullptr, Cc, t ? t + hb : nullptr,
+                              out + (size_t)hb * u->cfg.out_dim * plane, H, W, te1, ts1);
+        OFD_HIP(hipEventRecord(u->ev_join, u->s2));
+        OFD_HIP(hipStreamWaitEvent(s1, u->ev_join, 0));                // the caller's stream owns the whole output again
+        u->last_split = true;
+        return rc != OFD_OK ? rc : rc1;
+    }
+    u->last_split = false;
+    Ctx c;
+    float *temb, *temb_silu;
+    layout(c, B, w, workspace_bytes, (hipStream_t)stream, temb, temb_silu);
     const size_t stg = staging_bytes(u, B, H, W);
-    c.scratch_cap = workspace_bytes - stg - (size_t)(c.scratch - w);
     if (!u->graph_enabled || u->profiling) return run_forward(c, x, Cx, cond, Cc, t, out, H, W, temb, temb_silu);
 
     // ---- graph replay: stage the inputs at fixed addresses, (capture once and) launch the whole forward as ONE graph
@@ -732,13 +787,27 @@ extern "C" int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float
     return OFD_OK;
 }
 
+extern "C" int ofd_unet_set_split_streams(ofd_unet* u, int enabled, int offset_blocks) {
+    OFD_CHECK_ARG(u, "unet_set_split_streams: null handle");
+    u->split_streams = enabled != 0;
+    if (offset_blocks >= 0) u->split_offset = offset_blocks;
+    return OFD_OK;
+}
+
 extern "C" int ofd_unet_read_tap(ofd_unet* u, const char* name, float* dst, size_t numel, void* stream) {
     OFD_CHECK_ARG(u && name && dst, "unet_read_tap: null argument");
     auto it = u->taps.find(name);
     OFD_CHECK_ARG(it != u->taps.end(), "unet_read_tap: no tap named '%s' in the last forward", name);
     const Tensor& t = it->second;
-    OFD_CHECK_ARG(numel == (size_t)u->last_B * t.C * t.H * t.W, "unet_read_tap: %s has %zu elements, got %zu", name,
-                  (size_t)u->last_B * t.C * t.H * t.W, numel);
+    const int halves = u->last_split ? 2 : 1;            // split forward: last_B is the half batch, u->taps belongs to half 1
+    OFD_CHECK_ARG(numel == (size_t)halves * u->last_B * t.C * t.H * t.W, "unet_read_tap: %s has %zu elements, got %zu", name,
+                  (size_t)halves * u->last_B * t.C * t.H * t.W, numel);
+    if (u->last_split) {
+        const Tensor& t0 = u->taps_half0.at(name);
+        int rc = k_nhwc_to_nchw(t0.p, dst, u->last_B, t.H, t.W, t.C, (hipStream_t)stream);
+        if (rc != OFD_OK) return rc;
+        dst += (size_t)u->last_B * t.C * t.H * t.W;
+    }
     return k_nhwc_to_nchw(t.p, dst, u->last_B, t.H, t.W, t.C, (hipStream_t)stream);
 }
 

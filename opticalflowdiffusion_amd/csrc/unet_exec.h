@@ -131,6 +131,13 @@ struct ofd_unet {
     // last forward: taps
     std::map<std::string, Tensor> taps;
     int last_B = 0;
+    // two half-batch forwards on two streams (ofd_unet_set_split_streams; OFD_SPLIT_STREAMS / OFD_SPLIT_OFFSET give the defaults)
+    int split_streams = getenv("OFD_SPLIT_STREAMS") ? atoi(getenv("OFD_SPLIT_STREAMS")) : 0;
+    int split_offset = getenv("OFD_SPLIT_OFFSET") ? atoi(getenv("OFD_SPLIT_OFFSET")) : 2;   // blocks half 1 starts behind half 0
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_phase = nullptr;
+    std::map<std::string, Tensor> taps_half0;
+    bool last_split = false;
     // profiling
     bool profiling = false;
     std::string dump_path;                    // per-launch CSV (class,label,ms,flops,bytes) appended on resolve
@@ -197,7 +204,14 @@ struct Ctx {
         return t;
     }
     float* tmpf(size_t n) { return (float*)alloc(scratch, scratch_used, scratch_cap, n * 4); }
-    void reset_scratch() { scratch_used = 0; }
+    // split forward: half 0 records `signal_ev` once it has enqueued `signal_at` blocks; half 1's stream waits on it
+    int blocks_done = 0, signal_at = -1;
+    hipEvent_t signal_ev = nullptr;
+    bool signalled = false;
+    void reset_scratch() {
+        scratch_used = 0;
+        if (signal_ev && !signalled && !dry && blocks_done++ >= signal_at) { (void)hipEventRecord(signal_ev, s); signalled = true; }
+    }
 
     // profiling bracket.  Back-to-back regions share an event: the end of one is the start of the next unless something was
     // launched in between (RUN outside a region) -- half the event records, half their cost in the timed region.

@@ -283,6 +283,11 @@ class Unet(nn.Module):
         regimes: small images, long sampling loops); bit-identical, ignored while profiling"""
         L.check(L.lib().ofd_unet_set_graph(self._handle, int(enabled)))
 
+    def set_split_streams(self, enabled=True, offset_blocks=-1):
+        """inference forward of an even batch as two half-batches on two streams, the second `offset_blocks` blocks behind the
+        first (HBM-bound kernels of one half overlap the MFMA-bound kernels of the other); bit-identical per sample"""
+        L.check(L.lib().ofd_unet_set_split_streams(self._handle, int(enabled), int(offset_blocks)))
+
     # -- per-kernel-class device timing (HIP events on the launch stream) ----------------------
     def set_profiling(self, enabled, dump_path=None):
         L.check(L.lib().ofd_unet_set_profiling(self._handle, int(enabled)))
@@ -341,8 +346,12 @@ class ConditionalDiffusion(nn.Module):
     def __init__(self, model, image_size, timesteps=1000, sampling_timesteps=None, objective="pred_v",
                  beta_schedule="sigmoid", schedule_fn_kwargs=dict(), ddim_sampling_eta=0.0, auto_normalize=True,
                  offset_noise_strength=0.0, min_snr_loss_weight=False, min_snr_gamma=5, conditioned=True,
-                 channels=3, noise_space="image"):
+                 channels=3, noise_space="image", ddim_draw_unused_noise=False):
         super().__init__()
+        # ddim_draw_unused_noise (not in the reference): the reference's ddim_sample draws randn_like(img) every step even when
+        # eta == 0 multiplies it by zero (DD:763); the engine skips that draw, so a SEEDED eta == 0 run consumes a different RNG
+        # stream.  True restores the draw (same stream positions as the reference) for seeded comparisons.
+        self.ddim_draw_unused_noise = bool(ddim_draw_unused_noise)
         if objective != "pred_x0" or noise_space != "image" or auto_normalize or offset_noise_strength != 0.0:
             raise NotImplementedError("HIP path: objective='pred_x0', noise_space='image', auto_normalize=False (FD:118-127); "
                                       "noise_space='flow' is broken in the reference itself (warp.py:181-182)")
@@ -464,7 +473,11 @@ class ConditionalDiffusion(nn.Module):
     def _sampling_tables(self, batch, device):
         """per-(T, batch) views of everything a reverse step reads that does not depend on the data: timestep tensors and the
         posterior coefficients, expanded once so that a step indexes a ROW (a view, no gather launch, no allocation)"""
-        key = (batch, str(device))
+        # the key carries the identity AND version of every schedule buffer a row is derived from: load_state_dict of another
+        # schedule, a dtype / device move or an in-place edit of a buffer rebuilds the tables instead of serving stale rows
+        srcs = (self.posterior_mean_coef1, self.posterior_mean_coef2, self.posterior_log_variance_clipped,
+                self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod)
+        key = (batch, str(device)) + tuple((b.data_ptr(), b._version, b.dtype) for b in srcs)
         if getattr(self, "_samp_tab", None) is None or self._samp_tab[0] != key:
             T = self.num_timesteps
             rep = lambda v: v.to(device=device, dtype=torch.float32).reshape(T, 1).repeat(1, batch).contiguous()
@@ -532,13 +545,13 @@ class ConditionalDiffusion(nn.Module):
         c = (1 - alpha_next - sigma ** 2).sqrt()
         coef = torch.stack((alpha_next.sqrt(), c, sigma), dim=1).to(torch.float32).reshape(len(time_pairs), 3, 1).repeat(1, 1, batch).contiguous()
         pong = [torch.empty_like(img), torch.empty_like(img)]
-        noise = torch.empty_like(img) if eta > 0 else None
+        noise = torch.empty_like(img) if (eta > 0 or self.ddim_draw_unused_noise) else None
         lib = L.lib()
         for i, (time, time_next) in enumerate(time_pairs):
             out = L.f32c(self.model_with_condition(img, tab["t"][time], None, external_cond=external_cond))
             last = time_next < 0
             if noise is not None and not last:
-                noise.normal_()                                                          # DD:763
+                noise.normal_()                                                          # DD:763 (eta == 0: only with ddim_draw_unused_noise)
             nxt = pong[i & 1]
             L.check(lib.ofd_ddim_update(L.ptr(img), L.ptr(out), L.ptr(noise) if not last else None, L.ptr(tab["sr"][time]), L.ptr(tab["srm1"][time]),
                                         None if last else L.ptr(coef[i, 0]), None if last else L.ptr(coef[i, 1]), None if last else L.ptr(coef[i, 2]),

@@ -341,6 +341,55 @@ def random_weight_unet():
         save(f"unet_rand_{tag}", **arrays)
 
 
+GRAD_FULL = ("init_conv.weight", "time_mlp.1.weight", "downs.0.0.block1.proj.weight", "downs.0.0.mlp.1.weight",
+             "downs.1.2.fn.fn.to_qkv.weight", "downs.2.0.block2.norm.weight", "downs.3.2.fn.fn.to_out.1.g", "mid_attn.fn.fn.to_out.bias",
+             "mid_block1.block1.proj.bias", "ups.1.2.fn.norm.g", "ups.3.0.res_conv.weight", "ups.3.1.block2.proj.weight",
+             "final_res_block.block1.norm.bias", "final_conv.weight", "final_conv.bias")
+
+
+def random_weight_unet_gradients():
+    """(9) gradients of the DIFFUSION Unet (time_in=True, channels=9) from the reference module itself: (y * gy).sum().backward() under
+    the well-conditioned weights of (8), in fp32 and under bf16 autocast.  Stored: the norm of every one of the 276 parameter
+    gradients in both modes, the per-tensor relative distance between the two (the reference's own bf16-vs-fp32 gradient floor), and
+    fifteen full fp32 gradient tensors spread over the levels.  The HIP backward is asserted against these DIRECTLY
+    (tests/test_backward_gpu.py::test_hip_unet_gradients_against_the_reference_module)."""
+    torch.set_num_threads(8)
+    dd, _ = import_reference()
+    ch, hw = 9, (32, 48)
+    u = dd.Unet(64, channels=ch, out_dim=2)
+    P = random_params({k: tuple(v.shape) for k, v in u.state_dict().items()}, seed=1)
+    u.load_state_dict(P)
+    u.train()                      # (no dropout / batch statistics in this UNet: train() == eval(), DD:272-361)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, ch - 3, *hw, generator=g)
+    cond = torch.rand(2, 3, *hw, generator=g) * 2 - 1
+    gy = torch.randn(2, 2, *hw, generator=g)
+    t = torch.tensor([3, 700])
+    arrays = dict(x=x, cond=cond, t=t, gy=gy, seed=np.int64(1))
+    names = [n for n, _ in u.named_parameters()]
+    grads = {}
+    for mode in ("fp32", "autocast"):
+        u.zero_grad(set_to_none=True)
+        if mode == "fp32":
+            y = u(x, cond, t)
+        else:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                y = u(x, cond, t)
+        (y.float() * gy).sum().backward()
+        arrays[f"y.{mode}"] = y.detach().float()
+        grads[mode] = {n: p.grad.detach().float().clone() for n, p in u.named_parameters()}
+    arrays["names"] = np.asarray(names)
+    arrays["norm.fp32"] = np.asarray([float(grads["fp32"][n].double().norm()) for n in names])
+    arrays["norm.autocast"] = np.asarray([float(grads["autocast"][n].double().norm()) for n in names])
+    arrays["floor"] = np.asarray([float((grads["autocast"][n].double() - grads["fp32"][n].double()).norm() / (grads["fp32"][n].double().norm() + 1e-30))
+                                  for n in names])
+    for n in GRAD_FULL:
+        arrays[f"grad.{n}"] = grads["fp32"][n]
+    fl = arrays["floor"]
+    print(f"276-gradient floor (reference bf16 autocast vs its fp32): median {np.median(fl):.3e}  max {fl.max():.3e} ({names[int(fl.argmax())]})")
+    save("unet_rand_grads_c9_32x48", **arrays)
+
+
 if __name__ == "__main__":
     if "--only-loss-helpers" in sys.argv:
         loss_helpers()
@@ -348,8 +397,11 @@ if __name__ == "__main__":
         regression_unet()
     elif "--only-random-unet" in sys.argv:
         random_weight_unet()
+    elif "--only-random-unet-gradients" in sys.argv:
+        random_weight_unet_gradients()
     else:
         main()
         regression_unet()
         loss_helpers()
         random_weight_unet()
+        random_weight_unet_gradients()

@@ -131,5 +131,18 @@ def test_gpu_augmentor_keeps_the_flow_consistent():
     i3, t3, f3 = OnlyFlipX()((im, tg, fl))
     assert torch.equal(i3, im.flip(-1)) and float(f3[:, 0].mean()) == -3.0 and float(f3[:, 1].abs().max()) == 0.0
     assert torch.allclose(t3[..., :-3], i3[..., 3:])                     # t3(x) = i3(x + 3), i.e. flow x = -3
-    r = OnlyFlipX(reference_flip_channels=True)((im, tg, fl))[2]
+    r = OnlyFlipX(reference_semantics=True)((im, tg, fl))[2]
     assert float(r[:, 0].mean()) == 3.0                                 # the reference's own channel choice leaves x untouched (augmentation.py:37-39)
+    # crop scaling: ours divides each component by its axis' window fraction; reference_semantics multiplies channel 0 by the HEIGHT
+    # fraction and channel 1 by the WIDTH fraction (augmentation.py:47-48: batch[:, -2:] / image_size * (h, w))
+    class OnlyCrop(Augmentor):
+        def draw(self, B, device):
+            P = torch.zeros(B, self.NP, device=device)
+            P[:, 1:4], P[:, 6], P[:, 9] = 1.0, 0.25, 1.0
+            P[:, 10], P[:, 11], P[:, 12], P[:, 13] = 0.05, 0.1, 0.8, 0.9       # oy, ox, ch, cw
+            return P
+    fl2 = torch.zeros(1, 2, H, W)
+    fl2[:, 0], fl2[:, 1] = 3.0, -2.0
+    ours, ref = OnlyCrop()((im, tg, fl2))[2], OnlyCrop(reference_semantics=True)((im, tg, fl2))[2]
+    assert torch.allclose(ours[:, 0], torch.full_like(ours[:, 0], 3.0 / 0.9)) and torch.allclose(ours[:, 1], torch.full_like(ours[:, 1], -2.0 / 0.8))
+    assert torch.allclose(ref[:, 0], torch.full_like(ref[:, 0], 3.0 * 0.8)) and torch.allclose(ref[:, 1], torch.full_like(ref[:, 1], -2.0 * 0.9))

@@ -64,7 +64,10 @@ def test_flow_learner_training_reduces_the_loss_and_samples():
         loss.backward()
         opt.step()
         losses.append(float(loss.detach()))
-    assert losses[1] < losses[0], losses            # the first (sign-of-gradient sized) Adam step is a descent step
+    # Adam's first steps are sign-of-gradient sized (every one of the 35.7 M parameters moves by lr) and the bf16 forward carries
+    # ~1e-2 of rounding noise, so a single step is not guaranteed to descend; within four steps the loss must have gone down
+    print("\n  FlowLearner losses:", [round(v, 5) for v in losses])
+    assert min(losses[1:]) < losses[0], losses
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in fl.parameters())
     with torch.no_grad():
         samples, flow, wts = fl.sample(torch.cat((2 * img - 1, 2 * tgt - 1), dim=1), true_flow)

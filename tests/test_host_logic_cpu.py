@@ -179,6 +179,15 @@ def test_utils_shim_and_import_alias(tmp_path):
         out = torch.load(wu.rewrite_checkpoint_for_compatibility(str(ck)), weights_only=False)
         assert set(out["state_dict"]) == {"unet.final_conv.weight", "_model.final_conv.weight", "model.model.final_conv.weight", "betas"}
         assert out["global_step"] == 7
+        with pytest.raises(FileExistsError):                      # an existing output is not silently replaced
+            wu.rewrite_checkpoint_for_compatibility(str(ck))
+        wu.rewrite_checkpoint_for_compatibility(str(ck), overwrite=True)
+        import argparse                                           # a checkpoint that needs the full unpickler is refused by default
+        bad = tmp_path / "b.ckpt"
+        torch.save({"state_dict": {"unet.final_conv.weight": torch.ones(2)}, "hyper_parameters": argparse.Namespace(lr=1.0)}, bad)
+        with pytest.raises(RuntimeError, match="weights_only"):
+            wu.rewrite_checkpoint_for_compatibility(str(bad))
+        assert wu.rewrite_checkpoint_for_compatibility(str(bad), allow_pickle=True).endswith("b.compat.ckpt")
         da = importlib.import_module("algorithms.diffusion_animation")
         import opticalflowdiffusion_amd as m
         assert da.FlowDiffuser is m.FlowDiffuser and da.Unet is m.Unet and da.ConditionalDiffusion is m.ConditionalDiffusion
@@ -186,3 +195,28 @@ def test_utils_shim_and_import_alias(tmp_path):
         sys.path.remove(shims)
         for m in [k for k in sys.modules if k == "utils" or k.startswith("utils.") or k == "algorithms" or k.startswith("algorithms.")]:
             del sys.modules[m]
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-runs itself under torch.distributed.run as a CHILD process (never an exec:
+    the parent has not touched the GPU, and must not), rendezvous on 127.0.0.1, and returns the child's exit code."""
+    import argparse
+    import importlib
+    import subprocess
+    import sys
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, **kw):
+        seen["cmd"] = cmd
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    rc = bench.self_launch(argparse.Namespace(gpus=4))
+    cmd = seen["cmd"]
+    assert rc == 7
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")

@@ -415,7 +415,7 @@ def test_validation_step_diagnostics(target):
 def test_fused_augmentation_kernel_against_its_tensor_op_restatement():
     """`ofd_augment` (one pass over the batch) against `Augmentor.apply_torch` on the SAME table of per-sample decisions: random
     draws on a non-square batch, then every transform forced on at once (jitter + grayscale + blur + both flips + crop), the
-    reference's swapped flip channels, and the wiring through FlowDiffuser.preprocess(aug=True)."""
+    reference's own flow arithmetic (swapped flip channels, multiplying crop scaling), and the wiring through FlowDiffuser.preprocess(aug=True)."""
     from opticalflowdiffusion_amd import FlowDiffuser
     from opticalflowdiffusion_amd.augmentation import Augmentor
     torch.manual_seed(4)
@@ -423,7 +423,7 @@ def test_fused_augmentation_kernel_against_its_tensor_op_restatement():
     img, tgt = torch.rand(B, 3, H, W, device="cuda"), torch.rand(B, 3, H, W, device="cuda")
     flow = torch.randn(B, 2, H, W, device="cuda") * 5
     for ref_flip in (False, True):
-        a = Augmentor(reference_flip_channels=ref_flip)
+        a = Augmentor(reference_semantics=ref_flip)
         for trial in range(3):
             P = a.draw(B, img.device)
             if trial == 2:                                  # everything at once, for every sample

@@ -505,3 +505,52 @@ def test_eps_sites_are_those_of_rocm_autocast(L):
     diff = {k: (trace[k], table[k]) for k in table if trace[k] != pytest.approx(table[k])}
     assert not diff, diff
     assert torch.isfinite(y.float()).all()
+
+
+def test_forward_follows_the_parameters_after_a_rebind(L):
+    """ofd_unet_bind_param_buffer after a prepare: the batched weight-preparation table caches pointers into the parameter buffer, so
+    a re-bind (every `p.data` replaced: a .cpu()/.cuda() round trip, a dtype cast, a manual edit) must rebuild it -- the next
+    forward has to follow the NEW parameters, not the freed buffer.  Checked against a fresh engine loaded with the same values."""
+    torch.manual_seed(21)
+    P = default_init_params(5)
+    u = make_unet(5, P)
+    x, cond, t = torch.randn(2, 2, 32, 48).cuda(), (torch.rand(2, 3, 32, 48) * 2 - 1).cuda(), torch.tensor([5, 900]).cuda()
+    with torch.no_grad():
+        y0 = u(x, cond, t).clone()
+        junk = []
+        for p in u.parameters():
+            p.data = (p.data * 1.25 + 0.01).clone()         # new storage for every parameter
+            junk.append(torch.full_like(p.data, 1e4))       # and something else where the caching allocator may reuse the old one
+        u._pflat = None                                     # drop the old flat buffer: its memory goes back to the allocator
+        filler = torch.full((u._poffsets[-1] + 4096,), 1e4, device="cuda")
+        y1 = u(x, cond, t).clone()
+        P2 = {n: p.detach().cpu().clone() for n, p in u.named_parameters()}
+        y2 = make_unet(5, P2)(x, cond, t)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y1).all())
+    assert torch.equal(y1, y2), rel_l2(y1.cpu(), y2.cpu())
+    assert rel_l2(y1.cpu(), y0.cpu()) > 1e-2                # the parameters did change the function
+    del junk, filler
+
+
+def test_split_stream_forward_is_bit_identical_per_sample(L):
+    """ofd_unet_set_split_streams: samples [0, B/2) on the caller's stream, [B/2, B) on the library's second stream, `offset` blocks
+    behind.  Every kernel of the network treats samples independently (GroupNorm / LinearAttention / attention per sample,
+    DD:172-268), so outputs and taps must equal the one-stream forward to the bit; an odd batch runs on one stream."""
+    torch.manual_seed(31)
+    u = make_unet(5, default_init_params(5))
+    B, H, W = 4, 40, 72
+    x, cond, t = torch.randn(B, 2, H, W).cuda(), (torch.rand(B, 3, H, W) * 2 - 1).cuda(), torch.tensor([5, 900, 33, 410]).cuda()
+    with torch.no_grad():
+        y1 = u(x, cond, t).clone()
+        taps1 = {n: u.read_tap(n, (B, c, H // s, W // s)).clone() for n, c, s in (("init_conv", 64, 1), ("downs.1.2", 64, 2), ("mid_attn", 512, 8), ("ups.3.2", 64, 1))}
+        for off in (0, 2, 7):
+            u.set_split_streams(True, off)
+            y2 = u(x, cond, t)
+            torch.cuda.synchronize()
+            assert torch.equal(y1, y2), (off, rel_l2(y2.cpu(), y1.cpu()))
+            for n, ref in taps1.items():
+                assert torch.equal(u.read_tap(n, tuple(ref.shape)), ref), (off, n)
+        y3 = u(x[:3], cond[:3], t[:3])                      # odd batch: the one-stream path
+        u.set_split_streams(False)
+        assert torch.equal(y3, u(x[:3], cond[:3], t[:3]))

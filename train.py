@@ -13,6 +13,7 @@ algorithm=flow_diffuser` does through Lightning (experiments/exp_base.py:177-214
 * one JSON line per logged step on rank 0.
 """
 import argparse
+import contextlib
 import json
 import os
 import time
@@ -85,6 +86,8 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--config-dir", default=None, help="a `configurations/` tree laid out as the reference's (config.yaml + experiment/ "
                     "algorithm/ dataset/ groups): composed the way main.py's @hydra.main does, then overlaid on the built-in defaults")
+    ap.add_argument("--grad-bucket-dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="--ddp hook: dtype of the all-reduce buckets (bf16 halves the bytes on the wire; the flat gradient buffer stays fp32)")
     ap.add_argument("--ddp", choices=["hook", "torch"], default="hook", help="multi-GPU gradient averaging: the executor's bucketed "
                     "all-reduce hook (default) or torch.nn.parallel.DistributedDataParallel around the module (what Lightning's DDPStrategy does, exp_base.py:198)")
     ap.add_argument("overrides", nargs="*", help="Hydra-style overrides for --config-dir: group=option, a.b=value, +a.b=value, ~a.b")
@@ -123,7 +126,7 @@ def main(argv=None):
     parallel.broadcast_parameters(fd)
     step_module = fd
     if world > 1 and a.ddp == "hook":
-        parallel.attach_grad_sync(fd)
+        parallel.attach_grad_sync(fd, bucket_dtype=a.grad_bucket_dtype)
     elif world > 1:
         step_module = parallel.TorchDDP(fd, dev)
     opt = fd.configure_optimizers()
@@ -147,8 +150,11 @@ def main(argv=None):
         for micro in range(accum):
             base = ((step * accum + micro) * world + rank) * B            # disjoint samples per rank and step
             batch = ds.batch(base, B, dev)
-            loss = step_module.training_step(batch, step)
-            (loss / accum).backward()
+            # torch DDP: gradients are all-reduced by the LAST micro-batch's backward only (no_sync on the others)
+            hold = step_module.no_sync() if (micro + 1 < accum and hasattr(step_module, "no_sync")) else contextlib.nullcontext()
+            with hold:
+                loss = step_module.training_step(batch, step)
+                (loss / accum).backward()
         opt.step()
         step += 1
         if rank == 0 and (step % a.log_every == 0 or step == a.steps):
