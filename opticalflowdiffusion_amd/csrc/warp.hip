@@ -926,6 +926,270 @@ __global__ void __launch_bounds__(GT_THREADS) grid_warp_tile_kernel(const float*
     }
 }
 
+// Ring variant (C = 3; r03): the tile kernel above runs its phases in series -- while a tile is gathered and written out no window
+// load is in flight, because the three channel windows are ONE buffer group that is refilled only when the whole tile is done
+// (ablation: coordinates 27 + window loads 25 + gathers 20 + stores 17 us of a 73 us launch).  Same tiles, same 3 x 47 KB of LDS,
+// same arithmetic, but the three single-channel windows are a RING over (tile, channel) items: item k is gathered from window
+// k % 3 (= its channel) while the windows of items k + 1 and k + 2 are in flight, and the window an item frees is refilled one
+// barrier later.  One workgroup barrier and one COUNTED vmcnt wait per item:
+//   per wave the VMEM issue order is  ... [DMA(k+2): d pieces] [flow of the next tile: 2, with channel 0] [stores(k): S] ...  (in-order
+//   return), so "all of DMA(k) has landed" = all but the youngest 2 S + d (+ 2) operations have; d = 3 pieces per wave and
+//   channel (2 for the last wave: 47 pieces over 16 waves), S = 2 stores (1 without a mask).  For the count to be the same for every
+//   wave at every item, nothing in the loop is conditional: threads outside the image park their stores in a dump buffer, the
+//   loads past the workgroup's last item fetch that item again (into a window nobody reads any more).
+// The flow loads and the LDS reads of the common path are inline asm: a load the compiler can see makes it drain every outstanding
+// LDS-DMA (vmcnt(0)) before the first use -- the serialisation this variant removes.  Border / out-of-window threads keep the
+// compiler-visible path (correct under any extra wait).  Bit-identical to the kernels above.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// Registers written by an asm load must not be touched before the counted wait that covers the load (a register operand on the
+// wait itself makes the compiler shuffle them into place BEFORE it -- copies of data still in flight).  The waits carry no operands;
+// this empty statement, placed after the wait, is what the consumers of the registers cannot be scheduled above.
+__device__ __forceinline__ void gw_pin(f32x4v& a, f32x4v& b) { asm volatile("" : "+v"(a), "+v"(b) :: "memory"); }
+
+// TH x 64 output tiles, TH * 16 threads, NBUF single-channel windows:
+//   <64, 3>: one 1024-thread workgroup per CU, look-ahead of two items (the form described above);
+//   <32, 2>: two 512-thread workgroups per CU (2 x 67 KB of LDS), look-ahead of one item each.  The waves of ONE workgroup run in step
+//            (a barrier per item), so its phases -- window DMA issue, coordinates, LDS gather, stores -- add up whatever is in flight
+//            (same-box ablation of <64, 3>: skeleton 27 + DMA 15 + gather 8 + stores 12 + divisions 6 us, removals additive); a second,
+//            independent workgroup on the CU is what fills one's memory phases with the other's arithmetic.
+template <int TH, int NBUF>
+struct GwRing {
+    static constexpr int THREADS = TH * 16, WAVES = THREADS / 64;
+    static constexpr int WH = TH + 2 * GT_RY + 1, NV = WH * GT_VPR, NQ = (NV + 63) / 64, CH = NQ * 256;   // window rows, 16-byte vectors, wave-sized pieces, floats
+    static constexpr int PMAX = (NQ + WAVES - 1) / WAVES, PFULL = NQ - (PMAX - 1) * WAVES;                  // pieces per wave: PMAX for waves < PFULL, else PMAX - 1
+    static constexpr int LDS_BYTES = NBUF * CH * 4;
+    static_assert(NBUF == 2 || NBUF == 3, "look-ahead of one or two items");
+};
+
+template <bool MASK, int TH, int NBUF>
+__global__ void __launch_bounds__(TH * 16) grid_warp_ring_kernel(const float* __restrict__ second, const float* __restrict__ flow,
+                                                                 float* __restrict__ out, float* __restrict__ mask, int B, int H, int W,
+                                                                 int tiles_x, int tiles_y, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float win[];
+    using R = GwRing<TH, NBUF>;
+    constexpr int C = 3, S = MASK ? 2 : 1, PMAX = R::PMAX;
+    const size_t plane = (size_t)H * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool three = wave < R::PFULL;                       // this wave issues PMAX pieces per window (else PMAX - 1)
+    const int tpi = tiles_x * tiles_y, ntiles = tpi * B, g = (int)gridDim.x, bidx = (int)blockIdx.x;
+    if (bidx >= ntiles) return;
+    const int nt = (ntiles - 1 - bidx) / g + 1;               // tiles of this workgroup: l = bidx + i g
+    const int xslot = (bidx & 7) * (g >> 3) + (bidx >> 3);    // XCD-aware order inside a full round of g tiles (see grid_warp_tile_kernel)
+    const bool g8 = (g & 7) == 0;
+    // everything about a tile that is the same for the whole workgroup: scalar registers, decoded ONCE per tile
+    struct Tile { int n, ox0, oy0; };
+    auto tile_at = [&](int i) {
+        i = min(i, nt - 1);                                   // past the end: the last tile again (loads that nobody consumes)
+        const int t = (g8 && (i + 1) * g <= ntiles) ? i * g + xslot : bidx + i * g;
+        const int n = t / tpi, t_in = t - n * tpi, ty = t_in / tiles_x;
+        return Tile{n, (t_in - ty * tiles_x) * GT_W, ty * TH};
+    };
+    // per-lane constants of the window pieces this wave issues: piece p = chunk wave + 16 p of a channel window
+    int prow[PMAX], pcol[PMAX];
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) {
+        const int vid = min((wave + R::WAVES * p) * 64 + lane, R::NV - 1);
+        prow[p] = vid / GT_VPR;
+        pcol[p] = (vid - prow[p] * GT_VPR) * 4;
+    }
+    auto issue = [&](const Tile& T, int c, int buf) {         // this wave's pieces of channel c's window of tile T, straight into window `buf`
+        if (dbg & 1) return;                                  // (timing ablation, OFD_GW_DBG: results are wrong with any bit set)
+        const int wx0 = T.ox0 - GT_RX, wy0 = T.oy0 - GT_RY;
+        const float* base = second + ((size_t)T.n * C + c) * plane;
+        const bool interior = wx0 >= 0 && wy0 >= 0 && wx0 + GT_WW <= W && wy0 + R::WH <= H;     // (uniform) no clamping needed
+        auto piece = [&](int p) {
+            int gy = wy0 + prow[p], gx = wx0 + pcol[p];
+            if (!interior) { gy = min(max(gy, 0), H - 1); gx = min(max(gx, 0), W - 4); }
+            const unsigned off = (unsigned)(gy * W + gx) * 4u;
+            __builtin_amdgcn_global_load_lds((const float*)((const char*)base + off),
+                                             (__attribute__((address_space(3))) void*)(win + buf * R::CH + (wave + R::WAVES * p) * 256), 16, 0, 0);
+        };
+#pragma unroll
+        for (int p = 0; p < PMAX - 1; ++p) piece(p);
+        if (three) piece(PMAX - 1);
+    };
+    // this thread's four pixels: row ty, columns tx4 .. tx4 + 3 of the tile.  Threads past the image edge take the last row / the last
+    // quad of columns instead: they repeat a neighbour's work bit for bit and store the same values to the same place, so no load or
+    // store in the loop is conditional (the counted waits need a fixed number of them per wave).
+    const int ty = tid >> 4, tx4 = (tid & 15) * 4;
+    f32x4v f0, f1;
+    auto flow_issue = [&](const Tile& T) {                    // two 16-byte loads the compiler does not count
+        const int y = min(T.oy0 + ty, H - 1), x4 = min(T.ox0 + tx4, W - 4);
+        const unsigned off = (unsigned)(y * W + x4) * 4u;
+        const float* p0 = flow + (size_t)T.n * 2 * plane;
+        const float* p1 = p0 + plane;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f0) : "v"(off), "s"(p0) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f1) : "v"(off), "s"(p1) : "memory");
+    };
+    const unsigned win_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)win;
+
+    // per-tile state of this thread's four pixels (computed once per tile, used by its three channel items)
+    float w[4][4], m[4];
+    unsigned inb[4], inw[4], pixb = 0;
+    int li[4], gi[4];
+    bool inner = true, all_in_window = true;
+    auto coords = [&](const Tile& T) {                         // from the flow registers f0, f1 (which must have landed)
+        const int wx0 = T.ox0 - GT_RX, wy0 = T.oy0 - GT_RY;
+        const int yc = min(T.oy0 + ty, H - 1), xc4 = min(T.ox0 + tx4, W - 4);
+        pixb = (unsigned)(yc * W + xc4) * 4u;
+        const float fl0[4] = {f0.x, f0.y, f0.z, f0.w}, fl1[4] = {f1.x, f1.y, f1.z, f1.w};
+        float wx[4][2], wy[4][2];
+        int x0s[4], y0s[4];
+        inner = true;
+        all_in_window = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float ix, iy;
+            if (dbg & 8) { ix = (float)(xc4 + j) + fl1[j]; iy = (float)yc + fl0[j]; }
+            else grid_coords(fl0[j], fl1[j], xc4 + j, yc, H, W, ix, iy);
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            const bool finite = fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
+            const int x0 = finite ? (int)fx0 : -10, y0 = finite ? (int)fy0 : -10;
+            wx[j][0] = fx0 + 1.0f - ix; wx[j][1] = ix - fx0; wy[j][0] = fy0 + 1.0f - iy; wy[j][1] = iy - fy0;
+            w[j][0] = wx[j][0] * wy[j][0];
+            w[j][1] = wx[j][1] * wy[j][0];
+            w[j][2] = wx[j][0] * wy[j][1];
+            w[j][3] = wx[j][1] * wy[j][1];
+            const int lx = x0 - wx0, ly = y0 - wy0;            // window coordinates of the north-west corner
+            li[j] = ly * GT_WW + lx;
+            gi[j] = y0 * W + x0;
+            x0s[j] = x0; y0s[j] = y0;
+            inner = inner && (unsigned)x0 < (unsigned)(W - 1) && (unsigned)y0 < (unsigned)(H - 1) && (unsigned)lx < (unsigned)(GT_WW - 1) &&
+                    (unsigned)ly < (unsigned)(R::WH - 1);
+        }
+        if (!inner) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x0 = x0s[j], y0 = y0s[j];
+                const float wx0_ = wx[j][0], wx1 = wx[j][1], wy0_ = wy[j][0], wy1 = wy[j][1];
+                const bool bx0 = x0 >= 0 && x0 < W, bx1 = x0 + 1 >= 0 && x0 + 1 < W, by0 = y0 >= 0 && y0 < H, by1 = y0 + 1 >= 0 && y0 + 1 < H;
+                inb[j] = (bx0 && by0 ? 1u : 0u) | (bx1 && by0 ? 2u : 0u) | (bx0 && by1 ? 4u : 0u) | (bx1 && by1 ? 8u : 0u);
+                float ms = 0.0f;                               // sum of in-bounds weights = grid_sample(ones)
+                if (bx0 && by0) ms += wx0_ * wy0_;
+                if (bx1 && by0) ms += wx1 * wy0_;
+                if (bx0 && by1) ms += wx0_ * wy1;
+                if (bx1 && by1) ms += wx1 * wy1;
+                if (ms < 0.999f) ms = 0.0f;                    // WP:116-117
+                if (ms > 0.0f) ms = 1.0f;
+                m[j] = ms;
+                const int lx = x0 - wx0, ly = y0 - wy0;
+                const bool wxa = lx >= 0 && lx < GT_WW, wxb = lx + 1 >= 0 && lx + 1 < GT_WW, wya = ly >= 0 && ly < R::WH, wyb = ly + 1 >= 0 && ly + 1 < R::WH;
+                inw[j] = (wxa && wya ? 1u : 0u) | (wxb && wya ? 2u : 0u) | (wxa && wyb ? 4u : 0u) | (wxb && wyb ? 8u : 0u);
+            }
+            all_in_window = (inw[0] & inw[1] & inw[2] & inw[3]) == 15u;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { inb[j] = 15u; inw[j] = 15u; m[j] = 1.0f; }
+        }
+    };
+    auto gather_store = [&](const Tile& T, int c, int buf) {
+        const size_t cbase = ((size_t)T.n * C + c) * plane;    // (uniform)
+        const float* sp = second + cbase;
+        const float* wc = win + buf * R::CH;
+        float o[4];
+        if (dbg & 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = w[j][0] + w[j][1] + w[j][2] + w[j][3];
+        } else if (inner) {
+            f32x2v top[4], bot[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned a = win_addr + (unsigned)(buf * R::CH + li[j]) * 4u;
+                asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read2_b32 %1, %2 offset0:%3 offset1:%4"
+                             : "=&v"(top[j]), "=&v"(bot[j]) : "v"(a), "n"(GT_WW), "n"(GT_WW + 1) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(top[0]), "+v"(top[1]), "+v"(top[2]), "+v"(top[3]), "+v"(bot[0]), "+v"(bot[1]), "+v"(bot[2]), "+v"(bot[3]) :: "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = top[j].x * w[j][0];
+                acc += top[j].y * w[j][1];
+                acc += bot[j].x * w[j][2];
+                acc += bot[j].y * w[j][3];
+                o[j] = acc;
+            }
+        } else if (all_in_window) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float c0v = wc[li[j]], c1v = wc[li[j] + 1], c2v = wc[li[j] + GT_WW], c3v = wc[li[j] + GT_WW + 1];
+                float acc = 0.0f;
+                if (inb[j] & 1u) acc += c0v * w[j][0];
+                if (inb[j] & 2u) acc += c1v * w[j][1];
+                if (inb[j] & 4u) acc += c2v * w[j][2];
+                if (inb[j] & 8u) acc += c3v * w[j][3];
+                o[j] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float cv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int dl = (k & 1) + (k >> 1) * GT_WW, dg = (k & 1) + (k >> 1) * W;
+                    const bool in_win = (inw[j] >> k) & 1u, in_img = (inb[j] >> k) & 1u;
+                    float v1 = wc[in_win ? li[j] + dl : 0];
+                    asm volatile("" : "+v"(v1));                               // (see grid_warp_tile_kernel)
+                    if (in_img && !in_win) v1 = sp[(size_t)(gi[j] + dg)];      // beyond the staged window: rare
+                    cv[k] = v1;
+                }
+                float acc = 0.0f;
+                if (inb[j] & 1u) acc += cv[0] * w[j][0];
+                if (inb[j] & 2u) acc += cv[1] * w[j][1];
+                if (inb[j] & 4u) acc += cv[2] * w[j][2];
+                if (inb[j] & 8u) acc += cv[3] * w[j][3];
+                o[j] = acc;
+            }
+        }
+        if ((dbg & 4) && o[0] != 12345.0f) return;
+        // unconditional stores: uniform channel base + this thread's 32-bit byte offset
+        *(float4*)((char*)(out + cbase) + pixb) = make_float4(o[0], o[1], o[2], o[3]);
+        if constexpr (MASK) *(float4*)((char*)(mask + cbase) + pixb) = make_float4(m[0], m[1], m[2], m[3]);
+    };
+    auto wait_plain = [&](auto nc) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(nc)::value) : "memory"); };
+
+    Tile T = tile_at(0);
+    flow_issue(T);
+    issue(T, 0, 0);
+    if constexpr (NBUF == 3) issue(T, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gw_pin(f0, f1);
+    coords(T);
+
+    // Counted waits.  Per wave the VMEM issue order of one tile (d = window pieces per wave, S = stores per item) is
+    //   NBUF 3: [flow(next): 2] [DMA(i,2): d] [S] | [DMA(i+1,0): d] [S] | [DMA(i+1,1): d] [S]      item k gathers window k % 3 = its channel
+    //   NBUF 2: [DMA(i,1): d] [flow(next): 2] [S] | [DMA(i,2): d] [S] | [DMA(i+1,0): d] [S]         item k gathers window k % 2
+    // "the window about to be gathered has landed" = all but the youngest N operations have; the flow loads are older than the window
+    // item (i, 2) waits for, so they have landed there as well.
+    constexpr int DA = PMAX, DB = PMAX - 1;
+    constexpr int N0a = NBUF == 3 ? 2 * S + DA : S, N0b = NBUF == 3 ? 2 * S + DB : S;
+    constexpr int N1a = NBUF == 3 ? 2 * S + DA + 2 : S + 2, N1b = NBUF == 3 ? 2 * S + DB + 2 : S + 2;
+    for (int i = 0; i < nt; ++i) {
+        const Tile Tn = tile_at(i + 1);
+        const int k0 = 3 * i;                                  // item index of (i, 0): window of item k is k % NBUF
+        const int b0 = NBUF == 3 ? 0 : (k0 & 1), b1 = NBUF == 3 ? 1 : (b0 ^ 1), b2 = NBUF == 3 ? 2 : b0, b3 = NBUF == 3 ? 0 : (b0 ^ 1);
+        // ---- item (i, 0)
+        if (three) wait_plain(std::integral_constant<int, N0a>{}); else wait_plain(std::integral_constant<int, N0b>{});
+        __builtin_amdgcn_s_barrier();                          // this item's window is complete; everybody is done with the previous item's
+        if constexpr (NBUF == 3) { flow_issue(Tn); issue(T, 2, b2); }
+        else { issue(T, 1, b1); flow_issue(Tn); }
+        gather_store(T, 0, b0);
+        // ---- item (i, 1)
+        if (three) wait_plain(std::integral_constant<int, N1a>{}); else wait_plain(std::integral_constant<int, N1b>{});
+        __builtin_amdgcn_s_barrier();
+        if constexpr (NBUF == 3) issue(Tn, 0, b3); else issue(T, 2, b2);
+        gather_store(T, 1, b1);
+        // ---- item (i, 2): the next tile's flow has landed too
+        if (three) wait_plain(std::integral_constant<int, N0a>{}); else wait_plain(std::integral_constant<int, N0b>{});
+        __builtin_amdgcn_s_barrier();
+        gw_pin(f0, f1);
+        if constexpr (NBUF == 3) issue(Tn, 1, 1); else issue(Tn, 0, b3);
+        gather_store(T, 2, b2);
+        coords(Tn);                                            // the next tile's coordinates, while its windows are in flight
+        T = Tn;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead loads of the last items land before the workgroup gives its LDS back
+}
+
 // Gradient of warp_backward_flow's output with respect to the flow (ATen grid_sampler_2d_backward's grid gradient chained
 // through the reference's normalisation WP:108-109; the thresholded mask has no gradient).  A gather: one thread per pixel.
 __global__ void __launch_bounds__(256) grid_warp_flowgrad_kernel(const float* __restrict__ second, const float* __restrict__ flow,
@@ -1657,7 +1921,35 @@ extern "C" int ofd_grid_warp_fwd(const float* second, const float* flow, float* 
             OFD_HIP(hipFuncSetAttribute((const void*)grid_warp_tile_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES));
             attr = true;
         }
-        if (C == 3) grid_warp_tile_kernel<3><<<gridn, GT_THREADS, GT_LDS_BYTES, s_>>>(second, flow, out, mask, B, C, H, W, tx, ty);
+        // OFD_GW_RING (opt-in, all three measure 72-75 us: the kernel is instruction-issue-bound, profiles/r03_pmc_grid_warp_ring.json): 2 = two 512-thread
+        // workgroups per CU on 32 x 64 tiles, 1 = one 1024-thread workgroup on 64 x 64 tiles,
+        // 0 (default) = the tile kernel above
+        static const int ring = getenv("OFD_GW_RING") ? atoi(getenv("OFD_GW_RING")) : 0;
+        static const int gdbg = getenv("OFD_GW_DBG") ? atoi(getenv("OFD_GW_DBG")) : 0;      // timing ablations only
+        if (C == 3 && ring == 2) {
+            using R = GwRing<32, 2>;
+            static bool rattr = false;
+            if (!rattr) {
+                OFD_HIP(hipFuncSetAttribute((const void*)grid_warp_ring_kernel<true, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, R::LDS_BYTES));
+                OFD_HIP(hipFuncSetAttribute((const void*)grid_warp_ring_kernel<false, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, R::LDS_BYTES));
+                rattr = true;
+            }
+            const int ty2 = cdiv(H, 32), nt2 = B * tx * ty2, grid2 = nt2 < 512 ? nt2 : 512;
+            if (mask) grid_warp_ring_kernel<true, 32, 2><<<grid2, R::THREADS, R::LDS_BYTES, s_>>>(second, flow, out, mask, B, H, W, tx, ty2, gdbg);
+            else grid_warp_ring_kernel<false, 32, 2><<<grid2, R::THREADS, R::LDS_BYTES, s_>>>(second, flow, out, mask, B, H, W, tx, ty2, gdbg);
+        }
+        else if (C == 3 && ring == 1) {
+            using R = GwRing<64, 3>;
+            static bool rattr = false;
+            if (!rattr) {
+                OFD_HIP(hipFuncSetAttribute((const void*)grid_warp_ring_kernel<true, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, R::LDS_BYTES));
+                OFD_HIP(hipFuncSetAttribute((const void*)grid_warp_ring_kernel<false, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, R::LDS_BYTES));
+                rattr = true;
+            }
+            if (mask) grid_warp_ring_kernel<true, 64, 3><<<gridn, R::THREADS, R::LDS_BYTES, s_>>>(second, flow, out, mask, B, H, W, tx, ty, gdbg);
+            else grid_warp_ring_kernel<false, 64, 3><<<gridn, R::THREADS, R::LDS_BYTES, s_>>>(second, flow, out, mask, B, H, W, tx, ty, gdbg);
+        }
+        else if (C == 3) grid_warp_tile_kernel<3><<<gridn, GT_THREADS, GT_LDS_BYTES, s_>>>(second, flow, out, mask, B, C, H, W, tx, ty);
         else if (C == 1) grid_warp_tile_kernel<1><<<gridn, GT_THREADS, GT_LDS_BYTES, s_>>>(second, flow, out, mask, B, C, H, W, tx, ty);
         else if (C == 2) grid_warp_tile_kernel<2><<<gridn, GT_THREADS, GT_LDS_BYTES, s_>>>(second, flow, out, mask, B, C, H, W, tx, ty);
         else grid_warp_tile_kernel<0><<<gridn, GT_THREADS, GT_LDS_BYTES, s_>>>(second, flow, out, mask, B, C, H, W, tx, ty);

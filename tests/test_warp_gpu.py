@@ -225,6 +225,35 @@ def test_grid_sample_warp_full_size_properties(ofd):
     assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), 1.0) + 1e-2
 
 
+@pytest.mark.parametrize("B,H,W", [(16, 440, 1024), (3, 100, 1000), (1, 64, 64)])
+def test_grid_sample_warp_ring_kernel_against_the_oracle_at_size(ofd, B, H, W):
+    """The C = 3 grid_sample warp runs as a RING over (tile, channel) items (warp.hip: grid_warp_ring_kernel): counted waits, look-ahead
+    window loads across tile and sample seams, stores parked for threads outside the image.  At the BASELINE size every persistent
+    workgroup walks seven tiles; (3, 100, 1000) has partial tiles on both axes; one sample carries displacements beyond the staged
+    window (the global-load fallback) and non-finite flows.  Against the CPU oracle (the torch op the reference calls, WP:95-119):
+    mask bit-equal, values within 2e-6; the mask-less entry point (mask = NULL) returns the same image to the bit."""
+    from opticalflowdiffusion_amd._lib import lib, check, ptr, stream
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    img = torch.rand(B, 3, H, W, generator=g)
+    flow = torch.nn.functional.avg_pool2d(torch.randn(B, 2, H, W, generator=g) * 8 * 9, 9, 1, 4).clamp(-20, 20)      # SURVEY 8d flow
+    flow[-1] = (torch.rand(2, H, W, generator=g) * 2 - 1) * 45.0                                                    # beyond the window
+    flow[0, :, H // 3, W // 2] = float("nan")
+    flow[0, 0, H // 2, W // 3] = float("inf")
+    flow[0, 1, 5, 7] = -float("inf")
+    ro, rm = WR.warp_backward_flow(img, flow)
+    o, m = ofd.warp(None, img.cuda(), flow.cuda(), mode="backward")
+    torch.cuda.synchronize()
+    ok = torch.isfinite(ro)                                   # (non-finite grid positions: ATen returns NaN there or 0, see below)
+    assert torch.equal(m.cpu()[ok], rm[ok])
+    assert float((o.cpu()[ok] - ro[ok]).abs().max()) < 2e-6
+    bad = ~torch.isfinite(flow).all(dim=1, keepdim=True).expand_as(ro)
+    assert bool((o.cpu()[bad] == 0).all()) and bool((m.cpu()[bad] == 0).all())      # non-finite target: no corner in bounds (as ATen's zeros padding)
+    o2 = torch.empty_like(o)
+    check(lib().ofd_grid_warp_fwd(ptr(img.cuda()), ptr(flow.cuda()), ptr(o2), None, B, 3, H, W, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(o2, o)
+
+
 def test_splat_full_size_properties(ofd):
     """BASELINE size (16,4,440,1024): mass conservation (sum of the splat == sum of the inputs
     whose four corners stay inside) and zero flow identity."""
