@@ -415,6 +415,7 @@ __global__ void __launch_bounds__(S_NT) splat_tile_fast_kernel(const float* __re
     constexpr int S_U = 7, S_COLS = 128, S_ROWS = S_NT / S_COLS;
     const int col = tid % S_COLS;
     const int xw = wx0 + min(col, ww - 1);
+    const float xlo = (float)(X0 - 1), xhi = (float)(X0 + S_TW), ylo = (float)(Y0 - 1), yhi = (float)(Y0 + S_TH), far_thr = (float)(g.radius - 2);
     for (int r0 = tid / S_COLS; r0 < wh; r0 += S_ROWS * S_U) {
         float f0[S_U], f1[S_U];
 #pragma unroll
@@ -427,10 +428,9 @@ __global__ void __launch_bounds__(S_NT) splat_tile_fast_kernel(const float* __re
         for (int u = 0; u < S_U; ++u) {
             const int r = r0 + u * S_ROWS, y = wy0 + min(r, wh - 1), x = xw;
             const float fx = (float)x + f0[u], fy = (float)y + f1[u];
-            const bool ok = r < wh && col < ww && isfinite(fx) && isfinite(fy);
-            const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
-            const int lx0 = x0 - X0, ly0 = y0 - Y0;
-            const bool touches = ok && (lx0 >= -1) && (lx0 < S_TW) && (ly0 >= -1) && (ly0 < S_TH);
+            // "the target touches the tile" as four float compares: for an integer bound b, floor(f) >= b <=> f >= b and floor(f) < b
+            // <=> f < b; NaN and +-inf fail one of them (r03: was isfinite x 2, floor / clamp / int conversion x 2, four int compares)
+            const bool touches = r < wh && col < ww && fx >= xlo && fx < xhi && fy >= ylo && fy < yhi;
             // append (r, col) to the list: one LDS atomic per wave
             const unsigned long long m = __ballot(touches);
             unsigned base = 0;
@@ -447,13 +447,14 @@ __global__ void __launch_bounds__(S_NT) splat_tile_fast_kernel(const float* __re
                     const int pix = y * g.W + x;
 #pragma unroll
                     for (int c = 0; c < S_CG; ++c) v[c] = (c < cg) ? in_n[(size_t)c * plane + pix] : 0.0f;
-                    sf_accumulate(acc, flags, v, kd, fx, fy, x0, y0, X0, Y0, g.Wo, g.Ho, cg);
+                    sf_accumulate(acc, flags, v, kd, fx, fy, floor_to_int(fx), floor_to_int(fy), X0, Y0, g.Wo, g.Ho, cg);
                 }
             }
-            // far corners (|displacement| > radius): as in the general kernel, by the workgroup that owns the source pixel
-            const bool own = ok && (x >= fx0) && (x < fx1) && (y >= fy0) && (y < fy1);
-            const bool maybe_far = fabsf(fx - (float)x) >= (float)(g.radius - 2) || fabsf(fy - (float)y) >= (float)(g.radius - 2);
-            if (own && c0 == 0 && maybe_far) {
+            // far corners (|displacement| > radius): as in the general kernel, by the workgroup that owns the source pixel -- behind
+            // a prefilter on the raw flow (a corner is at most 1 px beyond the target: the 2 px margin covers it and the rounding of x + flow)
+            if (c0 == 0 && (fabsf(f0[u]) >= far_thr || fabsf(f1[u]) >= far_thr) && r < wh && col < ww && isfinite(fx) && isfinite(fy) &&
+                (x >= fx0) && (x < fx1) && (y >= fy0) && (y < fy1)) {
+                const int x0 = floor_to_int(fx), y0 = floor_to_int(fy);
                 unsigned mask = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -1707,13 +1708,6 @@ static int splat_launch(const float* in, const float* flow, float* out, const Sp
     unsigned int* absmax = (unsigned int*)((char*)workspace + 16);
     unsigned long long* list = (unsigned long long*)((char*)workspace + 16 + (size_t)B * S_MAXC * 4);
     const unsigned cap = (unsigned)((size_t)B * H * W);
-    OFD_HIP(hipMemsetAsync(count, 0, 16 + (size_t)B * C * 4, s));
-    {
-        const size_t plane = (size_t)H * W;
-        int gx = (int)((plane / 4 + 255) / 256);
-        gx = gx < 1 ? 1 : (gx > 24 ? 24 : gx);
-        splat_absmax_kernel<<<dim3(gx, B * C), 256, 0, s>>>(in, absmax, plane);
-    }
     static bool attr = false;
     if (!attr) {
         OFD_HIP(hipFuncSetAttribute((const void*)splat_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
@@ -1724,6 +1718,13 @@ static int splat_launch(const float* in, const float* flow, float* out, const Sp
     if (no_fast < 0) { const char* e = getenv("OFD_SPLAT_NO_FAST"); no_fast = (e && atoi(e)) ? 1 : 0; }
     // fast path: identity remap and a window that fits the 7-bit list coordinates (radius <= 32)
     const bool fast = g.scale == 1 && g.ox == 0 && g.oy == 0 && !g.grid && g.pyr_L == 0 && g.radius >= 3 && S_TW + 2 * g.radius <= 128 && !no_fast;
+    {
+        OFD_HIP(hipMemsetAsync(count, 0, 16 + (size_t)B * C * 4, s));
+        const size_t plane = (size_t)H * W;
+        int gx = (int)((plane / 4 + 255) / 256);
+        gx = gx < 1 ? 1 : (gx > 24 ? 24 : gx);
+        splat_absmax_kernel<<<dim3(gx, B * C), 256, 0, s>>>(in, absmax, plane);
+    }
     for (int c0 = 0; c0 < C; c0 += S_CG) {
         const int cg = (C - c0 < S_CG) ? (C - c0) : S_CG;
         if (fast) splat_tile_fast_kernel<<<g.ntx * g.nty * B, S_NT, SF_LDS_BYTES, s>>>(in, flow, out, list, count, cap, absmax, g, c0, cg);

@@ -69,6 +69,42 @@ def test_splat_far_displacements_and_nonfinite(ofd):
         assert rel_l2(out, ref) < 1e-6, radius
 
 
+def test_splat_converging_flows_and_wide_dynamic_range(ofd):
+    """The scale-1 forward splat keeps its accumulators as 64-bit fixed point, 44 fraction bits below the largest finite |in| of the
+    (sample, channel) plane (warp.hip: splat_tile_fast_kernel).  (1) flows converging on one tile overflow its survivor list: the
+    overflow entries are accumulated in place; (2) a plane whose values span six decades keeps 1e-6 relative accuracy in its small
+    region (the documented limit: relative error = 2^-44 x plane maximum / value); (3) non-finite inputs raise the IEEE result at
+    their corners only.  Against oracle/splat_ref.c."""
+    from opticalflowdiffusion_amd.softsplat import splat_forward
+    torch.manual_seed(6)
+    B, C, H, W = 2, 4, 192, 256
+    img = torch.rand(B, C, H, W) + 0.1
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    flow = torch.zeros(B, 2, H, W)
+    # sample 0: two bundles of pixels converge on the tile x 64..127, y 64..127: more than 6144 survivors for that tile
+    near = ((xx - 100).abs() <= 24) & ((yy - 96).abs() <= 24)
+    flow[0, 0] = torch.where(near, 100.3 - xx, torch.rand(H, W) * 4 - 2)
+    flow[0, 1] = torch.where(near, 96.6 - yy, torch.rand(H, W) * 4 - 2)
+    near2 = ((xx - 70).abs() <= 30) & ((yy - 110).abs() <= 14)
+    flow[0, 0] = torch.where(near2 & ~near, 75.5 - xx + (xx % 7) * 0.37, flow[0, 0])
+    flow[0, 1] = torch.where(near2 & ~near, 100.25 - yy + (yy % 5) * 0.61, flow[0, 1])
+    flow[1] = (torch.rand(2, H, W) * 2 - 1) * 9.0
+    img[1, :, :, :128] *= 1e-3
+    img[1, :, :, 128:] *= 1e3
+    img[1, 2, 40, 200] = float("inf")
+    img[1, 1, 41, 30] = float("nan")
+    ref = WR.splat_out(img, flow)
+    out = splat_forward(img.cuda(), flow.cuda()).cpu()
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isnan(out), torch.isnan(ref)) and torch.equal(torch.isinf(out), torch.isinf(ref))
+    assert rel_l2(out[0], ref[0]) < 1e-6
+    small, big = (slice(None), slice(None), slice(0, 100)), (slice(None), slice(None), slice(160, 256))
+    o1, r1, f1 = out[1], ref[1], fin[1]
+    assert rel_l2(torch.where(f1, o1, torch.zeros_like(o1))[small], torch.where(f1, r1, torch.zeros_like(r1))[small]) < 1e-6
+    assert rel_l2(torch.where(f1, o1, torch.zeros_like(o1))[big], torch.where(f1, r1, torch.zeros_like(r1))[big]) < 1e-6
+    assert 0 < float(r1[0, :, :100].abs().max()) < 1e-1 and float(r1[0, :, 160:].abs().max()) > 1e2      # the fixture does span the decades
+
+
 def test_splat_backward_kernels(ofd):
     from opticalflowdiffusion_amd._lib import lib, check, ptr, stream
     torch.manual_seed(6)
