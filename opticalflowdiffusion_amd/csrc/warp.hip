@@ -58,6 +58,28 @@ __device__ __forceinline__ void grid_coords(float flow_c0, float flow_c1, int x,
     iy = ((vy + 1.0f) / 2.0f) * (float)(H - 1);
 }
 
+// a / b with r = RN(1 / b) prepared once: the multiply + two residual corrections of the hardware's own IEEE division sequence
+// (v_rcp refinement, scaling and fix-up dropped: b is a small positive integer, r is already correctly rounded).  Bit-identical
+// to a / b for finite a in the normal range (brute-forced against IEEE division on 1.1e8 numerators x 14 divisors, and by the
+// index-parity tests against ATen); a = +-inf gives NaN instead of inf, which every caller treats alike (non-finite target).
+// 5 instructions instead of 11.
+__device__ __forceinline__ float div_by_const(float a, float b, float r) {
+    float q = a * r;
+    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+    return q;
+}
+// grid_coords with the two divisions done that way (dw = max(W - 1, 1) as float, rw = 1 / dw; same for H)
+__device__ __forceinline__ void grid_coords_rcp(float flow_c0, float flow_c1, int x, int y, int H, int W, float dw, float rw, float dh, float rh,
+                                                float& ix, float& iy) {
+    const float gx = (float)x + flow_c1;
+    const float gy = (float)y + flow_c0;
+    const float vx = div_by_const(2.0f * gx, dw, rw) - 1.0f;          // WP:108
+    const float vy = div_by_const(2.0f * gy, dh, rh) - 1.0f;          // WP:109
+    ix = ((vx + 1.0f) / 2.0f) * (float)(W - 1);                       // ATen align_corners un-normalise
+    iy = ((vy + 1.0f) / 2.0f) * (float)(H - 1);
+}
+
 // variant 0: forward (SS:374-390), 1: ingrad (SS:515-533), 2: flowgrad (SS:628-647).
 // Same float/double mix as the reference source: the bare 1.0 literals are double.
 template <int VARIANT>
@@ -988,22 +1010,29 @@ __global__ void __launch_bounds__(TH * 16) grid_warp_ring_kernel(const float* __
     };
     // per-lane constants of the window pieces this wave issues: piece p = chunk wave + 16 p of a channel window
     int prow[PMAX], pcol[PMAX];
+    unsigned poff[PMAX];                                      // byte offset of the piece's 16 bytes from the window origin (no clamping: interior windows)
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) {
         const int vid = min((wave + R::WAVES * p) * 64 + lane, R::NV - 1);
         prow[p] = vid / GT_VPR;
         pcol[p] = (vid - prow[p] * GT_VPR) * 4;
+        poff[p] = (unsigned)(prow[p] * W + pcol[p]) * 4u;
     }
     auto issue = [&](const Tile& T, int c, int buf) {         // this wave's pieces of channel c's window of tile T, straight into window `buf`
         if (dbg & 1) return;                                  // (timing ablation, OFD_GW_DBG: results are wrong with any bit set)
         const int wx0 = T.ox0 - GT_RX, wy0 = T.oy0 - GT_RY;
         const float* base = second + ((size_t)T.n * C + c) * plane;
         const bool interior = wx0 >= 0 && wy0 >= 0 && wx0 + GT_WW <= W && wy0 + R::WH <= H;     // (uniform) no clamping needed
+        // interior window (62 % of the tiles at 440 x 1024): uniform base of the window origin + the lane's precomputed offset, no
+        // per-piece arithmetic; border windows clamp row and column (positions outside the image are never read back)
+        const float* wbase = base + (interior ? wy0 * W + wx0 : 0);
         auto piece = [&](int p) {
-            int gy = wy0 + prow[p], gx = wx0 + pcol[p];
-            if (!interior) { gy = min(max(gy, 0), H - 1); gx = min(max(gx, 0), W - 4); }
-            const unsigned off = (unsigned)(gy * W + gx) * 4u;
-            __builtin_amdgcn_global_load_lds((const float*)((const char*)base + off),
+            unsigned off = poff[p];
+            if (!interior) {
+                const int gy = min(max(wy0 + prow[p], 0), H - 1), gx = min(max(wx0 + pcol[p], 0), W - 4);
+                off = (unsigned)(gy * W + gx) * 4u;
+            }
+            __builtin_amdgcn_global_load_lds((const float*)((const char*)wbase + off),
                                              (__attribute__((address_space(3))) void*)(win + buf * R::CH + (wave + R::WAVES * p) * 256), 16, 0, 0);
         };
 #pragma unroll
@@ -1024,6 +1053,7 @@ __global__ void __launch_bounds__(TH * 16) grid_warp_ring_kernel(const float* __
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(f1) : "v"(off), "s"(p1) : "memory");
     };
     const unsigned win_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)win;
+    const float dwf = (float)max(W - 1, 1), dhf = (float)max(H - 1, 1), rwf = 1.0f / dwf, rhf = 1.0f / dhf;
 
     // per-tile state of this thread's four pixels (computed once per tile, used by its three channel items)
     float w[4][4], m[4];
@@ -1032,6 +1062,8 @@ __global__ void __launch_bounds__(TH * 16) grid_warp_ring_kernel(const float* __
     bool inner = true, all_in_window = true;
     auto coords = [&](const Tile& T) {                         // from the flow registers f0, f1 (which must have landed)
         const int wx0 = T.ox0 - GT_RX, wy0 = T.oy0 - GT_RY;
+        const int ixlo = max(0, wx0), iylo = max(0, wy0);
+        const unsigned ixspan = (unsigned)(min(W, wx0 + GT_WW) - 2 - ixlo), iyspan = (unsigned)(min(H, wy0 + R::WH) - 2 - iylo);
         const int yc = min(T.oy0 + ty, H - 1), xc4 = min(T.ox0 + tx4, W - 4);
         pixb = (unsigned)(yc * W + xc4) * 4u;
         const float fl0[4] = {f0.x, f0.y, f0.z, f0.w}, fl1[4] = {f1.x, f1.y, f1.z, f1.w};
@@ -1043,7 +1075,7 @@ __global__ void __launch_bounds__(TH * 16) grid_warp_ring_kernel(const float* __
         for (int j = 0; j < 4; ++j) {
             float ix, iy;
             if (dbg & 8) { ix = (float)(xc4 + j) + fl1[j]; iy = (float)yc + fl0[j]; }
-            else grid_coords(fl0[j], fl1[j], xc4 + j, yc, H, W, ix, iy);
+            else grid_coords_rcp(fl0[j], fl1[j], xc4 + j, yc, H, W, dwf, rwf, dhf, rhf, ix, iy);
             const float fx0 = floorf(ix), fy0 = floorf(iy);
             const bool finite = fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
             const int x0 = finite ? (int)fx0 : -10, y0 = finite ? (int)fy0 : -10;
@@ -1056,8 +1088,8 @@ __global__ void __launch_bounds__(TH * 16) grid_warp_ring_kernel(const float* __
             li[j] = ly * GT_WW + lx;
             gi[j] = y0 * W + x0;
             x0s[j] = x0; y0s[j] = y0;
-            inner = inner && (unsigned)x0 < (unsigned)(W - 1) && (unsigned)y0 < (unsigned)(H - 1) && (unsigned)lx < (unsigned)(GT_WW - 1) &&
-                    (unsigned)ly < (unsigned)(R::WH - 1);
+            // both corners inside the image AND inside the window, per axis as ONE range test: x0 in [max(0, wx0), min(W, wx0 + WW) - 2]
+            inner = inner && (unsigned)(x0 - ixlo) <= ixspan && (unsigned)(y0 - iylo) <= iyspan;
         }
         if (!inner) {
 #pragma unroll
