@@ -1114,6 +1114,7 @@ static int launch_conv(const ConvParams& P, hipStream_t s) {
 int launch_conv3x3_c64_rw(const ConvParams& P, hipStream_t s);     // conv_rw.hip
 int launch_conv3x3_wp(const ConvParams& P, bool wide, hipStream_t s);   // conv_wp.hip
 int launch_conv1x1_wp(const ConvParams& P, hipStream_t s);              // conv1_wp.hip: 1 = shape not served
+int launch_conv_up2_phases_wp(const ConvParams& P, hipStream_t s);      // conv_wp.hip: 1 = shape not served
 
 static int conv_wp_bits() {
     static int use_wp = -1;
@@ -1240,6 +1241,10 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0, int pool
         if (r != 1) return r;
     }
     if (a->ksize == 1) return wide ? launch_conv<1, 128>(P, s) : launch_conv<1, 64>(P, s);
+    if (a->ksize == 2 && P.phase_all && !P.dbg) {        // the four phases as four wave pairs of one workgroup (conv_wp.hip): OFD_PHASE_WP=0 switches it off
+        const int r = launch_conv_up2_phases_wp(P, s);
+        if (r != 1) return r;
+    }
     if (a->ksize == 2) return wide ? launch_conv<2, 128>(P, s) : launch_conv<2, 64>(P, s);
     return k7p ? launch_conv<8, 64>(P, s) : launch_conv<7, 64>(P, s);
 }

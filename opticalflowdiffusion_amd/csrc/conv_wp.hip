@@ -449,6 +449,163 @@ static int launch(const ConvParams& P, hipStream_t s) {
     return OFD_OK;
 }
 
+
+// ---- Upsample(x2, nearest) + 3x3 (DD:89-93) as its four 2x2 phase convs on the LOW-RES tensor, all four in one workgroup (r03) ---------
+// Output pixel (2y + py, 2x + px) reads low-res rows y - 1 + py + {0, 1} and columns x - 1 + px + {0, 1} with the collapsed weights of
+// ofd_conv_upsample_phase_weight_prep (4 x [2x2 taps][Cin/8][Cout][8]): 2.25x fewer MACs than the 3x3 over the up-sampled tensor.  The
+// shared-slab kernel ran these at 500-900 TF/s of REAL work (conv_igemm_kernel<2, BN>: a weight slab copy and a barrier per tap); here the
+// wave-private-weights scheme of conv3x3_wp_kernel with the four phases as four wave pairs of ONE workgroup:
+//   * wave = (phase, 32-channel slice): 4 phases x 2 slices = 8 waves = 64 output channels of an 8 x 32 block of low-res pixels, i.e. a
+//     16 x 64 block of output pixels.  All eight waves read the SAME staged input tile (10 x 34 pixels with halo, 64 channels per chunk,
+//     double buffered): the tile is fetched and written to LDS once for the four phases (the one-launch shared-slab form fetched it from
+//     L2 four times);
+//   * a wave's A operand (its phase's weights, its 32 output channels) comes straight from L2 into registers, a ring of four fragments
+//     ahead of their use; every fragment feeds 8 MFMAs (rows) and every row fragment from LDS two (the two kernel rows): 9 ds_read_b128
+//     and 2 weight loads per 16 MFMAs;
+//   * one workgroup barrier per 128 MFMAs per wave.
+constexpr int PCK = 64, PNC = PCK / 8, PFRAGS = 16, PRING = 4;          // staged channels / octets per chunk; weight fragments per chunk
+struct PCfg {
+    static constexpr int NTHREADS = 512, IH = 10, NPIX = IH * IW;
+    static constexpr int US = (NPIX + 1) * 16, XB = PNC * US, LDS_BYTES = 2 * XB;
+    static constexpr int XPT = (NPIX * PNC + NTHREADS - 1) / NTHREADS;
+};
+
+__global__ void __launch_bounds__(512, 2) conv_up2_phases_wp_kernel(const ConvParams P) {
+    using C = PCfg;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ns = wave & 1, phase = wave >> 1, py = phase >> 1, px = phase & 1;
+
+    // XCD-aware tile order; channel blocks of a pixel tile adjacent (cy fastest) so that their input tile comes from one L2
+    const int tiles_y = (P.H + 7) / 8, tpi = P.tiles_x * tiles_y, ntiles = tpi * P.B, ny = P.Cout / 64;
+    const int j = blockIdx.x, gq = j >> 3, cy = gq % ny;
+    int tile = (gq / ny) * 8 + (j & 7);
+    if (tile >= ntiles) return;
+    if (ntiles >= 8) {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int b = tile / tpi, t_in = tile % tpi;
+    const int oy0 = (t_in / P.tiles_x) * 8, ox0 = (t_in % P.tiles_x) * TW;           // low-res block origin
+    const int cb = cy * 64 + 32 * ns;                 // this wave's 32 output channels
+
+    // ---- weights of this wave's phase: buffer loads, per-lane offset fixed for the launch, per-fragment offset scalar
+    const int cin8 = P.Cin_total / 8, nck = P.total_chunks;                           // 64-channel chunks
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(P.weight + (size_t)phase * 4 * P.Cin_total * P.Cout), 0,
+                                                                           4 * P.Cin_total * P.Cout * 2, 0x00020000);
+    const int w_lane = (half * P.Cout + cb + l31) * 16;
+    const int w_row = P.Cout * 16;                    // bytes per [Cin/8] row
+    auto load_w = [&](int kc, int fi) -> u4 {         // fragment fi = (ks, tx, ty) of 64-channel chunk kc; tap = ty * 2 + tx
+        const int ty = fi & 1, tx = (fi >> 1) & 1, ks = fi >> 2;
+        const int row = (ty * 2 + tx) * cin8 + kc * PNC + ks * 2;
+        return __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane, row * w_row, 0));
+    };
+    u4 ring[PRING];
+#pragma unroll
+    for (int i = 0; i < PRING; ++i) ring[i] = load_w(0, i);
+
+    // ---- input staging map: unit u = tid + i * 512 -> octet c8 = tid % 8, tile pixel p = u / 8 (low-res tile with a one-pixel halo)
+    const int c8 = tid % PNC;
+    int pyx[C::XPT];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int i = 0; i < C::XPT; ++i) {
+        const int p = min(tid / PNC + i * (C::NTHREADS / PNC), C::NPIX - 1);
+        const int ty_ = p / IW, tx_ = p - ty_ * IW;
+        const int iy = oy0 - 1 + ty_, ix = ox0 - 1 + tx_;
+        const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+        okmask |= (ok ? 1u : 0u) << i;
+        pyx[i] = (min(max(iy, 0), P.H - 1) << 16) | min(max(ix, 0), P.W - 1);
+    }
+    const ConvSrcDev& S = P.src[0];
+    auto load_x = [&](int kc, u4 (&xs)[C::XPT]) {
+        const bf16_t* base = S.ptr + (size_t)b * S.SH * S.SW * S.src_channels + S.ch_offset + kc * PCK + c8 * 8;
+#pragma unroll
+        for (int i = 0; i < C::XPT; ++i) {
+            const int sy = pyx[i] >> 16, sx = pyx[i] & 0xffff;
+            xs[i] = *(const u4*)(base + ((size_t)sy * S.SW + sx) * S.src_channels);
+        }
+    };
+    auto write_x = [&](const u4 (&xs)[C::XPT], unsigned char* xbuf) {
+#pragma unroll
+        for (int i = 0; i < C::XPT; ++i) {
+            const int p = min(tid / PNC + i * (C::NTHREADS / PNC), C::NPIX - 1);
+            u4 v = xs[i];
+            const bool ok = (okmask >> i) & 1u;       // zero padding of the up-sampled tensor = zero padding of the low-res one
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = ok ? v[q] : 0u;
+            *(u4*)(xbuf + c8 * C::US + p * 16) = v;
+        }
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[r][k] = 0.0f;
+
+    u4 xs[C::XPT];
+    load_x(0, xs);
+    write_x(xs, smem);
+
+    // this wave's fragment origin: octet `half` of a k-step, staged row py, column px + l31 (rows / columns of the tile count from the halo)
+    const int xrow_off = half * C::US + ((py * IW) + px + l31) * 16;
+    auto chunk = [&](const int kc, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int kn = LAST ? kc : kc + 1;
+        if constexpr (!LAST) load_x(kn, xs);
+        __syncthreads();                              // tile kc complete; every wave is done reading the other buffer
+        const unsigned char* xrow = smem + (kc & 1) * C::XB + xrow_off;
+        unsigned char* xnext = smem + ((kc + 1) & 1) * C::XB;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                 // g = (ks, tx): k-step of 16 channels, kernel column
+            const int ks = g >> 1, tx = g & 1;
+            bf16x8 x[9];
+#pragma unroll
+            for (int jr = 0; jr < 9; ++jr) x[jr] = *(const bf16x8*)(xrow + (jr * IW + tx) * 16 + ks * 2 * C::US);
+            bf16x8 a[2];
+#pragma unroll
+            for (int ty = 0; ty < 2; ++ty) {
+                const int fi = g * 2 + ty;
+                a[ty] = as_frag(ring[fi % PRING]);
+                if (fi + PRING < PFRAGS) ring[fi % PRING] = load_w(kc, fi + PRING);
+                else if constexpr (!LAST) ring[fi % PRING] = load_w(kn, fi + PRING - PFRAGS);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int ty = 0; ty < 2; ++ty) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ty], x[r + ty], acc[r], 0, 0, 0);
+            if constexpr (!LAST) { if (g == 2) write_x(xs, xnext); }
+        }
+    };
+    for (int kc = 0; kc < nck - 1; ++kc) chunk(kc, std::false_type{});
+    chunk(nck - 1, std::true_type{});
+
+    // ---- epilogue: bias, bf16, 16-byte stores to pixel (2 y + py, 2 x + px) of the (2H, 2W) tensor
+    float4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = P.bias ? *(const float4*)(P.bias + cb + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int OW = 2 * P.W;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int y = oy0 + r, x = ox0 + l31;
+        const bool ok = y < P.H && x < P.W && !(P.dbg & 16);
+        const size_t pix = ((size_t)b * 2 * P.H + (2 * min(y, P.H - 1) + py)) * OW + (2 * min(x, P.W - 1) + px);
+        uint2 q[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            q[g] = make_uint2(f2bf2(acc[r][4 * g] + bias4[g].x, acc[r][4 * g + 1] + bias4[g].y),
+                              f2bf2(acc[r][4 * g + 2] + bias4[g].z, acc[r][4 * g + 3] + bias4[g].w));
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+            const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
+            if (ok) *(uint4*)(P.out + pix * P.Cout + cb + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+        }
+    }
+}
+
 }  // namespace wp
 
 // 3x3, stride 1, sources of mode 0 (same size) or 1 (nearest x2): called from conv_forward_impl
@@ -463,4 +620,23 @@ int launch_conv3x3_wp(const ConvParams& P0, bool wide, hipStream_t s) {
     return wide ? wp::launch<4, 1, false>(P, s) : wp::launch<2, 2, false>(P, s);
 }
 
+}  // namespace ofd
+
+namespace ofd {
+// Upsample(x2) + 3x3 as four 2x2 phase convs in one launch (ConvParams of the ksize-2 / phase_all form): 1 = shape not served
+int launch_conv_up2_phases_wp(const ConvParams& P, hipStream_t s) {
+    static const bool off = getenv("OFD_PHASE_WP") && atoi(getenv("OFD_PHASE_WP")) == 0;
+    if (off || !P.phase_all || P.n_src != 1 || P.src[0].mode != 0 || P.Cout % 64 || P.Cin_total % 64 || P.residual || P.res_act || P.gn_partial ||
+        P.in_scale || P.split || P.total_chunks < 1)
+        return 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OFD_HIP(hipFuncSetAttribute((const void*)wp::conv_up2_phases_wp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wp::PCfg::LDS_BYTES));
+        attr_set = true;
+    }
+    const int tiles_y = (P.H + 7) / 8, ntiles = P.tiles_x * tiles_y * P.B, ny = P.Cout / 64;
+    wp::conv_up2_phases_wp_kernel<<<(ntiles + 7) / 8 * 8 * ny, wp::PCfg::NTHREADS, wp::PCfg::LDS_BYTES, s>>>(P);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
 }  // namespace ofd

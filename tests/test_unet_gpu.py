@@ -345,7 +345,7 @@ def test_state_dict_layout_matches_reference_names(L):
     assert sum(v.numel() for v in sd.values()) == 35729858
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 32, 128, 64), (2, 11, 40, 256, 128), (1, 5, 9, 64, 64)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 32, 128, 64), (2, 11, 40, 256, 128), (1, 5, 9, 64, 64), (3, 17, 70, 512, 256)])
 def test_upsample_conv_as_four_phase_convs(L, B, H, W, Cin, Cout):
     """Upsample(x2, nearest) + Conv3x3 (DD:89-93) computed as four 2x2 convs on the low-res input (2.25x fewer MACs):
     same function; the collapsed weights are rounded to bf16 once, hence the slightly wider per-op tolerance."""
@@ -372,7 +372,9 @@ def test_upsample_conv_as_four_phase_convs(L, B, H, W, Cin, Cout):
     assert torch.isfinite(got).all()                       # every output pixel written by exactly one phase
     # vs the per-tap-rounded weights of the bf16c contract: two different bf16 roundings of the same fp32 kernel ...
     check_close(got, ref, tol=4e-3, what="phase-decomposed upsample conv")
-    # the four phases in ONE launch (up2_phase = 5, what the UNet runs): the same kernel per phase, bit-identical output
+    # the four phases in ONE launch (up2_phase = 5, what the UNet runs): conv_up2_phases_wp_kernel (conv_wp.hip) -- the four phases as four
+    # wave pairs of one workgroup over ONE staged input tile; another summation order than the per-phase kernel: equal after rounding
+    # except where the fp32 sums straddle a bf16 rounding boundary
     out1 = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
     a = L.ConvArgs()
     a.B, a.H, a.W, a.ksize, a.n_src, a.Cout = B, H, W, 2, 1, Cout
@@ -380,7 +382,10 @@ def test_upsample_conv_as_four_phase_convs(L, B, H, W, Cin, Cout):
     a.weight, a.bias, a.out, a.up2_phase = wp.data_ptr(), bd.data_ptr(), out1.data_ptr(), 5
     L.check(L.lib().ofd_conv_forward(ctypes.byref(a), L.stream()))
     torch.cuda.synchronize()
-    assert torch.equal(out1, out)
+    got1 = from_nhwc(out1)
+    assert torch.isfinite(got1).all()
+    check_close(got1, ref, tol=4e-3, what="phase-decomposed upsample conv, one launch")
+    assert rel_l2(got1, got) < 2e-3 and float((got1 != got).float().mean()) < 0.05
     # ... and vs the un-rounded fp32 weights the collapsed kernels are at least as close as the per-tap rounding is
     exact = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, bias, padding=1)
     assert rel_l2(got, q(exact)) <= 1.25 * rel_l2(q(ref), q(exact)) + 1e-4
