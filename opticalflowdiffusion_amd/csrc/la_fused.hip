@@ -44,10 +44,19 @@ __device__ __forceinline__ void load_raw_x(const bf16_t* __restrict__ xrow, XRaw
     for (int s = 0; s < C / 16; ++s) r.v[s] = *(const u32x4*)(xrow + 16 * s + 8 * half);
 }
 
-// raw tile -> normalised (no gain) bf16 fragments (LayerNorm over channels, DD:121-125)
+// raw tile -> normalised (no gain) bf16 fragments (LayerNorm over channels, DD:121-125).  r03: the two sums run on the PACKED words
+// (v_dot2_f32_bf16: x . (1, 1) and x . x, two channels per instruction, fp32 accumulate) and the variance is E[x^2] - mean^2 -- the
+// inputs are bf16 activations, |mean| / std stays far below the 2^12 at which fp32 cancellation would reach bf16 resolution -- so an
+// element costs unpack + one fma + convert instead of unpack + add + subtract + fma + multiply + convert (OFD_LA_TWO_PASS_LN=1 at
+// build time restores the centred form).
+#ifndef OFD_LA_TWO_PASS_LN
+#define OFD_LA_TWO_PASS_LN 0
+#endif
+typedef __bf16 la_bf16x2 __attribute__((ext_vector_type(2)));
 template <int C>
 __device__ __forceinline__ void norm_x(const XRaw<C>& r, float eps, bf16x8 (&xs)[C / 16]) {
     constexpr int KS = C / 16;
+#if OFD_LA_TWO_PASS_LN
     float v[KS][8];
     float sum = 0.0f;
 #pragma unroll
@@ -76,6 +85,31 @@ __device__ __forceinline__ void norm_x(const XRaw<C>& r, float eps, bf16x8 (&xs)
     for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) xs[s][j] = (__bf16)(v[s][j] * rstd);
+#else
+    const la_bf16x2 one = __builtin_bit_cast(la_bf16x2, 0x3f803f80u);
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const la_bf16x2 w = __builtin_bit_cast(la_bf16x2, (uint32_t)r.v[s][j]);
+            s1 = __builtin_amdgcn_fdot2_f32_bf16(w, one, s1, false);
+            s2 = __builtin_amdgcn_fdot2_f32_bf16(w, w, s2, false);
+        }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float mean = s1 * (1.0f / C);
+    const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * (1.0f / C)), 0.0f);
+    const float rstd = rsqrtf(var + eps), off = -mean * rstd;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t w = r.v[s][j];
+            xs[s][2 * j] = (__bf16)__builtin_fmaf(bf2f((bf16_t)(w & 0xffffu)), rstd, off);
+            xs[s][2 * j + 1] = (__bf16)__builtin_fmaf(bf2f((bf16_t)(w >> 16)), rstd, off);
+        }
+#endif
 }
 
 // ---- end of pass 1: the workgroup's four waves merge their online-softmax states (m, l, ctx relative to m) of one head through LDS and
@@ -125,7 +159,7 @@ __device__ __forceinline__ void la_store_part(float* lds, float* __restrict__ o,
 // ---- pass 1 ---------------------------------------------------------------------------------------
 template <int C>
 __global__ void __launch_bounds__(256, 2) la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wkv,
-                                                           float* __restrict__ partial, int n, float eps) {
+                                                           float* __restrict__ partial, int n, float eps, float defer) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KS = C / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -175,20 +209,29 @@ __global__ void __launch_bounds__(256, 2) la_ctx_fused_kernel(const bf16_t* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, ka[r]);
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            const float m_new = fmaxf(m[hd], mt);
-            const float f = __expf(m[hd] - m_new);
-            m[hd] = m_new;
+            // deferred running maximum: the reference point m moves only when a tile's maximum exceeds it by more than `defer`
+            // (natural-log units; 0 = always): p = exp(k - m) then stays below e^defer (2^8 by default: exact range for fp32 sums and
+            // bf16 operands alike) and the rescaling of l and ctx^T -- 16 multiplies + an exp per head and tile -- runs only in the
+            // tiles where some column's reference moves (wave-uniform skip).  (m, l, ctx) stay a consistent triple: the combine
+            // kernel only needs sums relative to the m it is handed.
+            const bool move = mt > m[hd] + defer;
+            if (__builtin_amdgcn_ballot_w64(move)) {
+                const float m_new = move ? mt : m[hd];
+                const float f = __expf(m[hd] - m_new);
+                m[hd] = m_new;
+                l[hd] *= f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ctxT[hd][r] *= f;
+            }
             float ps = 0.0f;
-            const float m2 = m_new * LOG2E;      // exp(k - m) as exp2(k log2e - m log2e): one fma + v_exp per element instead of sub, mul, v_exp
+            const float m2 = m[hd] * LOG2E;      // exp(k - m) as exp2(k log2e - m log2e): one fma + v_exp per element instead of sub, mul, v_exp
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(ka[r], LOG2E, -m2));
                 ka[r] = p;
                 ps += p;
             }
-            l[hd] = l[hd] * f + ps;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ctxT[hd][r] *= f;
+            l[hd] += ps;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)   // ctx^T[e][d] += sum_pix v[pix][e] p[pix][d]
                 ctxT[hd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acc_frag(va, s2), acc_frag(ka, s2), ctxT[hd], 0, 0, 0);
@@ -534,7 +577,8 @@ static int launch_la(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const
         attr = true;
     }
     const int gx = la_fused_blocks(n, B);
-    la_ctx_fused_kernel<C><<<dim3(gx, B), 256, LDS1, s>>>(x, wkv, partial, n, eps_pre);
+    static const float defer = getenv("OFD_LA_DEFER") ? (float)atof(getenv("OFD_LA_DEFER")) : 5.545177f;      // 8 ln 2; 0: the reference point follows every new maximum
+    la_ctx_fused_kernel<C><<<dim3(gx, B), 256, LDS1, s>>>(x, wkv, partial, n, eps_pre, defer);
     la_ctx_combine_frag_kernel<<<dim3(B * 4, 4), 256, 0, s>>>(partial, ctxfrag, gx, 1.0f / (float)n);
     int gx2 = cdiv(cdiv(n, 32), 4 * 4);     // >= 4 tiles per wave amortise the weight staging
     if (gx2 < 1) gx2 = 1;

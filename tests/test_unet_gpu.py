@@ -559,3 +559,35 @@ def test_split_stream_forward_is_bit_identical_per_sample(L):
         y3 = u(x[:3], cond[:3], t[:3])                      # odd batch: the one-stream path
         u.set_split_streams(False)
         assert torch.equal(y3, u(x[:3], cond[:3], t[:3]))
+
+
+def test_fused_linear_attention_with_moving_softmax_reference(L):
+    """The fused LinearAttention's first pass keeps a DEFERRED running maximum for the softmax over pixels (la_fused.hip: the reference
+    point moves only when a tile's maximum exceeds it by more than 8 ln 2, and only then are l and ctx rescaled).  With the k rows
+    of every to_qkv scaled x25 the logits span tens of units, so the reference point does move between tiles and the
+    rarely-taken rescale branch runs; a rare data-dependent branch needs its own forcing input (cdna guide rule 26).  Checked
+    against the engine's own unfused path (the training forward: la_core.hip, per-tile exact maximum) at the three block sizes."""
+    torch.manual_seed(41)
+    P = default_init_params(5)
+    for k_, v_ in P.items():
+        if k_.endswith("fn.fn.to_qkv.weight") and "mid_attn" not in k_:
+            v_[128:256] *= 25.0
+    u = make_unet(5, P)
+    B, H, W = 2, 64, 96
+    x, cond, t = torch.randn(B, 2, H, W).cuda(), (torch.rand(B, 3, H, W) * 2 - 1).cuda(), torch.tensor([5, 900]).cuda()
+    taps = [("downs.0.2", 64, 1), ("downs.1.2", 64, 2), ("ups.2.2", 128, 2), ("ups.3.2", 64, 1)]
+    with torch.no_grad():
+        y_inf = u(x, cond, t).clone()
+        t_inf = {n: u.read_tap(n, (B, c, H // s, W // s)).clone() for n, c, s in taps}
+    y_tr = u(x, external_cond=cond, time=t).detach()            # grad enabled: the training forward (materialised qkv, exact maxima)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y_inf).all() and torch.isfinite(y_tr).all()
+    # (the training executor keeps its own taps: compare the outputs, and the fused taps against the oracle below)
+    assert rel_l2(y_inf.cpu(), y_tr.cpu()) < 2e-2
+    ref_taps = {}
+    with torch.no_grad():
+        ref = R.unet_forward({k_: v_.clone() for k_, v_ in P.items()}, x.cpu(), cond.cpu(), t.cpu(), mode="bf16c", taps=ref_taps)
+    assert rel_l2(y_inf.cpu(), ref) < 2e-2
+    for n, c, s in taps:
+        if n in ref_taps:
+            assert rel_l2(t_inf[n].cpu(), ref_taps[n]) < 2e-2, n
