@@ -94,7 +94,8 @@ __global__ void __launch_bounds__(256) block_mlp_kernel(const float* __restrict_
 // ---- GroupNorm(8) statistics -> per-(sample, channel) affine (DD:181-185) -------------------------
 // partial: [B][tiles*4 waves][C/8][2] from the conv epilogue.  y = x*a + s with
 //   a = gamma*rstd*(scale+1), s = (beta - mean*rstd*gamma)*(scale+1) + shift.   grid (B, 8)
-__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial, int tiles, int C, double count,
+constexpr int GNF_NT = 1024;      // threads per (sample, group): the 7040 entries of a full-resolution group are one round of 8 loads per thread (256 threads: four dependent rounds, 9 us)
+__global__ void __launch_bounds__(GNF_NT) gn_finalize_kernel(const float* __restrict__ partial, int tiles, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ ss, int ss_stride, int ss_offset,
                                                           float* __restrict__ a_out, float* __restrict__ s_out, float* __restrict__ stats_out) {
@@ -105,23 +106,24 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
     constexpr int GU = 8;
     double s1 = 0.0, s2 = 0.0;
     const int total = tiles * octs;
-    for (int i0 = tid; i0 < total; i0 += 256 * GU) {
+    for (int i0 = tid; i0 < total; i0 += GNF_NT * GU) {
         float2 v[GU];
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
-            const int i = min(i0 + u * 256, total - 1);
+            const int i = min(i0 + u * GNF_NT, total - 1);
             const int tile = i / octs, o = g * octs + i % octs;
             v[u] = *(const float2*)(partial + (((size_t)b * tiles + tile) * noct + o) * 2);
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u)
-            if (i0 + u * 256 < total) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
+            if (i0 + u * GNF_NT < total) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
     }
-    __shared__ double r1[256], r2[256];
-    r1[tid] = s1;
-    r2[tid] = s2;
+    // wave sums first (the order of the additions is fixed: deterministic), then one value per wave through LDS
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    __shared__ double r1[GNF_NT / 64], r2[GNF_NT / 64];
+    if ((tid & 63) == 0) { r1[tid >> 6] = s1; r2[tid >> 6] = s2; }
     __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
+    for (int k = GNF_NT / 128; k > 0; k >>= 1) {
         if (tid < k) { r1[tid] += r1[tid + k]; r2[tid] += r2[tid + k]; }
         __syncthreads();
     }
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
         stats_out[((size_t)b * 8 + g) * 2] = mean;
         stats_out[((size_t)b * 8 + g) * 2 + 1] = rstd;
     }
-    for (int c = g * gs + tid; c < (g + 1) * gs; c += 256) {
+    for (int c = g * gs + tid; c < (g + 1) * gs; c += GNF_NT) {
         float sc = 0.0f, sh = 0.0f;
         if (ss) {
             sc = ss[(size_t)b * ss_stride + ss_offset + c];
@@ -466,7 +468,7 @@ int k_gn_finalize(const float* partial, int B, int H, int W, int C, const float*
                   int ss_offset, float* a_out, float* s_out, hipStream_t s, float* stats_out) {
     OFD_CHECK_ARG(C % 64 == 0, "gn_finalize: C=%d", C);
     const int tiles = cdiv(H, 8) * cdiv(W, 32) * 4;    // one partial per (tile, wave) from the conv epilogue
-    gn_finalize_kernel<<<dim3(B, 8), 256, 0, s>>>(partial, tiles, C, (double)H * W * (C / 8), gamma, beta, ss, ss_stride, ss_offset, a_out, s_out, stats_out);
+    gn_finalize_kernel<<<dim3(B, 8), GNF_NT, 0, s>>>(partial, tiles, C, (double)H * W * (C / 8), gamma, beta, ss, ss_stride, ss_offset, a_out, s_out, stats_out);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
