@@ -335,7 +335,7 @@ def main():
                                 "algorithmic_flops_per_launch": k["flops"] / max(k["launches"], 1), "avg_launch_ms": per_launch_ms,
                                 "launches": k["launches"],
                                 "measured_in": f"instrumented loop of {prof_steps} steps after the headline loop ({1e3 * prof_elapsed / prof_steps:.2f} ms per step with the events on)"}
-            c3 = [prof[n] for n in ("conv3x3_wp_kernel<4,1>", "conv3x3_wp_kernel<2,2>", "conv3x3_c64_pingpong_kernel") if n in prof and prof[n]["ms"] > 0]
+            c3 = [prof[n] for n in ("conv3x3_wp_kernel<4,1>", "conv3x3_wp_kernel<2,2>", "conv3x3_wp_kernel<2,2> (64->64)") if n in prof and prof[n]["ms"] > 0]
             line["conv3x3_all_tflops"] = sum(v["flops"] for v in c3) / (sum(v["ms"] for v in c3) * 1e-3) / 1e12
             line["kernel_ms_per_step"] = {n: v["ms"] / prof_steps for n, v in prof.items()}
 
