@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(256) la_ctx_combine_frag_kernel(const float* _
 
 // ---- pass 2 ---------------------------------------------------------------------------------------
 template <int C>
-__global__ void __launch_bounds__(256, 2) la_out_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wq,
+__global__ void __launch_bounds__(256, C == 64 ? 4 : 2) la_out_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wq,
                                                            const bf16_t* __restrict__ woutp, const bf16_t* __restrict__ ctxfrag,
                                                            const float* __restrict__ bias, const float* __restrict__ g2,
                                                            bf16_t* __restrict__ y, int n, float eps_pre, float eps_post, float scale) {
@@ -517,7 +517,10 @@ __global__ void __launch_bounds__(256, 2) la_out_fused_kernel(const bf16_t* __re
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
-                    const uint4 xv = *(const uint4*)(xrow + rt * 32 + 8 * g + 8 * half);
+                    // the residual x: the very words this lane loaded for the LayerNorm (channels 16 s + 8 half .. + 7 with s = 2 rt + g / 2) --
+                    // kept in registers (r03; was a second global load per tile: 922 MB more through L2 at full resolution)
+                    const u32x4 xw = raw.v[rt * 2 + (g >> 1)];
+                    const uint4 xv = make_uint4(xw[0], xw[1], xw[2], xw[3]);
                     const auto sx = __builtin_amdgcn_permlane32_swap(xv.x, xv.z, false, false);
                     const auto sy = __builtin_amdgcn_permlane32_swap(xv.y, xv.w, false, false);
                     const unsigned xq[2][2] = {{sx[0], sy[0]}, {sx[1], sy[1]}};      // residual of quad g, quad g+1
