@@ -195,6 +195,10 @@ int ofd_unet_set_graph(ofd_unet* u, int enabled);
  * bit-identical to the one-stream forward per sample.  ofd_unet_workspace_bytes already covers the two half contexts. */
 int ofd_unet_set_split_streams(ofd_unet* u, int enabled, int offset_blocks);
 int ofd_unet_read_tap(ofd_unet* u, const char* name, float* dst, size_t numel, void* stream);
+/* debug: materialise EVERY named intermediate of the inference forward.  Off (default), final_res_block's 64-channel output is not:
+ * the final 1x1 conv (DD:361) then rides on the tile of its producer (out_dim 2, H*W a multiple of 128) and "final_res_block" is
+ * not a tap.  The two forms sum the 64 products of a pixel in different orders (equal to fp32 rounding). */
+int ofd_unet_set_debug_taps(ofd_unet* u, int enabled);
 /* per-kernel-class device time of forwards run with profiling enabled (HIP events on the
  * stream the kernels are launched on).  classes: see ofd_unet_prof_name(). */
 int ofd_unet_set_profiling(ofd_unet* u, int enabled);

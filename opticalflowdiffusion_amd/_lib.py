@@ -79,6 +79,7 @@ SIGNATURES = {
     "ofd_unet_set_graph": (c_int, [c_void_p, c_int]),
     "ofd_unet_set_split_streams": (c_int, [c_void_p, c_int, c_int]),
     "ofd_unet_read_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t, c_void_p]),
+    "ofd_unet_set_debug_taps": (c_int, [c_void_p, c_int]),
     "ofd_unet_set_profiling": (c_int, [c_void_p, c_int]),
     "ofd_unet_prof_count": (c_int, [c_void_p]),
     "ofd_unet_prof_name": (c_char_p, [c_void_p, c_int]),

@@ -11,7 +11,9 @@ struct MlpDesc {            // one ResnetBlock's time-embedding Linear (DD:193-1
     int offset;             // into the per-sample scale/shift row
 };
 
-int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0 = 0, int pool2 = 0, const bf16_t* residual_b = nullptr);      // cout0: see ConvParams::cout0 (honoured by the streaming 1x1 kernel only
+struct FcFuse { const float* w; const float* b; float* out; };      // ConvParams::fc_* (the UNet's final 1x1 conv on the final res_conv's tile)
+bool conv_fc_fuse_supported(const ofd_conv_args* a, int out_dim);
+int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0 = 0, int pool2 = 0, const bf16_t* residual_b = nullptr, const FcFuse* fc = nullptr);      // cout0: see ConvParams::cout0 (honoured by the streaming 1x1 kernel only
                                                                                    // for 64 -> 384 with cout0 = 128; everything else computes all channels)
 bool conv_pool2_supported(const ofd_conv_args* a);
 bool conv_residual_b_supported(const ofd_conv_args* a);                            // residual_b: ConvParams::residual_b (3x3 through conv_wp.hip only)                                 // pool2: ConvParams::pool2 (3x3 through conv_wp.hip only)

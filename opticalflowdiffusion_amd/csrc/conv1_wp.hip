@@ -70,17 +70,25 @@ struct Params {
     bf16_t* out;
     int B, H, W, Cout, ntiles;
     int cout0;                 // first output channel computed (the blocks of this launch start there; the tensor keeps its full pixel stride Cout)
+    const float* fc_w;         // FC instantiation: the final 1x1 conv [2][Cout], its bias [2], its zeroed (B, 2, H, W) fp32 output
+    const float* fc_b;
+    float* fc_out;
     int interleave;            // 1: workgroup w walks tiles w, w + G, ... (the resident workgroups sweep ONE moving window of memory); 0: a contiguous range each
 };
 
 // NSG: 32-channel slices per workgroup (output block = 32 NSG channels), CIN, TILE pixels per step, RA: fused SiLU(affine(h2)) input,
 // NCB: output blocks a workgroup computes from one staged tile (to_qkv: 3 x 128 channels -- the input is read once, not per block)
-template <int NSG, int CIN, int TILE, bool RA, int NCB = 1>
+// FC (r03): the UNet's final 1x1 conv (64 -> 2, fp32) rides on the output tile -- each wave dots its 32 channels (as stored: bf16-rounded)
+// with the two weight rows, one v_permlane32_swap + add joins the lane halves (lanes 0-31 end with channel 0's partial, 32-63 with
+// channel 1's), and ONE float atomic per fragment adds it to the zeroed fp32 output (the other 32-channel wave adds the second addend:
+// two addends onto zero, any order, same sum).  The 922 MB bf16 tensor between the two convs is neither written nor read.
+template <int NSG, int CIN, int TILE, bool RA, int NCB = 1, bool FC = false>
 __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P) {
     constexpr int KS = CIN / 16, UNITS = CIN / 64, UNITB = TILE * 128, BUFB = UNITS * UNITB;
     constexpr int PG = 4 / NSG, F = (TILE / 32) / PG;                 // pixel groups of waves, 32-pixel fragments per wave
     constexpr int NPW = BUFB / 1024 / 4;                               // 1-KiB DMA pieces per wave and tile
-    constexpr int NRA = RA ? F * 2 : 0, NST = F * 2 * NCB;             // per wave and tile: h2 loads, output stores (16 B per lane each)
+    constexpr int NRA = RA ? F * 2 : 0, NST = FC ? F : F * 2 * NCB;    // per wave and tile: h2 loads, output stores (16 B per lane each; FC: one atomic per fragment instead)
+    static_assert(!FC || (NCB == 1 && NSG == 2), "FC: two 32-channel waves per pixel");
     static_assert(TILE % 32 == 0 && (TILE / 32) % PG == 0 && BUFB % 4096 == 0, "tile shape");
     static_assert(!(RA && NCB > 1) && NRA + NST <= 63, "the fused epilogue input is for single-block launches; vmcnt is 6 bits");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -107,6 +115,22 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P)
     if constexpr (NCB == 1) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bias4[g].x), "+v"(bias4[g].y), "+v"(bias4[g].z), "+v"(bias4[g].w));
+    }
+    float fcw[FC ? 2 : 1][16], fcb = 0.0f;                             // FC: rows of the final conv for this lane's 16 channels; its bias (first wave of a pixel only)
+    if constexpr (FC) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 w4 = *(const float4*)(P.fc_w + k * P.Cout + cb + 8 * g + 4 * half);
+                fcw[k][4 * g] = w4.x; fcw[k][4 * g + 1] = w4.y; fcw[k][4 * g + 2] = w4.z; fcw[k][4 * g + 3] = w4.w;
+            }
+        fcb = (ns == 0) ? P.fc_b[half] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(fcw[k][i]));
+        asm volatile("" : "+v"(fcb));
     }
     const int plane = P.H * P.W, tps = plane / TILE;                   // tiles per sample
     // DMA lane constants: piece = 8 pixel rows x 128 B of one unit; lane -> row lane >> 3, 16-byte chunk (lane & 7) ^ (lane >> 3)
@@ -257,6 +281,24 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P)
             }
         }
         issue_ra(tq);                                        // into the registers the lines above have just finished with
+        if constexpr (FC) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float v0 = bf2f((bf16_t)(qout[f][g].x & 0xffffu)), v1 = bf2f((bf16_t)(qout[f][g].x >> 16));
+                    const float v2 = bf2f((bf16_t)(qout[f][g].y & 0xffffu)), v3 = bf2f((bf16_t)(qout[f][g].y >> 16));
+                    p0 += v0 * fcw[0][4 * g] + v1 * fcw[0][4 * g + 1] + v2 * fcw[0][4 * g + 2] + v3 * fcw[0][4 * g + 3];
+                    p1 += v0 * fcw[1][4 * g] + v1 * fcw[1][4 * g + 1] + v2 * fcw[1][4 * g + 2] + v3 * fcw[1][4 * g + 3];
+                }
+                // X' = [p0 of lanes 0-31 | p1 of lanes 0-31], Y' = [p0 of lanes 32-63 | p1 of lanes 32-63]: X' + Y' = channel `half`'s sum over the wave's 32 channels
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+                const float part = __uint_as_float(sw[0]) + __uint_as_float(sw[1]) + fcb;
+                const size_t pin = gp0 - (size_t)b * plane + (pg * F + f) * 32 + l31;          // pixel inside its sample (tiles never straddle samples)
+                unsafeAtomicAdd(P.fc_out + ((size_t)b * 2 + half) * plane + pin, part);
+            }
+        } else {
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const size_t pix = gp0 + (pg * F + f) * 32 + l31;
@@ -267,6 +309,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P)
                 *(uint4*)(P.out + pix * P.Cout + cb + 32 * NSG * cbk + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
             }
         }
+        }
         });
         if (tn >= t_end) break;
         t = tn;
@@ -276,19 +319,19 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NSG, int CIN, int TILE, bool RA, int NCB = 1>
+template <int NSG, int CIN, int TILE, bool RA, int NCB = 1, bool FC = false>
 static int launch(const Params& P, hipStream_t s) {
     constexpr int LDS = 2 * (CIN / 64) * TILE * 128;
     static bool attr = false;
     if (!attr) {
-        OFD_HIP(hipFuncSetAttribute((const void*)conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        OFD_HIP(hipFuncSetAttribute((const void*)conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB, FC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
     const int per_cu = (LDS * 2 <= 160 * 1024) ? 2 : 1;
     int gx = 256 * per_cu;
     if (const char* e = getenv("OFD_CONV1_GRID")) gx = atoi(e) > 0 ? atoi(e) : gx;       // diagnostics / tests: long tile ranges on small inputs
     if (gx > P.ntiles) gx = P.ntiles;
-    conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB><<<dim3(gx, (P.Cout - P.cout0) / (32 * NSG * NCB)), NTHREADS, LDS, s>>>(P);
+    conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB, FC><<<dim3(gx, (P.Cout - P.cout0) / (32 * NSG * NCB)), NTHREADS, LDS, s>>>(P);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -322,6 +365,8 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
     }
     if (nu * 64 != cin) return 1;
     P.weight = C.weight; P.bias = C.bias; P.res_act = C.res_act; P.res_scale = C.res_scale; P.res_shift = C.res_shift; P.out = C.out;
+    P.fc_w = C.fc_w; P.fc_b = C.fc_b; P.fc_out = C.fc_out;
+    if (C.fc_out && !(cin == 128 && C.Cout == 64 && ra)) return 1;
     P.B = C.B; P.H = C.H; P.W = C.W; P.Cout = C.Cout; P.ntiles = C.B * (plane / tile);
     static const int order = getenv("OFD_CONV1_ORDER") ? atoi(getenv("OFD_CONV1_ORDER")) : 1;
     P.interleave = order;
@@ -331,6 +376,7 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
     if (cin == 64) return launch<4, 64, 128, false, 3>(P, s);                 // to_qkv of the 64-channel LinearAttention (training)
     if (cin == 128 && C.Cout == 384 && !ra && !C.bias) return launch<4, 128, 128, false, 3>(P, s);
     if (cin == 128) {
+        if (narrow && C.fc_out) return launch<2, 128, 128, true, 1, true>(P, s);
         if (narrow) return ra ? launch<2, 128, 128, true>(P, s) : launch<2, 128, 128, false>(P, s);
         return ra ? 1 : launch<4, 128, 128, false>(P, s);      // (no 128 -> 128+ res_conv in this UNet)
     }

@@ -1131,6 +1131,15 @@ bool conv_pool2_supported(const ofd_conv_args* a) {
     return !c64 && (conv_wp_bits() & 3) == 3;
 }
 
+// final 1x1 conv fused into the final res_conv (conv1_wp.hip, FC instantiation): 128 -> 64, fused h2 input, whole 128-pixel tiles, out_dim 2
+bool conv_fc_fuse_supported(const ofd_conv_args* a, int out_dim) {
+    static const bool off = (getenv("OFD_NO_FC_FUSE") && atoi(getenv("OFD_NO_FC_FUSE"))) || (getenv("OFD_CONV1_WP") && atoi(getenv("OFD_CONV1_WP")) == 0);
+    if (off || !a || out_dim != 2 || a->ksize != 1 || a->Cout != 64 || !a->res_act || a->residual || a->gn_partial || a->split || a->in_scale) return false;
+    int cin = 0;
+    for (int i = 0; i < a->n_src; ++i) { if (a->src[i].upsample || a->src[i].unshuffle || a->src[i].channels % 64) return false; cin += a->src[i].channels; }
+    return cin == 128 && ((long)a->H * a->W) % 128 == 0;
+}
+
 bool conv_residual_b_supported(const ofd_conv_args* a) {
     static const bool off = getenv("OFD_NO_RESIDUAL_B") && atoi(getenv("OFD_NO_RESIDUAL_B"));
     if (off || !a || a->ksize != 3 || a->split || a->Cout % 64) return false;
@@ -1139,7 +1148,7 @@ bool conv_residual_b_supported(const ofd_conv_args* a) {
     return (conv_wp_bits() & 7) == 7 || ((conv_wp_bits() & 3) == 3 && a->residual);      // (with a residual the 64 -> 64 case is conv_wp's too)
 }
 
-int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0, int pool2, const bf16_t* residual_b) {
+int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0, int pool2, const bf16_t* residual_b, const FcFuse* fc) {
     OFD_CHECK_ARG(a && a->out && a->weight, "conv: null out/weight");
     OFD_CHECK_ARG(a->B > 0 && a->H > 0 && a->W > 0, "conv: bad shape");
     OFD_CHECK_ARG(a->ksize == 1 || a->ksize == 2 || a->ksize == 3 || a->ksize == 7, "conv: ksize %d unsupported", a->ksize);
@@ -1189,6 +1198,8 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0, int pool
     P.cout0 = cout0;
     P.pool2 = pool2;
     P.residual_b = residual_b;
+    if (fc) { P.fc_w = fc->w; P.fc_b = fc->b; P.fc_out = fc->out; }
+    OFD_CHECK_ARG(!fc || conv_fc_fuse_supported(a, 2), "conv: the fused final conv serves the 128 -> 64 streaming 1x1 with a SiLU(GN(h2)) input only");
     OFD_CHECK_ARG(!residual_b || conv_residual_b_supported(a), "conv: a second residual is served by the conv_wp 3x3 kernels only");
     OFD_CHECK_ARG(!pool2 || conv_pool2_supported(a), "conv: the 2x2-pooled epilogue does not serve this configuration");
     { static int dbg_env = -1; if (dbg_env < 0) { const char* e = getenv("OFD_CONV_DBG"); dbg_env = e ? atoi(e) : 0; } P.dbg = dbg_env; }
@@ -1240,6 +1251,7 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0, int pool
         const int r = launch_conv1x1_wp(P, s);
         if (r != 1) return r;
     }
+    OFD_CHECK_ARG(!P.fc_out, "conv: the fused final conv was requested for a shape the streaming 1x1 kernel does not serve");
     if (a->ksize == 1) return wide ? launch_conv<1, 128>(P, s) : launch_conv<1, 64>(P, s);
     if (a->ksize == 2 && P.phase_all && !P.dbg) {        // the four phases as four wave pairs of one workgroup (conv_wp.hip): OFD_PHASE_WP=0 switches it off
         const int r = launch_conv_up2_phases_wp(P, s);

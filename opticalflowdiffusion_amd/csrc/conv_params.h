@@ -41,6 +41,12 @@ struct ConvParams {
     const bf16_t* residual_b;   // conv_wp 3x3: a second plain residual (same shape as `residual`; training: gradient already in the buffer + the identity-residual gradient)
     int pool2;          // conv_wp 3x3: the epilogue sums every 2x2 block of output pixels and writes the (H/2, W/2) tensor (+ residual there): the
                         // data gradient of Upsample(x2, nearest) + conv lands in the low-resolution source's gradient without a full-size tensor
+    // streaming 1x1 (128 -> 64 with the fused SiLU(GN(h2)) input) only: the UNet's final 1x1 conv (DD:361, out_dim 2) on the tile the kernel
+    // holds -- fc_out (B, 2, H, W) fp32, ZEROED by the caller, receives the two 32-channel partial sums of a pixel as float atomics (two
+    // addends onto zero: the order cannot change the sum); the bf16 `out` tensor is then NOT written
+    const float* fc_w;  // [2][Cout]
+    const float* fc_b;  // [2]
+    float* fc_out;
     int dbg;            // diagnostic ablation bits (OFD_CONV_DBG), 0 in production
 };
 

@@ -121,7 +121,7 @@ static void build_registry(ofd_unet* u) {
 
 void conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& srcs, Tensor out, const float* in_scale,
                  const float* in_shift, const bf16_t* residual, const bf16_t* res_act, const float* res_scale,
-                 const float* res_shift, float* gn_partial, int cout0) {
+                 const float* res_shift, float* gn_partial, int cout0, const FcFuse* fc) {
     if (c.rc != OFD_OK) return;
     const ConvDesc& d = c.u->convs[c.u->cindex.at(prefix)];
     ofd_conv_args a{};
@@ -151,11 +151,11 @@ void conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& srcs, T
     const int cls3 = pp ? PC_CONV3_PP : (d.Cout % 128 == 0 ? PC_CONV3 : PC_CONV3_64);
     c.begin(d.ksize == 3 ? cls3 : (d.ksize == 1 ? PC_CONV1 : PC_CONV7), flops, bytes,
             prefix + " " + std::to_string(d.Cin) + "->" + std::to_string(d.Cout) + " @" + std::to_string(out.H) + "x" + std::to_string(out.W));
-    RUN(conv_forward_impl(&a, c.s, cout0));
+    RUN(conv_forward_impl(&a, c.s, cout0, 0, nullptr, fc));
     c.end();
 }
 
-static Tensor resblock(Ctx& c, const std::string& name, const std::vector<Tensor>& in, int Cout, bool keep_out = true) {
+static Tensor resblock(Ctx& c, const std::string& name, const std::vector<Tensor>& in, int Cout, bool keep_out = true, const FcFuse* fc = nullptr) {
     ofd_unet* u = c.u;
     const int H = in[0].H, W = in[0].W, B = c.B;
     std::vector<SrcSpec> srcs;
@@ -185,7 +185,7 @@ static Tensor resblock(Ctx& c, const std::string& name, const std::vector<Tensor
     RUN(k_gn_finalize(p2, B, H, W, Cout, u->P(name + ".block2.norm.weight"), u->P(name + ".block2.norm.bias"), nullptr, 0, 0, a2, s2, c.s, st2));
     c.end();
     if (cin != Cout) {
-        conv(c, name + ".res_conv", srcs, out, nullptr, nullptr, nullptr, h2.p, a2, s2, nullptr);   // DD:214 fused into the 1x1
+        conv(c, name + ".res_conv", srcs, out, nullptr, nullptr, nullptr, h2.p, a2, s2, nullptr, 0, fc);   // DD:214 fused into the 1x1 (fc: + the final 1x1 conv, `out` not written)
     } else {
         c.begin(PC_RESOUT, 0, (double)B * H * W * Cout * 6.0);
         RUN(k_resblock_out(h2.p, a2, s2, in[0].p, out.p, B, H, W, Cout, c.s));
@@ -434,11 +434,26 @@ int run_forward(Ctx& c, const float* x, int Cx, const float* cond, int Cc, const
         u->taps[p + ".3"] = xcur;
     }
     c.reset_scratch();
-    xcur = resblock(c, "final_res_block", {xcur, r}, dim);
-    u->taps["final_res_block"] = xcur;
-    c.begin(PC_MISC, 2.0 * B * H * W * dim * u->cfg.out_dim, (double)B * H * W * (dim * 2 + u->cfg.out_dim * 4));
-    RUN(k_final_conv(xcur.p, u->P("final_conv.weight"), u->P("final_conv.bias"), out, B, H, W, dim, u->cfg.out_dim, c.s));
-    c.end();
+    // inference: the final 1x1 conv (DD:361) rides on the tile of final_res_block's res_conv (conv1_wp.hip, FC): the block's 64-channel
+    // output tensor is neither written nor read.  Off when the tensor itself is wanted (training tape, ofd_unet_set_debug_taps) or the
+    // shape is not the streaming kernel's (out_dim 2, whole 128-pixel tiles)
+    static const bool no_fc = (getenv("OFD_NO_FC_FUSE") && atoi(getenv("OFD_NO_FC_FUSE"))) || (getenv("OFD_CONV1_WP") && atoi(getenv("OFD_CONV1_WP")) == 0) ||
+                              (getenv("OFD_CONV_DBG") && atoi(getenv("OFD_CONV_DBG")));
+    const bool fuse_fc = !c.train && !u->debug_taps && !no_fc && u->cfg.out_dim == 2 && dim == 64 && ((long)H * W) % 128 == 0;
+    if (fuse_fc) {
+        const FcFuse fc{u->P("final_conv.weight"), u->P("final_conv.bias"), out};
+        if (c.rc == OFD_OK && !c.dry) {
+            if (hipMemsetAsync(out, 0, (size_t)B * 2 * H * W * sizeof(float), c.s) != hipSuccess) { set_error("unet_forward: hipMemsetAsync failed"); c.rc = OFD_ERR_HIP; }
+            c.chain_ok = false;
+        }
+        xcur = resblock(c, "final_res_block", {xcur, r}, dim, true, &fc);
+    } else {
+        xcur = resblock(c, "final_res_block", {xcur, r}, dim);
+        u->taps["final_res_block"] = xcur;
+        c.begin(PC_MISC, 2.0 * B * H * W * dim * u->cfg.out_dim, (double)B * H * W * (dim * 2 + u->cfg.out_dim * 4));
+        RUN(k_final_conv(xcur.p, u->P("final_conv.weight"), u->P("final_conv.bias"), out, B, H, W, dim, u->cfg.out_dim, c.s));
+        c.end();
+    }
     if (c.train) {
         u->ts.B = B; u->ts.H = H; u->ts.W = W; u->ts.t = t; u->ts.ss = c.ss; u->ts.temb = temb; u->ts.temb_silu = temb_silu;
         u->ts.xin = xin; u->ts.r = r; u->ts.xf = xcur; u->ts.persist_used = c.persist_used;
@@ -794,10 +809,17 @@ extern "C" int ofd_unet_set_split_streams(ofd_unet* u, int enabled, int offset_b
     return OFD_OK;
 }
 
+extern "C" int ofd_unet_set_debug_taps(ofd_unet* u, int enabled) {
+    OFD_CHECK_ARG(u, "unet_set_debug_taps: null handle");
+    u->debug_taps = enabled != 0;
+    return OFD_OK;
+}
+
 extern "C" int ofd_unet_read_tap(ofd_unet* u, const char* name, float* dst, size_t numel, void* stream) {
     OFD_CHECK_ARG(u && name && dst, "unet_read_tap: null argument");
     auto it = u->taps.find(name);
-    OFD_CHECK_ARG(it != u->taps.end(), "unet_read_tap: no tap named '%s' in the last forward", name);
+    OFD_CHECK_ARG(it != u->taps.end(), "unet_read_tap: no tap named '%s' in the last forward%s", name,
+                  std::string(name) == "final_res_block" ? " (that tensor is only materialised after ofd_unet_set_debug_taps(u, 1): the final 1x1 conv normally rides on its producer)" : "");
     const Tensor& t = it->second;
     const int halves = u->last_split ? 2 : 1;            // split forward: last_B is the half batch, u->taps belongs to half 1
     OFD_CHECK_ARG(numel == (size_t)halves * u->last_B * t.C * t.H * t.W, "unet_read_tap: %s has %zu elements, got %zu", name,

@@ -139,6 +139,7 @@ struct ofd_unet {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_phase = nullptr;
     std::map<std::string, Tensor> taps_half0;
     bool last_split = false;
+    bool debug_taps = false;       // ofd_unet_set_debug_taps: every tap of the inference forward is materialised (the fused final conv is off)
     // profiling
     bool profiling = false;
     std::string dump_path;                    // per-launch CSV (class,label,ms,flops,bytes) appended on resolve
@@ -267,7 +268,8 @@ static inline bool la_train_no_ao(int C) { return C == 64 && la_fuse_to_out() &&
 
 float site_eps(const ofd_unet* u, const std::string& site);
 void conv(Ctx& c, const std::string& prefix, const std::vector<SrcSpec>& srcs, Tensor out, const float* in_scale, const float* in_shift,
-          const bf16_t* residual, const bf16_t* res_act, const float* res_scale, const float* res_shift, float* gn_partial, int cout0 = 0);
+          const bf16_t* residual, const bf16_t* res_act, const float* res_scale, const float* res_shift, float* gn_partial, int cout0 = 0,
+          const FcFuse* fc = nullptr);
 size_t persist_bytes(const ofd_unet* u, int B, int H, int W);
 size_t scratch_bytes(const ofd_unet* u, int B, int H, int W);
 size_t small_bytes(const ofd_unet* u, int B);

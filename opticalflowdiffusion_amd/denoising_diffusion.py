@@ -278,6 +278,11 @@ class Unet(nn.Module):
         L.check(L.lib().ofd_unet_read_tap(self._handle, name.encode(), L.ptr(out), out.numel(), L.stream()))
         return out
 
+    def set_debug_taps(self, enabled=True):
+        """materialise every named intermediate of the inference forward for `read_tap` (off: `final_res_block`'s output is never written,
+        the final 1x1 conv rides on its producer's tile)"""
+        L.check(L.lib().ofd_unet_set_debug_taps(self._handle, int(enabled)))
+
     def set_graph(self, enabled=True):
         """replay the inference forward as one hipGraph per (shape, stream) instead of ~250 launches (launch-bound
         regimes: small images, long sampling loops); bit-identical, ignored while profiling"""

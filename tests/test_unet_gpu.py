@@ -288,7 +288,13 @@ def test_unet_forward_vs_engine_contract_oracle(L, ch, B, H, W):
     u = make_unet(ch, P)
     with torch.no_grad():
         out = u(x.cuda(), cond.cuda(), t.cuda())
+        # the shipped forward runs the final 1x1 conv on the tile of final_res_block's res_conv (no 64-channel tensor in between, where
+        # H*W is a multiple of 128); with debug taps that tensor is materialised and the conv is its own kernel: same 64 products per
+        # pixel, another summation order
+        u.set_debug_taps(True)
+        out_dbg = u(x.cuda(), cond.cuda(), t.cuda())
     torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), out_dbg.cpu()) < 1e-5
     report = []
     for name in TAPS:
         got = u.read_tap(name, tuple(taps[name].shape)).cpu()
@@ -469,7 +475,10 @@ def test_hip_unet_against_the_reference_module_outputs(L, tag, ch):
     u = make_unet(ch, P)
     with torch.no_grad():
         out = u(g["x"].cuda(), g["cond"].cuda(), g["t"].cuda())
+        u.set_debug_taps(True)                        # (every tap materialised: the fused final conv of the shipped forward is off)
+        out_dbg = u(g["x"].cuda(), g["cond"].cuda(), g["t"].cuda())
     torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), out_dbg.cpu()) < 1e-5
     floor = rel_l2(g["y.autocast"], g["y.fp32"])
     err = rel_l2(out.cpu(), g["y.fp32"])
     print(f"\n  output: HIP vs reference fp32 {err:.3e}; reference autocast vs its fp32 {floor:.3e}; HIP vs reference autocast "
@@ -536,6 +545,19 @@ def test_forward_follows_the_parameters_after_a_rebind(L):
     assert torch.equal(y1, y2), rel_l2(y1.cpu(), y2.cpu())
     assert rel_l2(y1.cpu(), y0.cpu()) > 1e-2                # the parameters did change the function
     del junk, filler
+
+
+def test_final_res_block_tap_needs_debug_taps(L):
+    torch.manual_seed(3)
+    u = make_unet(5, default_init_params(5))
+    x, cond, t = torch.randn(1, 2, 32, 32).cuda(), torch.rand(1, 3, 32, 32).cuda(), torch.tensor([7]).cuda()
+    with torch.no_grad():
+        u(x, cond, t)
+        with pytest.raises(L.OfdError, match="ofd_unet_set_debug_taps"):
+            u.read_tap("final_res_block", (1, 64, 32, 32))
+        u.set_debug_taps(True)
+        u(x, cond, t)
+        assert bool(torch.isfinite(u.read_tap("final_res_block", (1, 64, 32, 32))).all())
 
 
 def test_split_stream_forward_is_bit_identical_per_sample(L):
