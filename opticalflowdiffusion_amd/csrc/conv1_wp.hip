@@ -61,7 +61,7 @@ struct Unit {            // 64 input channels of one source; output pixel (b, y,
 };
 
 struct Params {
-    Unit unit[8];
+    Unit unit[12];
     const bf16_t* weight;      // [Cin/8][Cout][8]
     const float* bias;
     const bf16_t* res_act;
@@ -83,7 +83,7 @@ struct Params {
 // channel 1's), and ONE float atomic per fragment adds it to the zeroed fp32 output (the other 32-channel wave adds the second addend:
 // two addends onto zero, any order, same sum).  The 922 MB bf16 tensor between the two convs is neither written nor read.
 template <int NSG, int CIN, int TILE, bool RA, int NCB = 1, bool FC = false>
-__global__ void __launch_bounds__(NTHREADS, 2) conv1x1_wp_kernel(const Params P) {
+__global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel(const Params P) {      // (768 input channels: 192 weight registers per wave, one wave per SIMD)
     constexpr int KS = CIN / 16, UNITS = CIN / 64, UNITB = TILE * 128, BUFB = UNITS * UNITB;
     constexpr int PG = 4 / NSG, F = (TILE / 32) / PG;                 // pixel groups of waves, 32-pixel fragments per wave
     constexpr int NPW = BUFB / 1024 / 4;                               // 1-KiB DMA pieces per wave and tile
@@ -345,7 +345,7 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
     if (C.res_act && !(C.res_scale && C.res_shift)) return 1;
     const int cin = C.Cin_total, plane = C.H * C.W;
     const bool ra = C.res_act != nullptr;
-    if (cin % 64 != 0 || (cin > 384 && !(cin == 512 && !ra)) || cin == 320 || (cin < 128 && !(cin == 64 && C.Cout == 384 && !ra && !C.bias)) || (C.Cout != 64 && C.Cout % 128 != 0)) return 1;
+    if (cin % 64 != 0 || (cin > 384 && !(cin == 512 && !ra) && !(cin == 768 && ra)) || cin == 320 || (cin < 128 && !(cin == 64 && C.Cout == 384 && !ra && !C.bias)) || (C.Cout != 64 && C.Cout % 128 != 0)) return 1;
     const int tile = (cin <= 128) ? 128 : (cin >= 384 ? 32 : 64);
     if (plane % tile != 0 || (size_t)C.B * plane * (size_t)(C.Cout > cin ? C.Cout : cin) * 2 >= (1ull << 40)) return 1;
     Params P{};
@@ -355,7 +355,7 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
         if (S.mode == 1) return 1;
         if (S.mode == 2 && (C.W % tile != 0)) return 1;
         for (int k = 0; k < S.chunks; ++k) {
-            if (nu >= 8) return 1;
+            if (nu >= 12) return 1;
             Unit& U = P.unit[nu++];
             U.ptr = S.ptr + S.ch_offset + k * 64;
             U.stride = S.src_channels;
@@ -385,6 +385,7 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
         return ra ? launch<4, 192, 64, true>(P, s) : launch<4, 192, 64, false>(P, s);
     }
     if (cin == 512) return narrow ? 1 : launch<4, 512, 32, false>(P, s);        // to_qkv 512 -> 384, down-sample 512 -> 256
+    if (cin == 768) return (narrow || !ra) ? 1 : launch<4, 768, 32, true>(P, s); // res_conv 768 -> 512 of ups.0 (r03: was the shared-slab kernel at a third of the HBM roof)
     if (cin == 384) {
         if (narrow) return 1;
         return ra ? launch<4, 384, 32, true>(P, s) : launch<4, 384, 32, false>(P, s);
