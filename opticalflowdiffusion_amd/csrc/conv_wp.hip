@@ -432,19 +432,26 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
     }
 }
 
+// OFD_CONV_WP_LDS_PAD=bytes: at least that much dynamic LDS per workgroup (> 80 KB: ONE 3x3 workgroup per CU, the other half of the CU's
+// registers and LDS left to kernels of the other stream of ofd_unet_set_split_streams -- the co-residency experiment of DESIGN 4.0)
+static inline int wp_lds(int need) {
+    static const int pad = getenv("OFD_CONV_WP_LDS_PAD") ? atoi(getenv("OFD_CONV_WP_LDS_PAD")) : 0;
+    return need > pad ? need : pad;
+}
+
 template <int NS, int PH, bool PRO>
 static int launch(const ConvParams& P, hipStream_t s) {
     using C = Cfg<NS, PH>;
     static bool attr_set = false;
     if (!attr_set) {
-        OFD_HIP(hipFuncSetAttribute((const void*)conv3x3_wp_kernel<NS, PH, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        OFD_HIP(hipFuncSetAttribute((const void*)conv3x3_wp_kernel<NS, PH, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, wp_lds(C::LDS_BYTES)));
         attr_set = true;
     }
     const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
     const int ntiles = P.tiles_x * tiles_y * P.B, ny = P.Cout / C::BN;
     dim3 grid(ntiles, ny);
     if (P.cy_fast) grid = dim3((ntiles + 7) / 8 * 8 * ny, 1);
-    conv3x3_wp_kernel<NS, PH, PRO><<<grid, C::NTHREADS, C::LDS_BYTES, s>>>(P);
+    conv3x3_wp_kernel<NS, PH, PRO><<<grid, C::NTHREADS, wp_lds(C::LDS_BYTES), s>>>(P);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -691,14 +698,14 @@ static int launch16(const ConvParams& P, hipStream_t s) {
     using C = Cfg<4, 1>;
     static bool attr_set = false;
     if (!attr_set) {
-        OFD_HIP(hipFuncSetAttribute((const void*)conv3x3_wp16_kernel<PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        OFD_HIP(hipFuncSetAttribute((const void*)conv3x3_wp16_kernel<PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, wp_lds(C::LDS_BYTES)));
         attr_set = true;
     }
     const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
     const int ntiles = P.tiles_x * tiles_y * P.B, ny = P.Cout / C::BN;
     dim3 grid(ntiles, ny);
     if (P.cy_fast) grid = dim3((ntiles + 7) / 8 * 8 * ny, 1);
-    conv3x3_wp16_kernel<PRO><<<grid, C::NTHREADS, C::LDS_BYTES, s>>>(P);
+    conv3x3_wp16_kernel<PRO><<<grid, C::NTHREADS, wp_lds(C::LDS_BYTES), s>>>(P);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

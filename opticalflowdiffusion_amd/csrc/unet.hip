@@ -719,7 +719,8 @@ extern "C" int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float
     // network (GroupNorm, LinearAttention and attention are per sample), so half 1 runs the same launch sequence on a second stream,
     // started `split_offset` blocks behind half 0 -- the MFMA-bound 3x3 kernels of one half share the chip with the HBM-bound
     // 1x1 / normalisation / LinearAttention kernels of the other instead of running strictly in series
-    if (u->split_streams > 0 && B >= 2 && B % 2 == 0 && !u->profiling && !u->graph_enabled) {
+    const bool split_auto = u->split_streams < 0 && (long)B * H * W >= (1L << 21);
+    if ((u->split_streams > 0 || split_auto) && B >= 2 && B % 2 == 0 && !u->profiling && !u->graph_enabled) {
         if (!u->s2) {
             OFD_HIP(hipStreamCreateWithFlags(&u->s2, hipStreamNonBlocking));
             OFD_HIP(hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming));
@@ -804,7 +805,7 @@ extern "C" int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float
 
 extern "C" int ofd_unet_set_split_streams(ofd_unet* u, int enabled, int offset_blocks) {
     OFD_CHECK_ARG(u, "unet_set_split_streams: null handle");
-    u->split_streams = enabled != 0;
+    u->split_streams = enabled < 0 ? -1 : (enabled != 0);        // (< 0: back to the size-based default)
     if (offset_blocks >= 0) u->split_offset = offset_blocks;
     return OFD_OK;
 }

@@ -39,7 +39,7 @@ struct Tensor {
 enum ProfClass { PC_CONV3 = 0, PC_CONV3_64, PC_CONV3_PP, PC_CONV1, PC_CONV7, PC_GN, PC_RESOUT, PC_LN, PC_LINATTN, PC_FLASH, PC_MISC, PC_WGRAD3, PC_WGRAD1, PC_DGRAD3, PC_DGRAD1, PC_GNBWD, PC_LABWD, PC_FLASHBWD, PC_CONVUP, PC_COUNT };
 // (class = what the executor asked for; the 3x3 classes name the kernel that serves them by default: conv_wp.hip, OFD_CONV_WP / OFD_PHASE_WP;
 //  the 64 -> 64 layers were the ping-pong kernel's until r03)
-static const char* const kProfNames[PC_COUNT] = {"conv3x3_wp_kernel<4,1>", "conv3x3_wp_kernel<2,2>", "conv3x3_wp_kernel<2,2> (64->64)", "conv1x1_igemm", "conv7x7_igemm", "gn_finalize", "resblock_out",
+static const char* const kProfNames[PC_COUNT] = {"conv3x3_wp16_kernel", "conv3x3_wp_kernel<2,2>", "conv3x3_wp_kernel<2,2> (64->64)", "conv1x1_igemm", "conv7x7_igemm", "gn_finalize", "resblock_out",
                                            "layernorm_c", "linear_attention_core", "flash_attention_d32", "misc", "conv_wgrad_kernel<3>", "conv_wgrad_kernel<1>",
                                            "conv3x3_dgrad", "conv1x1_dgrad", "gn_silu_backward", "linear_attention_backward", "flash_attention_backward",
                                            "conv_up2_phases_wp_kernel (up-sample conv as 4 phase convs)"};
@@ -133,8 +133,10 @@ struct ofd_unet {
     std::map<std::string, Tensor> taps;
     int last_B = 0;
     // two half-batch forwards on two streams (ofd_unet_set_split_streams; OFD_SPLIT_STREAMS / OFD_SPLIT_OFFSET give the defaults)
-    int split_streams = getenv("OFD_SPLIT_STREAMS") ? atoi(getenv("OFD_SPLIT_STREAMS")) : 0;
-    int split_offset = getenv("OFD_SPLIT_OFFSET") ? atoi(getenv("OFD_SPLIT_OFFSET")) : 2;   // blocks half 1 starts behind half 0
+    // -1 (default): on for even batches of at least 2^21 pixels in all (the BASELINE sizes: same-box A/B 31.24 -> 30.82 ms per denoise step at
+    // 16 x 440 x 1024, profiles/r03_split_streams_ab.jsonl; small problems are launch-bound and would pay the second launch sequence), 0: off, 1: on
+    int split_streams = getenv("OFD_SPLIT_STREAMS") ? atoi(getenv("OFD_SPLIT_STREAMS")) : -1;
+    int split_offset = getenv("OFD_SPLIT_OFFSET") ? atoi(getenv("OFD_SPLIT_OFFSET")) : 1;   // blocks half 1 starts behind half 0
     hipStream_t s2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_phase = nullptr;
     std::map<std::string, Tensor> taps_half0;

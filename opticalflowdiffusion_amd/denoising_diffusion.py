@@ -290,8 +290,9 @@ class Unet(nn.Module):
 
     def set_split_streams(self, enabled=True, offset_blocks=-1):
         """inference forward of an even batch as two half-batches on two streams, the second `offset_blocks` blocks behind the
-        first (HBM-bound kernels of one half overlap the MFMA-bound kernels of the other); bit-identical per sample"""
-        L.check(L.lib().ofd_unet_set_split_streams(self._handle, int(enabled), int(offset_blocks)))
+        first (HBM-bound kernels of one half overlap the MFMA-bound kernels of the other); bit-identical per sample.
+        enabled: True / False, or None for the engine's default (on for batches of at least 2^21 pixels in all)"""
+        L.check(L.lib().ofd_unet_set_split_streams(self._handle, -1 if enabled is None else int(bool(enabled)), int(offset_blocks)))
 
     # -- per-kernel-class device timing (HIP events on the launch stream) ----------------------
     def set_profiling(self, enabled, dump_path=None):

@@ -277,7 +277,8 @@ def test_grid_sample_warp_ring_kernel_against_the_oracle_at_size(ofd, B, H, W):
     flow[0, 0, H // 2, W // 3] = float("inf")
     flow[0, 1, 5, 7] = -float("inf")
     ro, rm = WR.warp_backward_flow(img, flow)
-    o, m = ofd.warp(None, img.cuda(), flow.cuda(), mode="backward")
+    img_d, flow_d = img.cuda(), flow.cuda()                   # (kept alive: the C call below takes raw pointers)
+    o, m = ofd.warp(None, img_d, flow_d, mode="backward")
     torch.cuda.synchronize()
     ok = torch.isfinite(ro)                                   # (non-finite grid positions: ATen returns NaN there or 0, see below)
     assert torch.equal(m.cpu()[ok], rm[ok])
@@ -285,7 +286,7 @@ def test_grid_sample_warp_ring_kernel_against_the_oracle_at_size(ofd, B, H, W):
     bad = ~torch.isfinite(flow).all(dim=1, keepdim=True).expand_as(ro)
     assert bool((o.cpu()[bad] == 0).all()) and bool((m.cpu()[bad] == 0).all())      # non-finite target: no corner in bounds (as ATen's zeros padding)
     o2 = torch.empty_like(o)
-    check(lib().ofd_grid_warp_fwd(ptr(img.cuda()), ptr(flow.cuda()), ptr(o2), None, B, 3, H, W, stream()))
+    check(lib().ofd_grid_warp_fwd(ptr(img_d), ptr(flow_d), ptr(o2), None, B, 3, H, W, stream()))
     torch.cuda.synchronize()
     assert torch.equal(o2, o)
 
