@@ -51,6 +51,9 @@ int k_linear_attention_core(const bf16_t* qkv, float* partial, float* ctx, bf16_
                             const bf16_t* wq = nullptr);
 int la_fused_blocks(int n, int B);
 int la_fwd_parts(int B, int n);
+int k_linear_attention_fused_train(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const bf16_t* woutp, const float* bias, const float* g_pre,
+                                   const float* g2, float* partial, bf16_t* ctxfrag, float* ctx, float* ml, bf16_t* xn, bf16_t* qkv, bf16_t* o2,
+                                   bf16_t* y, int B, int n, int C, float eps_pre, float eps_post, hipStream_t s);
 int k_la_weight_prep(const float* wqkv, const float* g, const float* wout, bf16_t* wq, bf16_t* wkv, bf16_t* woutp, int C, hipStream_t s);
 int k_linear_attention_fused(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const bf16_t* woutp, const float* bias, const float* g2,
                              float* partial, bf16_t* ctxfrag, bf16_t* y, int B, int n, int C, float eps_pre, float eps_post, hipStream_t s);

@@ -112,6 +112,52 @@ __device__ __forceinline__ void norm_x(const XRaw<C>& r, float eps, bf16x8 (&xs)
 #endif
 }
 
+// Training form: the fragments ARE the LayerNorm output xn = x^ * g rounded to bf16 (what the unfused path stores and multiplies by the
+// plain weights, and what the backward's q recompute / to_qkv weight gradient read) -- g: the PreNorm gain, fp32 [C] in LDS.
+template <int C>
+__device__ __forceinline__ void norm_x_gain(const XRaw<C>& r, float eps, const float* __restrict__ g, int half, bf16x8 (&xs)[C / 16]) {
+    constexpr int KS = C / 16;
+    const la_bf16x2 one = __builtin_bit_cast(la_bf16x2, 0x3f803f80u);
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const la_bf16x2 w = __builtin_bit_cast(la_bf16x2, (uint32_t)r.v[s][j]);
+            s1 = __builtin_amdgcn_fdot2_f32_bf16(w, one, s1, false);
+            s2 = __builtin_amdgcn_fdot2_f32_bf16(w, w, s2, false);
+        }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float mean = s1 * (1.0f / C);
+    const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * (1.0f / C)), 0.0f);
+    const float rstd = rsqrtf(var + eps), off = -mean * rstd;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const float4 g0 = *(const float4*)(g + 16 * s + 8 * half), g1 = *(const float4*)(g + 16 * s + 8 * half + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t w = r.v[s][j];
+            xs[s][2 * j] = (__bf16)(__builtin_fmaf(bf2f((bf16_t)(w & 0xffffu)), rstd, off) * gg[2 * j]);
+            xs[s][2 * j + 1] = (__bf16)(__builtin_fmaf(bf2f((bf16_t)(w >> 16)), rstd, off) * gg[2 * j + 1]);
+        }
+    }
+}
+
+// accumulator tile [rows = 32 channels][col = this lane's pixel] -> bf16, 16-byte stores: pairs of register quads are exchanged between the
+// half-waves (v_permlane32_swap) so that a lane stores 8 consecutive channels of its pixel; `row` = that pixel's first channel of the tile
+__device__ __forceinline__ void store_acc_rows(const f32x16& a, bf16_t* __restrict__ row, int half, bool ok) {
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+        const uint2 q0 = make_uint2(la_pack2(a[4 * g], a[4 * g + 1]), la_pack2(a[4 * g + 2], a[4 * g + 3]));
+        const uint2 q1 = make_uint2(la_pack2(a[4 * g + 4], a[4 * g + 5]), la_pack2(a[4 * g + 6], a[4 * g + 7]));
+        const auto rx = __builtin_amdgcn_permlane32_swap(q0.x, q1.x, false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(q0.y, q1.y, false, false);
+        if (ok) *(uint4*)(row + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+    }
+}
+
 // ---- end of pass 1: the workgroup's four waves merge their online-softmax states (m, l, ctx relative to m) of one head through LDS and
 // write ONE part: a quarter of the partial traffic, and a grid of 256+ workgroups (small batches) stays within the combine's 256 parts.
 // Part format unchanged: [m 32 | l 32 | ctx[d][e] 32 x 32].  LDS: 4 x LA_PART_PITCH floats (rows padded to 36 floats).
@@ -157,13 +203,22 @@ __device__ __forceinline__ void la_store_part(float* lds, float* __restrict__ o,
 }
 
 // ---- pass 1 ---------------------------------------------------------------------------------------
-template <int C>
+// TRAIN (the training forward, C = 64): the pass also WRITES what the backward reads -- xn (LayerNorm output with the gain, bf16) and k | v
+// (channels 128 .. 383 of the [pixel][384] qkv tensor) -- so the LayerNorm kernel, the to_qkv conv and the read of k, v by la_ctx_stored_kernel
+// disappear (11 -> 6 tensor passes of 64 channels).  Its operands are those of the unfused path: xn rounded to bf16 times the PLAIN weights
+// (wkv: not folded with the gain), k rounded to bf16 before the softmax.  k, v leave through a second projection with the operands swapped
+// (rows = channel, col = pixel: a lane owns whole 8-channel units of its pixel and stores 16 bytes); the MFMA pipe has the room.
+template <int C, bool TRAIN>
 __global__ void __launch_bounds__(256, 2) la_ctx_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wkv,
-                                                           float* __restrict__ partial, int n, float eps, float defer) {
+                                                           float* __restrict__ partial, int n, float eps, float defer,
+                                                           const float* __restrict__ g, bf16_t* __restrict__ xn_out, bf16_t* __restrict__ qkv_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KS = C / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     for (int i = tid; i < (C / 8) * 256; i += 256) ((uint4*)smem)[i] = ((const uint4*)wkv)[i];
+    float* s_g = (float*)(smem + (C / 8) * 256 * 16);
+    if constexpr (TRAIN)
+        for (int i = tid; i < C; i += 256) s_g[i] = g[i];
     __syncthreads();
     const int b = blockIdx.y, wave_id = blockIdx.x * 4 + wave, nw = gridDim.x * 4, ntiles = (n + 31) / 32;
 
@@ -187,7 +242,31 @@ __global__ void __launch_bounds__(256, 2) la_ctx_fused_kernel(const bf16_t* __re
         // software prefetch of the next tile's rows (clamped: the last prefetch re-reads a valid row)
         load_raw_x<C>(xb + (size_t)min((tile + nw) * 32 + l31, n - 1) * C, raw_next, half);
         bf16x8 xs[KS];
-        norm_x<C>(raw, eps, xs);
+        const int pix = tile * 32 + l31;
+        if constexpr (TRAIN) {
+            norm_x_gain<C>(raw, eps, s_g, half, xs);
+            if (pix < n) {
+                bf16_t* xrow = xn_out + ((size_t)b * n + pix) * C;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) *(bf16x8*)(xrow + 16 * s + 8 * half) = xs[s];
+            }
+        } else {
+            norm_x<C>(raw, eps, xs);
+        }
+        if constexpr (TRAIN) {
+            // the stored k | v: the same products with rows = channel, col = pixel, one 32-channel block at a time (16 live accumulator registers)
+            bf16_t* qrow = qkv_out + ((size_t)b * n + min(pix, n - 1)) * 384 + 128;
+#pragma unroll
+            for (int blk = 0; blk < 8; ++blk) {
+                f32x16 t;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(smem + ((size_t)(2 * s + half) * 256 + blk * 32 + l31) * 16), xs[s], t, 0, 0, 0);
+                store_acc_rows(t, qrow + blk * 32, half, pix < n);
+            }
+        }
 #pragma unroll
         for (int hd = 0; hd < 4; ++hd) {
             f32x16 ka, va;
@@ -199,6 +278,10 @@ __global__ void __launch_bounds__(256, 2) la_ctx_fused_kernel(const bf16_t* __re
                 const bf16x8 wv = *(const bf16x8*)(smem + ((size_t)(2 * s + half) * 256 + 128 + hd * 32 + l31) * 16);
                 ka = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[s], wk, ka, 0, 0, 0);   // rows = pixels, col = d
                 va = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[s], wv, va, 0, 0, 0);   // rows = pixels, col = e
+            }
+            if constexpr (TRAIN) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ka[r] = bf2f(f2bf(ka[r]));      // the softmax sees the stored (bf16) k, as the backward will
             }
             float mt = -3.0e38f;
             if (tile * 32 + 32 > n) {            // (only a sample's last tile has rows past its end: 32 compares + selects per head otherwise)
@@ -411,11 +494,15 @@ __global__ void __launch_bounds__(256) la_ctx_combine_frag_kernel(const float* _
 }
 
 // ---- pass 2 ---------------------------------------------------------------------------------------
-template <int C>
+// TRAIN (the training forward, C = 64): operands as the unfused path has them (xn with the gain rounded to bf16 times the plain Wq, q rounded
+// to bf16 before its softmax -- what the backward recomputes), and o2 = to_out.0's output is WRITTEN (bf16; the to_out.1 LayerNorm backward
+// reads it) and the LayerNorm runs on those rounded values: lc_out_kernel + the LayerNorm kernel (5 tensor passes) become 3.
+template <int C, bool TRAIN>
 __global__ void __launch_bounds__(256, C == 64 ? 4 : 2) la_out_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wq,
                                                            const bf16_t* __restrict__ woutp, const bf16_t* __restrict__ ctxfrag,
                                                            const float* __restrict__ bias, const float* __restrict__ g2,
-                                                           bf16_t* __restrict__ y, int n, float eps_pre, float eps_post, float scale) {
+                                                           bf16_t* __restrict__ y, int n, float eps_pre, float eps_post, float scale,
+                                                           const float* __restrict__ g, bf16_t* __restrict__ o2_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KS = C / 16, RT = C / 32;
     constexpr int WQ_B = (C / 8) * 128 * 16, WO_B = 16 * C * 16, CF_B = 4 * 2 * 64 * 16;
@@ -424,8 +511,11 @@ __global__ void __launch_bounds__(256, C == 64 ? 4 : 2) la_out_fused_kernel(cons
     unsigned char* s_cf = s_wo + WO_B;
     float* s_bias = (float*)(s_cf + CF_B);
     float* s_g2 = s_bias + C;
+    float* s_g = s_g2 + C;                 // TRAIN: the PreNorm gain
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int b = blockIdx.y;
+    if constexpr (TRAIN)
+        for (int i = tid; i < C; i += 256) s_g[i] = g[i];
     for (int i = tid; i < WQ_B / 16; i += 256) ((uint4*)s_wq)[i] = ((const uint4*)wq)[i];
     for (int i = tid; i < WO_B / 16; i += 256) ((uint4*)s_wo)[i] = ((const uint4*)woutp)[i];
     for (int i = tid; i < CF_B / 16; i += 256) ((uint4*)s_cf)[i] = ((const uint4*)(ctxfrag + (size_t)b * 4096))[i];
@@ -444,7 +534,8 @@ __global__ void __launch_bounds__(256, C == 64 ? 4 : 2) la_out_fused_kernel(cons
         const XRaw<C> raw = raw_next;
         load_raw_x<C>(xb + (size_t)min((tile + nw) * 32 + l31, n - 1) * C, raw_next, half);
         bf16x8 xs[KS];
-        norm_x<C>(raw, eps_pre, xs);
+        if constexpr (TRAIN) norm_x_gain<C>(raw, eps_pre, s_g, half, xs);
+        else norm_x<C>(raw, eps_pre, xs);
         f32x16 acc_o[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -459,6 +550,10 @@ __global__ void __launch_bounds__(256, C == 64 ? 4 : 2) la_out_fused_kernel(cons
             for (int s = 0; s < KS; ++s) {   // rows = d, col = pixel
                 const bf16x8 wf = *(const bf16x8*)(s_wq + ((size_t)(2 * s + half) * 128 + hd * 32 + l31) * 16);
                 qa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xs[s], qa, 0, 0, 0);
+            }
+            if constexpr (TRAIN) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) qa[r] = bf2f(f2bf(qa[r]));
             }
             float mx = qa[0];                 // softmax over d (DD:234) then * scale (DD:237)
 #pragma unroll
@@ -497,8 +592,17 @@ __global__ void __launch_bounds__(256, C == 64 ? 4 : 2) la_out_fused_kernel(cons
             for (int g = 0; g < 4; ++g) {
                 const float4 bv = *(const float4*)(s_bias + rt * 32 + 8 * g + 4 * half);
                 acc_o[rt][4 * g] += bv.x; acc_o[rt][4 * g + 1] += bv.y; acc_o[rt][4 * g + 2] += bv.z; acc_o[rt][4 * g + 3] += bv.w;
+                if constexpr (TRAIN) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc_o[rt][4 * g + k] = bf2f(f2bf(acc_o[rt][4 * g + k]));       // o2 as stored
+                }
                 sum += (acc_o[rt][4 * g] + acc_o[rt][4 * g + 1]) + (acc_o[rt][4 * g + 2] + acc_o[rt][4 * g + 3]);
             }
+        if constexpr (TRAIN) {
+            bf16_t* orow = o2_out + ((size_t)b * n + min(pix, n - 1)) * C;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) store_acc_rows(acc_o[rt], orow + rt * 32, half, pix < n);
+        }
         sum += __shfl_xor(sum, 32, 64);
         const float mean = sum * (1.0f / C);
         float q = 0.0f;
@@ -554,18 +658,23 @@ __global__ void __launch_bounds__(256) la_weight_prep_kernel(const float* __rest
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         if (i < 128 * C) {
             const int j = i & 7, o = (i >> 3) & 127, c8 = i >> 10, c = c8 * 8 + j;
-            wq[i] = f2bf(wqkv[(size_t)o * C + c] * g[c]);
+            wq[i] = f2bf(wqkv[(size_t)o * C + c] * (g ? g[c] : 1.0f));
         } else if (i < 384 * C) {
             const int k = i - 128 * C;
             const int j = k & 7, o = (k >> 3) & 255, c8 = k >> 11, c = c8 * 8 + j;
-            wkv[k] = f2bf(wqkv[(size_t)(128 + o) * C + c] * g[c]);
-        } else {
+            wkv[k] = f2bf(wqkv[(size_t)(128 + o) * C + c] * (g ? g[c] : 1.0f));
+        } else if (woutp) {
             const int k = i - 384 * C;
             const int j = k & 7, c = (k >> 3) % C, rest = (k >> 3) / C;   // rest = (hd*2+s2)*2 + half
             const int hh = rest & 1, s2 = (rest >> 1) & 1, hd = rest >> 2;
             woutp[k] = f2bf(wout[(size_t)c * 128 + hd * 32 + 16 * s2 + 8 * (j >> 2) + 4 * hh + (j & 3)]);
         }
     }
+}
+
+static float la_defer() {
+    static const float defer = getenv("OFD_LA_DEFER") ? (float)atof(getenv("OFD_LA_DEFER")) : 5.545177f;      // 8 ln 2; 0: the reference point follows every new maximum
+    return defer;
 }
 
 template <int C>
@@ -575,13 +684,13 @@ static int launch_la(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const
     constexpr int LDS2 = (C / 8) * 128 * 16 + 16 * C * 16 + 4 * 2 * 64 * 16 + 2 * C * 4;
     static bool attr = false;
     if (!attr) {
-        OFD_HIP(hipFuncSetAttribute((const void*)la_ctx_fused_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1));
-        OFD_HIP(hipFuncSetAttribute((const void*)la_out_fused_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+        OFD_HIP(hipFuncSetAttribute((const void*)la_ctx_fused_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1));
+        OFD_HIP(hipFuncSetAttribute((const void*)la_out_fused_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
         attr = true;
     }
     const int gx = la_fused_blocks(n, B);
-    static const float defer = getenv("OFD_LA_DEFER") ? (float)atof(getenv("OFD_LA_DEFER")) : 5.545177f;      // 8 ln 2; 0: the reference point follows every new maximum
-    la_ctx_fused_kernel<C><<<dim3(gx, B), 256, LDS1, s>>>(x, wkv, partial, n, eps_pre, defer);
+    const float defer = la_defer();
+    la_ctx_fused_kernel<C, false><<<dim3(gx, B), 256, LDS1, s>>>(x, wkv, partial, n, eps_pre, defer, nullptr, nullptr, nullptr);
     la_ctx_combine_frag_kernel<<<dim3(B * 4, 4), 256, 0, s>>>(partial, ctxfrag, gx, 1.0f / (float)n);
     int gx2 = cdiv(cdiv(n, 32), 4 * 4);     // >= 4 tiles per wave amortise the weight staging
     if (gx2 < 1) gx2 = 1;
@@ -589,7 +698,36 @@ static int launch_la(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const
     if (gx2_cap < 0) { const char* e = getenv("OFD_LA_GX2"); gx2_cap = e ? atoi(e) : 128; }
     const int cap2 = (gx2_cap * B < 1024) ? 1024 / B : gx2_cap;          // small batches: enough workgroups for the chip
     if (gx2 > cap2) gx2 = cap2;
-    la_out_fused_kernel<C><<<dim3(gx2, B), 256, LDS2, s>>>(x, wq, woutp, ctxfrag, bias, g2, y, n, eps_pre, eps_post, 0.17677669529663687f);
+    la_out_fused_kernel<C, false><<<dim3(gx2, B), 256, LDS2, s>>>(x, wq, woutp, ctxfrag, bias, g2, y, n, eps_pre, eps_post, 0.17677669529663687f, nullptr, nullptr);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+void launch_la_ctx_combine(const float* partial, float* ctx, int B, int nparts, float inv_n, float* ml_out, hipStream_t s);   // blocks.hip
+
+// The training forward of a 64-channel block: the two fused passes, which also leave the tape (xn, k | v inside qkv, o2) and the fp32 context + softmax
+// statistics (ctx, ml) of the unfused path for the backward (unet_train.hip linattn_backward).  wq / wkv: the PLAIN to_qkv weights in fragment layout.
+int k_linear_attention_fused_train(const bf16_t* x, const bf16_t* wq, const bf16_t* wkv, const bf16_t* woutp, const float* bias, const float* g_pre,
+                                   const float* g2, float* partial, bf16_t* ctxfrag, float* ctx, float* ml, bf16_t* xn, bf16_t* qkv, bf16_t* o2,
+                                   bf16_t* y, int B, int n, int C, float eps_pre, float eps_post, hipStream_t s) {
+    if (C != 64) { set_error("linear_attention_fused_train: C=%d unsupported", C); return OFD_ERR_ARG; }
+    constexpr int LDS1 = (64 / 8) * 256 * 16 + 64 * 4;
+    constexpr int LDS2 = (64 / 8) * 128 * 16 + 16 * 64 * 16 + 4 * 2 * 64 * 16 + 3 * 64 * 4;
+    static bool attr = false;
+    if (!attr) {
+        OFD_HIP(hipFuncSetAttribute((const void*)la_ctx_fused_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1));
+        OFD_HIP(hipFuncSetAttribute((const void*)la_out_fused_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
+        attr = true;
+    }
+    const int gx = la_fused_blocks(n, B);
+    la_ctx_fused_kernel<64, true><<<dim3(gx, B), 256, LDS1, s>>>(x, wkv, partial, n, eps_pre, la_defer(), g_pre, xn, qkv);
+    la_ctx_combine_frag_kernel<<<dim3(B * 4, 4), 256, 0, s>>>(partial, ctxfrag, gx, 1.0f / (float)n);
+    launch_la_ctx_combine(partial, ctx, B, gx, 1.0f / (float)n, ml, s);
+    int gx2 = cdiv(cdiv(n, 32), 4 * 4);
+    if (gx2 < 1) gx2 = 1;
+    const int cap2 = (128 * B < 1024) ? 1024 / B : 128;
+    if (gx2 > cap2) gx2 = cap2;
+    la_out_fused_kernel<64, true><<<dim3(gx2, B), 256, LDS2, s>>>(x, wq, woutp, ctxfrag, bias, g2, y, n, eps_pre, eps_post, 0.17677669529663687f, g_pre, o2);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -609,7 +747,7 @@ int la_fused_blocks(int n, int B) {
 }
 
 int k_la_weight_prep(const float* wqkv, const float* g, const float* wout, bf16_t* wq, bf16_t* wkv, bf16_t* woutp, int C, hipStream_t s) {
-    la_weight_prep_kernel<<<cdiv(512 * C, 256), 256, 0, s>>>(wqkv, g, wout, wq, wkv, woutp, C);
+    la_weight_prep_kernel<<<cdiv((woutp ? 512 : 384) * C, 256), 256, 0, s>>>(wqkv, g, wout, wq, wkv, woutp, C);      // g == nullptr: plain weights; woutp == nullptr: q | k | v only
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }

@@ -69,6 +69,7 @@ static void add_linattn(ofd_unet* u, const std::string& name, int c) {
     if (c <= 128) {
         u->la_fused[name] = {u->n_labuf, c};
         u->n_labuf += (size_t)512 * c;
+        if (c == 64) u->n_labuf += (size_t)384 * c;      // + the plain (gain not folded in) wq | wkv of the fused TRAINING forward
     }
 }
 
@@ -223,6 +224,26 @@ static Tensor linattn(Ctx& c, const std::string& name, Tensor x) {
     }
     Tensor xn = c.tmp(C, H, W), qkv = c.tmp(384, H, W), ao = c.tmp(128, H, W), o2 = c.tmp(C, H, W);
     const int nparts = la_fwd_parts(B, n);
+    if (c.train && fit != u->la_fused.end() && la_train_fused(C)) {
+        // training, 64 channels: the two fused passes leave the tape themselves (xn, k | v, o2, ctx, ml): no LayerNorm kernels, no to_qkv conv
+        float* partial = c.tmpf((size_t)B * 4 * nparts * 1088);
+        bf16_t* ctxfrag = (bf16_t*)c.tmpf((size_t)B * 2048);
+        float* ctx = c.keepf((size_t)B * 4 * 1024);
+        float* ml = c.keepf((size_t)B * 4 * 64);
+        Tensor y = c.keep(C, H, W);
+        if (c.rc != OFD_OK) return y;
+        const bf16_t* base = u->d_labuf + fit->second.first;
+        c.begin(PC_LINATTN, npix * 2.0 * (C * 640.0 + 2 * 4 * 32 * 32 + 128.0 * C), (double)npix * C * 2 * (2 + 1 + 4 + 2),
+                name + " fused (training) C=" + std::to_string(C) + " @" + std::to_string(H) + "x" + std::to_string(W));
+        RUN(k_linear_attention_fused_train(x.p, base + (size_t)512 * C, base + (size_t)640 * C, base + (size_t)384 * C, u->P(name + ".fn.fn.to_out.0.bias"),
+                                           u->P(name + ".fn.norm.g"), u->P(name + ".fn.fn.to_out.1.g"), partial, ctxfrag, ctx, ml, xn.p, qkv.p, o2.p, y.p,
+                                           B, n, C, site_eps(u, name + ".fn.norm"), site_eps(u, name + ".fn.fn.to_out.1"), c.s));
+        c.end();
+        TapeRec r;
+        r.kind = TK_LINATTN; r.name = name; r.x = x; r.xn = xn; r.qkv = qkv; r.ao = ao; r.o2 = o2; r.out = y; r.ctx = ctx; r.ml = ml;
+        u->tape.push_back(r);
+        return y;
+    }
     float* partial = c.tmpf((size_t)B * 4 * nparts * 1088);
     float* ctx = c.train ? c.keepf((size_t)B * 4 * 1024) : c.tmpf((size_t)B * 4 * 1024);
     float* ml = c.train ? c.keepf((size_t)B * 4 * 64) : nullptr;
@@ -649,6 +670,10 @@ extern "C" int ofd_unet_prepare(ofd_unet* u, void* stream) {
         int rc = k_la_weight_prep(u->P(name + ".fn.fn.to_qkv.weight"), u->P(name + ".fn.norm.g"), u->P(name + ".fn.fn.to_out.0.weight"),
                                   base, base + (size_t)128 * C, base + (size_t)384 * C, C, (hipStream_t)stream);
         if (rc != OFD_OK) return rc;
+        if (C == 64) {
+            rc = k_la_weight_prep(u->P(name + ".fn.fn.to_qkv.weight"), nullptr, nullptr, base + (size_t)512 * C, base + (size_t)640 * C, nullptr, C, (hipStream_t)stream);
+            if (rc != OFD_OK) return rc;
+        }
     }
     u->prepared = true;
     u->wt_prepared = false;

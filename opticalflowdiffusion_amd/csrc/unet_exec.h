@@ -256,6 +256,11 @@ static inline bool la_bwd_fuse_dao() { static const bool v = la_env_on("OFD_LA_B
 static inline bool la_recompute_q() { static const bool v = la_env_on("OFD_LA_RECOMPUTE_Q"); return v; }
 // 64-channel block with every fusion on: the backward needs neither dout nor ao (the forward does not write ao then)
 static inline bool la_train_no_ao(int C) { return C == 64 && la_fuse_to_out() && la_bwd_fuse_qkv() && la_bwd_fuse_dao(); }
+// the training forward of a 64-channel block as the two fused passes (la_fused.hip TRAIN forms); OFD_LA_TRAIN_FUSED=0: LayerNorm + to_qkv conv + core
+static inline bool la_train_fused(int C) {
+    static const bool v = la_env_on("OFD_LA_TRAIN_FUSED");
+    return v && la_train_no_ao(C) && la_recompute_q();
+}
 
 #define RUN(expr)                         \
     do {                                  \
