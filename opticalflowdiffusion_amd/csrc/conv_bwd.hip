@@ -11,6 +11,7 @@
 //   * wgrad_finish_kernel: layout back to OIHW and the backward of weight standardisation
 //     (denoising_diffusion.py:109-112).
 #include <cstdlib>
+#include <type_traits>
 #include "blocks.h"
 #include "conv_params.h"
 #include "mfma_util.h"
@@ -68,6 +69,7 @@ struct WgradParams {
     const float* in_scale;
     const float* in_shift;
     int no_dma;          // A/B switch (OFD_WGRAD_NO_DMA): 3x3 dY tiles through registers
+    int dbg;             // conv_wgrad3_db_kernel ablation bits (OFD_WGRAD_DBG; 0 in production): 1 no DMA after the first tile, 2 no fragment reads after the first row, 4 no MFMAs
     // 3x3 only: where output pixel (b, oy, ox) of the (H, W) grid lives in dY: pixel b * dy_bs + (oy * dy_s + dy_y0) * dy_w + ox * dy_s + dy_x0
     // (plain: dy_bs = H W, dy_w = W, dy_s = 1; one phase of an up-sample conv, see conv_wgrad3_kernel: the stride-2 samples of the 2H x 2W tensor)
     long dy_bs;
@@ -542,6 +544,193 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
         }
 }
 
+// ---- 3x3, double-buffered (r03): the kernel above alternates "stage a tile" and "multiply it" inside a workgroup and relies on the second
+// resident workgroup to fill the gaps (staging alone 14.5 ms, MFMAs alone 17.0 ms, together 25.2 ms per training step).  Here ONE workgroup of
+// 8 waves per CU owns both LDS halves (2 x 75 KB): while tile t is multiplied, the halo tile and the dY tile of tile t + 1 arrive by LDS-DMA
+// (global_load_lds_dwordx4, no staging registers) in the other half -- one wait + one barrier per tile.
+//   * wave -> (16-pixel column block xb, 32 ci x 32 co quadrant): all ten halo rows, nine accumulator tiles (144 registers), 72 MFMAs per tile;
+//   * the operand fragments are read with inline-asm ds_read_b64_tr_b16 (one base register per operand, immediate offsets): an LDS load the
+//     compiler can see makes it wait for every outstanding LDS-DMA, i.e. for the NEXT tile.  Row rr + 1's fragments are requested before row
+//     rr's MFMAs are issued and awaited (lgkmcnt(0)) after them;
+//   * halo pixels outside the image / pixels of a tile overhang are fetched from a clamped address and zeroed in LDS by the lane that fetched
+//     them, after its own vmcnt(0) and before the barrier.
+template <int OFF>
+__device__ __forceinline__ void lds_tr8(s16x4& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+struct TrFrag {
+    s16x4 lo, hi;
+    __device__ __forceinline__ bf16x8 get() const {
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+};
+template <int OFF>
+__device__ __forceinline__ void tr_read(TrFrag& f, unsigned addr) {      // rows 128 bytes apart
+    lds_tr8<OFF>(f.lo, addr);
+    lds_tr8<OFF + 512>(f.hi, addr);
+}
+__device__ __forceinline__ void lds_landed(TrFrag& a, TrFrag& b, TrFrag& c, TrFrag& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi) : : "memory");
+}
+template <int I, int N, class Fn>
+__device__ __forceinline__ void wg_static_for(Fn&& fn) {
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        wg_static_for<I + 1, N>(fn);
+    }
+}
+
+__global__ void __launch_bounds__(512, 1) conv_wgrad3_db_kernel(const WgradParams P) {
+    constexpr int IWK = 34, XPIX = 10 * IWK, XPIECES = (XPIX + 7) / 8, XB = XPIECES * 1024, BUF = XB + 256 * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
+    const int ncob = P.Cout / 64, kc = blockIdx.y / ncob, cob = blockIdx.y % ncob;
+    const int quad = wave & 3, xb = wave >> 2, cit = quad & 1, cot = quad >> 1;
+    const int tpi = P.tiles_x * P.tiles_y, ntiles = tpi * P.B;
+    int si = 0, first = 0;
+    while (si + 1 < P.n_src && kc >= first + P.src[si].chunks) { first += P.src[si].chunks; ++si; }
+    const int kcl = kc - first;
+    const ConvSrcDev S = P.src[si];
+    const bool do_bias = P.dbias && kc == 0;
+    float bsum = 0.0f;
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][k][r] = 0.0f;
+
+    // tile-invariant part of this lane's DMA addresses: (row, column) of its halo pixels inside the tile, its swizzled channel unit
+    // (LDS rows are 128 bytes = all 32 banks: unswizzled, the four rows a 16-lane group of a transposing read touches collide 4-way.  The
+    // 16-byte unit u of tile pixel p therefore holds channel unit u ^ 2 (p & 3) -- the DMA is lane-linear, so the permutation is applied
+    // to each lane's SOURCE address, and again to the fragment reads' addresses)
+    const int H = P.H, W = P.W, SW = S.SW, sch = S.src_channels, tiles_x = P.tiles_x;
+    // source pixel of conv-input pixel (cy, cx), branch-free: same size (c), nearest up-sampled (c >> 1), pixel-unshuffled sub-pixel (2 c + p)
+    const int m_mul = S.mode == 2 ? 2 : 1, m_shr = S.mode == 1 ? 1 : 0, m_ay = S.mode == 2 ? S.p1 : 0, m_ax = S.mode == 2 ? S.p2 : 0;
+    const int dy_s = P.dy_s, dy_w = P.dy_w, dy_y0 = P.dy_y0, dy_x0 = P.dy_x0, Cout = P.Cout;
+    const int swz = ((lane & 7) ^ (2 * ((lane >> 3) & 3))) * 8;          // (piece * 8 is a multiple of 4: pixel & 3 = (lane >> 3) & 3)
+    int x_ty[6], x_tx[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int pc = min((wave + 8 * i) * 8 + (lane >> 3), XPIX - 1);
+        x_ty[i] = pc / IWK - 1;
+        x_tx[i] = pc - (pc / IWK) * IWK - 1;
+    }
+    const bf16_t* xsrc = S.ptr + S.ch_offset + kcl * 64 + swz;
+    const size_t x_bs = (size_t)S.SH * SW * sch;
+    const bf16_t* ysrc = P.dy + cob * 64 + swz;
+    const int y_r = (wave * 32 + (lane >> 3)) >> 5, y_c = (wave * 32 + (lane >> 3)) & 31;      // dY piece j of this wave: pixel (y_r, y_c + 8 j)
+    // requests tile t into `buf`; returns the mask of this lane's pieces that must read as zero (bits 0..5: halo pieces, 8..11: dY pieces)
+    auto issue = [&](int t, unsigned char* buf) -> unsigned {
+        const int b = t / tpi, t_in = t - b * tpi;
+        const int oy0 = (t_in / tiles_x) * 8, ox0 = (t_in % tiles_x) * 32;
+        unsigned zm = 0;
+        const bf16_t* xb_ = xsrc + (size_t)b * x_bs;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int piece = wave + 8 * i;                 // wave-uniform
+            if (piece < XPIECES) {
+                const int iy = oy0 + x_ty[i], ix = ox0 + x_tx[i];
+                const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+                zm |= ((cy == iy && cx == ix) ? 0u : 1u) << i;
+                const int sy = ((cy * m_mul) >> m_shr) + m_ay, sx = ((cx * m_mul) >> m_shr) + m_ax;
+                __builtin_amdgcn_global_load_lds(xb_ + (size_t)(unsigned)((sy * SW + sx) * sch), (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
+            }
+        }
+        const bf16_t* yb_ = ysrc + (size_t)b * P.dy_bs * Cout;
+        const int oy = oy0 + y_r, cyy = min(oy, H - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ox = ox0 + y_c + 8 * j, cxx = min(ox, W - 1);
+            zm |= ((oy < H && ox < W) ? 0u : 1u) << (8 + j);
+            __builtin_amdgcn_global_load_lds(yb_ + (size_t)(unsigned)(((cyy * dy_s + dy_y0) * dy_w + cxx * dy_s + dy_x0) * Cout),
+                                             (__attribute__((address_space(3))) void*)(buf + XB + (wave * 4 + j) * 1024), 16, 0, 0);
+        }
+        return zm;
+    };
+
+    // per-lane base addresses of the transposing reads inside a buffer (see tr_frag): rows = pixels, 128 bytes apart
+    const int li = lane & 15, tq = li >> 2, tp = li & 3, tcb = (lane >> 4) & 1;
+    // swizzled: this lane's row is base row + 8 half + tq (+ 4); k = (base row) & 3 selects one of four per-lane offsets
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto lane_off = [&](int unit0, int k) {      // unit0: first 16-byte unit of the wave's 32-channel block
+        return (unsigned)((8 * half + tq) * 128 + (((unit0 + tcb * 2 + (tp >> 1)) ^ (2 * ((k + tq) & 3))) * 16) + (tp & 1) * 8);
+    };
+    unsigned x_off[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x_off[k] = lane_off(cit * 4, k) + (unsigned)(xb * 16 * 128);
+    const unsigned y_off = lane_off(cot * 4, 0) + (unsigned)(XB + xb * 16 * 128);
+
+    int t = blockIdx.x, cur = 0;
+    unsigned zm = 0;
+    if (t < ntiles) zm = issue(t, smem);
+    for (; t < ntiles; t += gridDim.x) {
+        unsigned char* buf = smem + cur * BUF;
+        if (!(P.dbg & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile t have landed
+        if (zm) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if ((zm >> i) & 1u) *(u32x4*)(buf + (wave + 8 * i) * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((zm >> (8 + j)) & 1u) *(u32x4*)(buf + XB + (wave * 4 + j) * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+        __syncthreads();                                         // tile t is complete; everyone is done reading the other half (tile t - 1)
+        if (do_bias) {                                           // (before the next DMA is requested: these are loads the compiler sees)
+            const int co = tid & 63, part = tid >> 6;
+            const unsigned char* ys = buf + XB;
+#pragma unroll 8
+            for (int p = part * 32; p < part * 32 + 32; ++p) bsum += bf2f(*(const bf16_t*)(ys + p * 128 + (((co >> 3) ^ (2 * (p & 3))) * 16) + (co & 7) * 2));
+        }
+        const int tn = t + gridDim.x;
+        if (tn < ntiles && !(P.dbg & 1)) zm = issue(tn, smem + (cur ^ 1) * BUF);
+        unsigned xa[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xa[k] = smem_base + (unsigned)(cur * BUF) + x_off[k];
+        const unsigned ya = smem_base + (unsigned)(cur * BUF) + y_off;
+        // halo row rr feeds output rows rr, rr - 1, rr - 2 (ky = 0, 1, 2); fragment sets alternate between rows
+        TrFrag xf[2][3], yn[2];
+        bf16x8 yw[3];                                            // dY fragments of output rows rr, rr - 1, rr - 2
+        tr_read<0>(xf[0][0], xa[0]); tr_read<128>(xf[0][1], xa[1]); tr_read<256>(xf[0][2], xa[2]);
+        tr_read<0>(yn[0], ya);
+        wg_static_for<0, 10>([&](auto RR) {
+            constexpr int rr = decltype(RR)::value, c = rr & 1, nx = c ^ 1;
+            lds_landed(xf[c][0], xf[c][1], xf[c][2], yn[c]);
+            yw[2] = yw[1];
+            yw[1] = yw[0];
+            if constexpr (rr < 8) yw[0] = yn[c].get();
+            if (rr + 1 < 10 && !(P.dbg & 2)) {
+                tr_read<((rr + 1) * IWK) * 128>(xf[nx][0], xa[((rr + 1) * IWK) & 3]);
+                tr_read<((rr + 1) * IWK + 1) * 128>(xf[nx][1], xa[((rr + 1) * IWK + 1) & 3]);
+                tr_read<((rr + 1) * IWK + 2) * 128>(xf[nx][2], xa[((rr + 1) * IWK + 2) & 3]);
+                if constexpr (rr + 1 < 8) tr_read<(rr + 1) * 32 * 128>(yn[nx], ya);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const bf16x8 xv = xf[c][kx].get();
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+                    if (rr - ky >= 0 && rr - ky < 8 && !(P.dbg & 4)) acc[ky][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xv, yw[ky], acc[ky][kx], 0, 0, 0);   // rows = ci, cols = co
+            }
+        });
+        cur ^= 1;
+    }
+    if (do_bias) atomicAdd(P.dbias + cob * 64 + (tid & 63), bsum);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            float* d = P.dw + ((size_t)(ky * 3 + kx) * P.Cin_total + kc * 64 + cit * 32) * P.Cout + cob * 64 + cot * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
+                atomicAdd(d + (size_t)ci * P.Cout, acc[ky][kx][r]);
+            }
+        }
+}
+
 // 7x7 init conv (Cin padded to 16, Cout = 64): dW[tap][ci<16][co] = sum_p X16[p + tap][ci] dY[p][co].
 // MFMA over pixels like conv_wgrad_kernel.  The halo tile keeps 16 channels = 32 B per pixel, so the
 // "second 16-channel block" of a transposing fragment read is simply the NEXT PIXEL: one 32-row A
@@ -835,6 +1024,7 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
     OFD_CHECK_ARG(!a->in_scale || (a->in_shift && a->ksize == 3), "conv_wgrad: the input prologue is a 3x3 feature");
     P.in_scale = a->in_scale; P.in_shift = a->in_shift;
     { static const int nd = getenv("OFD_WGRAD_NO_DMA") ? atoi(getenv("OFD_WGRAD_NO_DMA")) : 0; P.no_dma = nd; }
+    P.dbg = getenv("OFD_WGRAD_DBG") ? atoi(getenv("OFD_WGRAD_DBG")) : 0;
     const int ntiles = P.tiles_x * P.tiles_y * P.B, combos = (cin / 64) * (a->Cout / 64);
     int gx = cdiv(1024, combos * a->ksize);     // ~4 workgroups per CU in total; each walks ntiles / gx pixel tiles
     if (gx < 1) gx = 1;
@@ -908,6 +1098,19 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
                 else if (ph == 2) conv_wgrad3_kernel<false, true, 2><<<dim3(gx, combos), 256, LDS, s>>>(Q);
                 else conv_wgrad3_kernel<false, true, 3><<<dim3(gx, combos), 256, LDS, s>>>(Q);
             }
+            OFD_LAUNCH_CHECK();
+            return OFD_OK;
+        }
+        static const int db = getenv("OFD_WGRAD3_DB") ? atoi(getenv("OFD_WGRAD3_DB")) : 1;
+        if (db && !P.no_dma && !P.in_scale) {
+            // double-buffered form: ONE 8-wave workgroup per CU (2 x 75 KB of LDS), each walking ntiles / gx tiles
+            constexpr int LDS_DB = 2 * (43 * 1024 + 256 * 128);
+            static bool attr_db = false;
+            if (!attr_db) { OFD_HIP(hipFuncSetAttribute((const void*)conv_wgrad3_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DB)); attr_db = true; }
+            gx = 256 * db / combos;
+            if (gx < 1) gx = 1;
+            if (gx > ntiles) gx = ntiles;
+            conv_wgrad3_db_kernel<<<dim3(gx, combos), 512, LDS_DB, s>>>(P);
             OFD_LAUNCH_CHECK();
             return OFD_OK;
         }
