@@ -622,33 +622,34 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad3_db_kernel(const WgradParam
     const size_t x_bs = (size_t)S.SH * SW * sch;
     const bf16_t* ysrc = P.dy + cob * 64 + swz;
     const int y_r = (wave * 32 + (lane >> 3)) >> 5, y_c = (wave * 32 + (lane >> 3)) & 31;      // dY piece j of this wave: pixel (y_r, y_c + 8 j)
-    // requests tile t into `buf`; returns the mask of this lane's pieces that must read as zero (bits 0..5: halo pieces, 8..11: dY pieces)
-    auto issue = [&](int t, unsigned char* buf) -> unsigned {
+    // DMA piece K of a tile (K = 0..5: halo pieces wave + 8 K; 6..9: dY pieces 4 wave + K - 6) into `buf`; returns the bit of `zm` (the mask of this
+    // lane's pieces that must read as zero: out-of-image halo pixels, tile overhang) -- (b, oy0, ox0) of the tile in the Tile struct
+    struct Tile { const bf16_t* xb_; const bf16_t* yb_; int oy0, ox0; };
+    auto tile_of = [&](int t) {
         const int b = t / tpi, t_in = t - b * tpi;
-        const int oy0 = (t_in / tiles_x) * 8, ox0 = (t_in % tiles_x) * 32;
-        unsigned zm = 0;
-        const bf16_t* xb_ = xsrc + (size_t)b * x_bs;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int piece = wave + 8 * i;                 // wave-uniform
-            if (piece < XPIECES) {
-                const int iy = oy0 + x_ty[i], ix = ox0 + x_tx[i];
-                const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-                zm |= ((cy == iy && cx == ix) ? 0u : 1u) << i;
-                const int sy = ((cy * m_mul) >> m_shr) + m_ay, sx = ((cx * m_mul) >> m_shr) + m_ax;
-                __builtin_amdgcn_global_load_lds(xb_ + (size_t)(unsigned)((sy * SW + sx) * sch), (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
-            }
-        }
-        const bf16_t* yb_ = ysrc + (size_t)b * P.dy_bs * Cout;
-        const int oy = oy0 + y_r, cyy = min(oy, H - 1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ox = ox0 + y_c + 8 * j, cxx = min(ox, W - 1);
-            zm |= ((oy < H && ox < W) ? 0u : 1u) << (8 + j);
-            __builtin_amdgcn_global_load_lds(yb_ + (size_t)(unsigned)(((cyy * dy_s + dy_y0) * dy_w + cxx * dy_s + dy_x0) * Cout),
+        Tile T;
+        T.oy0 = (t_in / tiles_x) * 8; T.ox0 = (t_in % tiles_x) * 32;
+        T.xb_ = xsrc + (size_t)b * x_bs;
+        T.yb_ = ysrc + (size_t)b * P.dy_bs * Cout;
+        return T;
+    };
+    auto issue_piece = [&](auto KK, const Tile& T, unsigned char* buf) -> unsigned {
+        constexpr int K = decltype(KK)::value;
+        if constexpr (K < 6) {
+            const int piece = wave + 8 * K;                 // wave-uniform
+            if (piece >= XPIECES) return 0u;
+            const int iy = T.oy0 + x_ty[K], ix = T.ox0 + x_tx[K];
+            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+            const int sy = ((cy * m_mul) >> m_shr) + m_ay, sx = ((cx * m_mul) >> m_shr) + m_ax;
+            __builtin_amdgcn_global_load_lds(T.xb_ + (size_t)(unsigned)((sy * SW + sx) * sch), (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
+            return ((cy == iy && cx == ix) ? 0u : 1u) << K;
+        } else {
+            constexpr int j = K - 6;
+            const int oy = T.oy0 + y_r, ox = T.ox0 + y_c + 8 * j;
+            __builtin_amdgcn_global_load_lds(T.yb_ + (size_t)(unsigned)(((min(oy, H - 1) * dy_s + dy_y0) * dy_w + min(ox, W - 1) * dy_s + dy_x0) * Cout),
                                              (__attribute__((address_space(3))) void*)(buf + XB + (wave * 4 + j) * 1024), 16, 0, 0);
+            return ((oy < H && ox < W) ? 0u : 1u) << (8 + j);
         }
-        return zm;
     };
 
     // per-lane base addresses of the transposing reads inside a buffer (see tr_frag): rows = pixels, 128 bytes apart
@@ -665,7 +666,10 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad3_db_kernel(const WgradParam
 
     int t = blockIdx.x, cur = 0;
     unsigned zm = 0;
-    if (t < ntiles) zm = issue(t, smem);
+    if (t < ntiles) {
+        const Tile T0 = tile_of(t);
+        wg_static_for<0, 10>([&](auto KK) { zm |= issue_piece(KK, T0, smem); });
+    }
     for (; t < ntiles; t += gridDim.x) {
         unsigned char* buf = smem + cur * BUF;
         if (!(P.dbg & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of tile t have landed
@@ -684,8 +688,13 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad3_db_kernel(const WgradParam
 #pragma unroll 8
             for (int p = part * 32; p < part * 32 + 32; ++p) bsum += bf2f(*(const bf16_t*)(ys + p * 128 + (((co >> 3) ^ (2 * (p & 3))) * 16) + (co & 7) * 2));
         }
+        // the next tile's DMA pieces are requested BETWEEN the MFMAs of rows 0..4 (two per row): their address arithmetic runs in the shadow of
+        // this wave's own MFMAs instead of ahead of them (the two waves of a SIMD are in step: nobody else would feed the pipe meanwhile)
         const int tn = t + gridDim.x;
-        if (tn < ntiles && !(P.dbg & 1)) zm = issue(tn, smem + (cur ^ 1) * BUF);
+        const bool has_next = tn < ntiles && !(P.dbg & 1);
+        const Tile Tn = tile_of(has_next ? tn : t);
+        unsigned char* nbuf = smem + (cur ^ 1) * BUF;
+        zm = 0;
         unsigned xa[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) xa[k] = smem_base + (unsigned)(cur * BUF) + x_off[k];
@@ -706,6 +715,12 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad3_db_kernel(const WgradParam
                 tr_read<((rr + 1) * IWK + 1) * 128>(xf[nx][1], xa[((rr + 1) * IWK + 1) & 3]);
                 tr_read<((rr + 1) * IWK + 2) * 128>(xf[nx][2], xa[((rr + 1) * IWK + 2) & 3]);
                 if constexpr (rr + 1 < 8) tr_read<(rr + 1) * 32 * 128>(yn[nx], ya);
+            }
+            if constexpr (rr < 5) {
+                if (has_next) {
+                    zm |= issue_piece(std::integral_constant<int, 2 * rr>{}, Tn, nbuf);
+                    zm |= issue_piece(std::integral_constant<int, 2 * rr + 1>{}, Tn, nbuf);
+                }
             }
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
