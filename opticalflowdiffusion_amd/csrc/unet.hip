@@ -181,6 +181,18 @@ static Tensor resblock(Ctx& c, const std::string& name, const std::vector<Tensor
                       u->ss_offset.at(name), a1, s1, c.s, st1));
     c.end();
     SrcSpec hs; hs.t = h1;
+    // inference, layers of several 128-channel output blocks: every block's workgroups would re-apply SiLU(GroupNorm(h1)) to the same staged tile
+    // (an exp + a reciprocal per element, 2-4 times over); the small tensors of those levels are activated ONCE by an elementwise pass instead
+    static const int act1_min = getenv("OFD_ACT1_MATERIALIZE_MIN") ? atoi(getenv("OFD_ACT1_MATERIALIZE_MIN")) : 256;
+    if (!c.train && act1_min > 0 && Cout >= act1_min) {
+        Tensor act1 = c.tmp(Cout, H, W);
+        if (c.rc != OFD_OK) return out;
+        c.begin(PC_MISC, 0, (double)B * H * W * Cout * 4.0);
+        RUN(k_affine_silu(h1.p, a1, s1, act1.p, B, H, W, Cout, c.s));
+        c.end();
+        hs.t = act1;
+        conv(c, name + ".block2.proj", {hs}, h2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, p2);
+    } else
     conv(c, name + ".block2.proj", {hs}, h2, a1, s1, nullptr, nullptr, nullptr, nullptr, p2);
     c.begin(PC_GN, 0, (double)np * 4);
     RUN(k_gn_finalize(p2, B, H, W, Cout, u->P(name + ".block2.norm.weight"), u->P(name + ".block2.norm.bias"), nullptr, 0, 0, a2, s2, c.s, st2));
