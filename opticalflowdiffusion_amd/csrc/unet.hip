@@ -184,8 +184,13 @@ static Tensor resblock(Ctx& c, const std::string& name, const std::vector<Tensor
     // inference, layers of several 128-channel output blocks: every block's workgroups would re-apply SiLU(GroupNorm(h1)) to the same staged tile
     // (an exp + a reciprocal per element, 2-4 times over); the small tensors of those levels are activated ONCE by an elementwise pass instead
     static const int act1_min = getenv("OFD_ACT1_MATERIALIZE_MIN") ? atoi(getenv("OFD_ACT1_MATERIALIZE_MIN")) : 256;
-    if (!c.train && act1_min > 0 && Cout >= act1_min) {
-        Tensor act1 = c.tmp(Cout, H, W);
+    // training: the weight gradient of block2.proj reads a materialised act1 for every layer wider than 64 channels anyway (unet_train.hip): the
+    // forward makes it (and multiplies by it) instead of the backward
+    static const int act1_train_min = getenv("OFD_ACT1_TRAIN_MIN") ? atoi(getenv("OFD_ACT1_TRAIN_MIN")) : 128;
+    const int amin = c.train ? act1_train_min : act1_min;
+    Tensor act1;
+    if (amin > 0 && Cout >= amin) {
+        act1 = c.tmp(Cout, H, W);
         if (c.rc != OFD_OK) return out;
         c.begin(PC_MISC, 0, (double)B * H * W * Cout * 4.0);
         RUN(k_affine_silu(h1.p, a1, s1, act1.p, B, H, W, Cout, c.s));
@@ -207,7 +212,7 @@ static Tensor resblock(Ctx& c, const std::string& name, const std::vector<Tensor
     if (c.train) {
         TapeRec r;
         r.kind = TK_RES; r.name = name; r.srcs = srcs; r.out = out; r.h1 = h1; r.h2 = h2;
-        r.a1 = a1; r.s1 = s1; r.a2 = a2; r.s2 = s2; r.st1 = st1; r.st2 = st2;
+        r.a1 = a1; r.s1 = s1; r.a2 = a2; r.s2 = s2; r.st1 = st1; r.st2 = st2; r.act1 = act1;
         u->tape.push_back(r);
     }
     return out;

@@ -65,6 +65,7 @@ struct TapeRec {
     std::string name;
     std::vector<SrcSpec> srcs;       // conv / resblock inputs
     Tensor out, h1, h2, xn, qkv, ao, o2, x;
+    Tensor act1;                     // resblock, training: SiLU(GroupNorm(h1)) as the forward materialised it (p == nullptr: the backward recomputes it)
     float *a1 = nullptr, *s1 = nullptr, *a2 = nullptr, *s2 = nullptr, *st1 = nullptr, *st2 = nullptr;
     float *ctx = nullptr, *ml = nullptr, *lse = nullptr;
 };

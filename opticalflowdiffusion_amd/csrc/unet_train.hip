@@ -188,8 +188,9 @@ static void resblock_backward(Bwd& b, const TapeRec& r, float* dss, float* dts) 
     // 440x1024: never 162.5 ms, C <= 64: 160.9, C <= 128: 161.8, always: 162.3.
     static const int act1_max = getenv("OFD_FUSE_ACT1_MAXC") ? atoi(getenv("OFD_FUSE_ACT1_MAXC")) : 64;      // A/B switch
     const bool fuse_act1 = Cout <= act1_max;
-    Tensor act1;
-    if (!fuse_act1) act1 = b.stmp(Cout, H, W);
+    Tensor act1 = r.act1;                 // (the forward's own, when it materialised one)
+    const bool have_act1 = act1.p != nullptr;
+    if (!fuse_act1 && !have_act1) act1 = b.stmp(Cout, H, W);
     if (c.rc != OFD_OK) return;
     const double ew = (double)B * H * W * Cout * 2;
     // out = SiLU(GN2(h2)) + res
@@ -200,7 +201,9 @@ static void resblock_backward(Bwd& b, const TapeRec& r, float* dss, float* dts) 
     c.end();
     // h2 = conv2(act1), act1 = SiLU(GN1(h1) * (scale + 1) + shift): recomputed, the forward fused it into conv2's loader
     SrcSpec sa;
-    if (fuse_act1) {
+    if (have_act1) {
+        sa.t = act1;
+    } else if (fuse_act1) {
         sa.t = r.h1;
     } else {
         c.begin(PC_GNBWD, 0, ew * 2, name + " act1 recompute");
@@ -208,8 +211,9 @@ static void resblock_backward(Bwd& b, const TapeRec& r, float* dss, float* dts) 
         c.end();
         sa.t = act1;
     }
-    Tensor dact1 = conv_backward(b, name + ".block2.proj", {sa}, r.h2.g, H, W, true, nullptr, true, false, fuse_act1 ? r.a1 : nullptr,
-                                 fuse_act1 ? r.s1 : nullptr);
+    const bool wg_pro = fuse_act1 && !have_act1;      // the weight gradient applies the affine + SiLU while staging h1
+    Tensor dact1 = conv_backward(b, name + ".block2.proj", {sa}, r.h2.g, H, W, true, nullptr, true, false, wg_pro ? r.a1 : nullptr,
+                                 wg_pro ? r.s1 : nullptr);
     c.begin(PC_GNBWD, 0, ew * 5, name + ".block1 gn-silu bwd");
     const bool timed = !u->cfg.no_time;       // Unet(time_in=False): block1 has no scale/shift and no time projection
     RUN(k_gn_silu_backward(dact1.p, r.h1.p, r.a1, r.s1, r.st1, u->P(name + ".block1.norm.weight"), u->P(name + ".block1.norm.bias"),
