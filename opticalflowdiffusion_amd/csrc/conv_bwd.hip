@@ -1117,7 +1117,10 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
             return OFD_OK;
         }
         static const int db = getenv("OFD_WGRAD3_DB") ? atoi(getenv("OFD_WGRAD3_DB")) : 1;
-        if (db && !P.no_dma && !P.in_scale) {
+        // (its per-sample element offsets are 32-bit: a plane of 2^32 elements or more keeps the kernel above)
+        bool small_planes = (size_t)a->H * a->W * a->Cout < (1ull << 32);
+        for (int i = 0; i < a->n_src; ++i) small_planes = small_planes && (size_t)P.src[i].SH * P.src[i].SW * P.src[i].src_channels < (1ull << 32);
+        if (db && !P.no_dma && !P.in_scale && small_planes) {
             // double-buffered form: ONE 8-wave workgroup per CU (2 x 75 KB of LDS), each walking ntiles / gx tiles
             constexpr int LDS_DB = 2 * (43 * 1024 + 256 * 128);
             static bool attr_db = false;
