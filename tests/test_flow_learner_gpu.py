@@ -57,15 +57,17 @@ def test_flow_learner_training_reduces_the_loss_and_samples():
     from opticalflowdiffusion_amd import warp
     tgt = torch.nan_to_num(warp(img, None, true_flow, mode="forward"), nan=0.5)
     losses = []
-    for it in range(4):
+    for it in range(12):
         loss = fl.training_step((img, tgt, true_flow), it)
         assert torch.isfinite(loss)
         opt.zero_grad()
         loss.backward()
         opt.step()
         losses.append(float(loss.detach()))
-    # Adam's first steps are sign-of-gradient sized (every one of the 35.7 M parameters moves by lr) and the bf16 forward carries
-    # ~1e-2 of rounding noise, so a single step is not guaranteed to descend; within four steps the loss must have gone down
+    # Adam's first steps are sign-of-gradient sized (every one of the 35.7 M parameters moves by lr, the noise-dominated ones with a sign that
+    # the float atomics of the backward decide differently from run to run) and the bf16 forward carries ~1e-2 of rounding noise, so a
+    # single step is not guaranteed to descend and trajectories differ run to run (tools/probe/flow_learner_steps.py: 5-15 % below the
+    # start within twelve steps in every repetition); within twelve steps the loss must have gone down
     print("\n  FlowLearner losses:", [round(v, 5) for v in losses])
     assert min(losses[1:]) < losses[0], losses
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in fl.parameters())
@@ -167,11 +169,12 @@ def test_fused_pyramid_loss_equals_the_loop_and_trains():
     opt = fl.configure_optimizers()
     im01, tg01 = (img + 1) / 2, (tgt + 1) / 2
     losses = []
-    for it in range(4):
+    for it in range(12):
         loss = fl.training_step((im01, tg01, flow), it)
         opt.zero_grad()
         loss.backward()
         opt.step()
         losses.append(float(loss.detach()))
-    # (four Adam steps on a randomly initialised bf16 UNet: the first step may overshoot by a percent, the loss must come down within the four)
+    # (twelve Adam steps on a randomly initialised bf16 UNet: the first step may overshoot by a percent and trajectories differ run to run, see above;
+    #  the loss must come down within the twelve)
     assert all(torch.isfinite(torch.tensor(losses))) and min(losses[1:]) < losses[0], losses
