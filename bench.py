@@ -63,6 +63,82 @@ def cpu_baseline(H, W, batch):
             "sample": f"1 of {batch} samples: fp32 UNet forward at 1x5x{H}x{W}, mean of {reps} runs = {dt:.1f} s, scaled x{batch}"}
 
 
+# ---- roofline of the instrumented loop -----------------------------------------------------------------------------------------------
+# A profile class is named `<kernel family> [<layer group>]` by the library (csrc/unet.hip:prof_class_name, from the switches the process runs
+# with); classes served by one kernel template share the family.  What bounds a family:
+HBM_FAMILIES = ("conv1x1", "resblock_out", "layernorm_c", "gn_finalize", "misc")
+VALU_FAMILIES = ("la_ctx_fused",)            # LinearAttention: transcendental / latency-bound passes with MFMA projections inside
+
+
+def family_of(name):
+    return name.split(" [")[0]
+
+
+def bound_of(name):
+    fam = family_of(name)
+    if fam.startswith(HBM_FAMILIES):
+        return "hbm"
+    if fam.startswith(VALU_FAMILIES):
+        return "valu"
+    return "mfma"
+
+
+def pmc_traffic(family, B, H, W):
+    """HBM bytes per launch of a kernel family from the newest committed rocprofv3 --pmc summary measured at this shape (separate passes of
+    this command, tools/pmc.sh: counters cannot be collected inside the timed region); (None, None) when there is none"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    key = family.split("|")[0].replace(" ", "").rstrip(">")          # "conv3x3_wp_kernel<2,2"
+    for pmc in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_summary.json")), reverse=True):
+        d = json.load(open(pmc))
+        es = [v for k, v in d["kernels"].items() if key in k.replace(" ", "")]
+        if es and d.get("shape") == [B, H, W]:
+            n = sum(v["launches"] for v in es)
+            return sum((v["fetch_MB_per_launch"] + v["write_MB_per_launch"]) * v["launches"] for v in es) / n * 1e6, os.path.relpath(pmc, here)
+    return None, None
+
+
+def roofline_objects(prof, prof_steps, prof_elapsed, B, H, W):
+    """`roofline` (the MFMA kernel family with the largest measured time per step -- picked from the measurement, not by name),
+    `roofline_classes` (every profile class that ran: ms, work, achieved rate against the roof that bounds it) and `kernel_ms_per_step`
+    (per kernel family, the classes of a family as sub-fields)."""
+    ran = {n: v for n, v in prof.items() if v["launches"] > 0}
+    classes, fams = [], {}
+    for n, v in ran.items():
+        ms, bound = v["ms"] / prof_steps, bound_of(n)
+        row = {"class": n, "bound": bound, "ms_per_step": ms, "launches_per_step": v["launches"] / prof_steps}
+        if v["flops"] > 0:
+            row["tflop_per_step"] = v["flops"] / prof_steps / 1e12
+            row["achieved_TFLOPs"] = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            row["frac_of_mfma_peak"] = row["achieved_TFLOPs"] / PEAK_BF16_TFLOPS
+        if bound == "hbm" and v["bytes"] > 0:
+            row["achieved_GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            row["frac_of_hbm_peak"] = row["achieved_GBps"] / PEAK_HBM_GBS
+        classes.append(row)
+        f = fams.setdefault(family_of(n), {"ms": 0.0, "flops": 0.0, "launches": 0, "bound": bound, "classes": {}})
+        f["ms"] += v["ms"]; f["flops"] += v["flops"]; f["launches"] += v["launches"]
+        f["classes"][n] = ms
+    classes.sort(key=lambda r: -r["ms_per_step"])
+    out = {"roofline_classes": classes,
+           "kernel_ms_per_step": {fam: ({"total": f["ms"] / prof_steps, **f["classes"]} if len(f["classes"]) > 1 else f["ms"] / prof_steps)
+                                  for fam, f in sorted(fams.items(), key=lambda kv: -kv[1]["ms"])}}
+    mf = {fam: f for fam, f in fams.items() if f["bound"] == "mfma" and f["flops"] > 0}
+    if mf:
+        fam, f = max(mf.items(), key=lambda kv: kv[1]["ms"])
+        achieved = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        traffic, traffic_source = pmc_traffic(fam, B, H, W)
+        out["roofline"] = {"kernel": fam + " (the MFMA kernel family with the largest time per step in this run; its classes: " + "; ".join(f["classes"]) + ")",
+                           "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                           "traffic": traffic, "traffic_source": traffic_source,
+                           "algorithmic_flops_per_launch": f["flops"] / f["launches"], "avg_launch_ms": f["ms"] / f["launches"],
+                           "launches": f["launches"], "ms_per_step": f["ms"] / prof_steps,
+                           "measured_in": f"instrumented loop of {prof_steps} steps after the headline loop ({1e3 * prof_elapsed / prof_steps:.2f} ms per step with the events on, "
+                                          "one stream: the headline loop runs the two half-batches on two streams, where a kernel's duration includes what it shares the chip with)"}
+        c3 = [f for f in mf.values() if any("[3x3" in c for c in f["classes"])]
+        if c3:
+            out["conv3x3_all_tflops"] = sum(f["flops"] for f in c3) / (sum(f["ms"] for f in c3) * 1e-3) / 1e12
+    return out
+
+
 TRAIN_TFLOP_PER_SAMPLE = 4.8917       # fwd + bwd = 2.99 x fwd (BASELINE.md section 2, ch=5 @ 440x1024)
 
 
@@ -312,33 +388,7 @@ def main():
         if warp is not None:
             line["warp"] = warp
         if prof:
-            # dominant kernel: the 128-channel-block 3x3 launches (25 of the 43 3x3 launches, largest total time)
-            name = "conv3x3_wp16_kernel"
-            k = prof[name]
-            per_launch_ms = k["ms"] / max(k["launches"], 1)
-            achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
-            # HBM bytes per launch: from separate rocprofv3 --pmc passes of THIS command (tools/pmc.sh), which cannot run inside the
-            # timed region; emitted only when the committed summary was measured at this run's shape, and tagged with its file
-            traffic, traffic_source = None, None
-            here = os.path.dirname(os.path.abspath(__file__))
-            for pmc in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_summary.json")), reverse=True):
-                d = json.load(open(pmc))
-                es = [v for k, v in d["kernels"].items() if "conv3x3_wp16_kernel" in k or "conv3x3_wp_kernel<4, 1" in k]     # prologue on / off instantiations
-                if es and d.get("shape") == [B, H, W]:
-                    n = sum(v["launches"] for v in es)
-                    traffic = sum((v["fetch_MB_per_launch"] + v["write_MB_per_launch"]) * v["launches"] for v in es) / n * 1e6
-                    traffic_source = os.path.relpath(pmc, here)
-                    break
-            line["roofline"] = {"kernel": name + " (ofd::wp::conv3x3_wp16_kernel<prologue on|off>: 3x3 implicit GEMM, 128-channel blocks, MFMA 16x16x32)", "bound": "mfma", "achieved": achieved,
-                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                                "traffic_source": traffic_source,
-                                "algorithmic_flops_per_launch": k["flops"] / max(k["launches"], 1), "avg_launch_ms": per_launch_ms,
-                                "launches": k["launches"],
-                                "measured_in": f"instrumented loop of {prof_steps} steps after the headline loop ({1e3 * prof_elapsed / prof_steps:.2f} ms per step with the events on, "
-                                               "one stream: the headline loop runs the two half-batches on two streams, where a kernel's duration includes what it shares the chip with)"}
-            c3 = [prof[n] for n in ("conv3x3_wp16_kernel", "conv3x3_wp_kernel<2,2>", "conv3x3_wp_kernel<2,2> (64->64)") if n in prof and prof[n]["ms"] > 0]
-            line["conv3x3_all_tflops"] = sum(v["flops"] for v in c3) / (sum(v["ms"] for v in c3) * 1e-3) / 1e12
-            line["kernel_ms_per_step"] = {n: v["ms"] / prof_steps for n, v in prof.items()}
+            line.update(roofline_objects(prof, prof_steps, prof_elapsed, B, H, W))
 
     import threading
     emitted, lock = threading.Event(), threading.Lock()

@@ -177,7 +177,12 @@ int ofd_unet_bind_param_buffer(ofd_unet* u, float* dev_params, size_t floats);
 int ofd_unet_prepare(ofd_unet* u, void* stream);
 size_t ofd_unet_workspace_bytes(const ofd_unet* u, int B, int H, int W);
 /* x: (B,Cx,H,W) fp32, cond: (B,Cc,H,W) fp32 or NULL (Cx+Cc == channels), t: (B,) int64,
- * out: (B,out_dim,H,W) fp32.  H and W must be multiples of 8. */
+ * out: (B,out_dim,H,W) fp32.  H and W must be multiples of 8.
+ * Memory of `out` (and of every device pointer of this header): ordinary device memory of the GPU the stream belongs to, as
+ * hipMalloc / torch's caching allocator return it (coarse-grained).  When H*W is a multiple of 128 the final 1x1 conv (DD:361) is
+ * computed on the tile of final_res_block's res_conv and reaches `out` as hardware fp32 atomic adds onto a buffer the call zeroes first
+ * (two addends per element, order-free); fine-grained / host-coherent / managed allocations, where such atomics are not guaranteed, are
+ * not supported for `out` -- ofd_unet_set_debug_taps(u, 1) selects the unfused final conv (plain stores) for such a buffer. */
 int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float* cond, int Cc, const int64_t* t,
                      float* out, int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 /* debug: copy a named intermediate of the LAST forward (e.g. "init_conv", "downs.0.0",

@@ -641,12 +641,12 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad3_db_kernel(const WgradParam
             const int iy = T.oy0 + x_ty[K], ix = T.ox0 + x_tx[K];
             const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
             const int sy = ((cy * m_mul) >> m_shr) + m_ay, sx = ((cx * m_mul) >> m_shr) + m_ax;
-            __builtin_amdgcn_global_load_lds(T.xb_ + (size_t)(unsigned)((sy * SW + sx) * sch), (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(T.xb_ + (size_t)(((unsigned)sy * (unsigned)SW + (unsigned)sx) * (unsigned)sch), (__attribute__((address_space(3))) void*)(buf + piece * 1024), 16, 0, 0);
             return ((cy == iy && cx == ix) ? 0u : 1u) << K;
         } else {
             constexpr int j = K - 6;
             const int oy = T.oy0 + y_r, ox = T.ox0 + y_c + 8 * j;
-            __builtin_amdgcn_global_load_lds(T.yb_ + (size_t)(unsigned)(((min(oy, H - 1) * dy_s + dy_y0) * dy_w + min(ox, W - 1) * dy_s + dy_x0) * Cout),
+            __builtin_amdgcn_global_load_lds(T.yb_ + (size_t)((((unsigned)(min(oy, H - 1) * dy_s + dy_y0)) * (unsigned)dy_w + (unsigned)(min(ox, W - 1) * dy_s + dy_x0)) * (unsigned)Cout),
                                              (__attribute__((address_space(3))) void*)(buf + XB + (wave * 4 + j) * 1024), 16, 0, 0);
             return ((oy < H && ox < W) ? 0u : 1u) << (8 + j);
         }
@@ -1117,7 +1117,7 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
             return OFD_OK;
         }
         static const int db = getenv("OFD_WGRAD3_DB") ? atoi(getenv("OFD_WGRAD3_DB")) : 1;
-        // (its per-sample element offsets are 32-bit: a plane of 2^32 elements or more keeps the kernel above)
+        // (its per-sample element offsets are 32-bit UNSIGNED arithmetic: a plane of 2^32 elements or more keeps the kernel above)
         bool small_planes = (size_t)a->H * a->W * a->Cout < (1ull << 32);
         for (int i = 0; i < a->n_src; ++i) small_planes = small_planes && (size_t)P.src[i].SH * P.src[i].SW * P.src[i].src_channels < (1ull << 32);
         if (db && !P.no_dma && !P.in_scale && small_planes) {

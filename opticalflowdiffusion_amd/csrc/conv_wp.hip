@@ -28,9 +28,25 @@
 #define OFD_WP_DOT2 1
 #endif
 
+// OFD_WP_STAMPS=1 (diagnostic builds only, tools/probe/wp_stamps.py): every wave of conv3x3_wp_kernel records s_memtime at its phase
+// boundaries into a buffer of its own that nothing else reads; the production build compiles none of it
+#ifndef OFD_WP_STAMPS
+#define OFD_WP_STAMPS 0
+#endif
+
 namespace ofd {
 
 namespace wp {
+
+#if OFD_WP_STAMPS
+constexpr int STAMP_SLOTS = 16, STAMP_WAVES = 1 << 16;
+__device__ unsigned long long g_wp_stamps[STAMP_SLOTS * STAMP_WAVES];
+#define WP_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WP_DRAIN_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define WP_STAMP(i) do { } while (0)
+#define WP_DRAIN_VM() do { } while (0)
+#endif
 
 constexpr int CK = 32, NC = CK / 8, IW = 34, TW = 32, RING = 6, FRAGS = 18;   // 18 weight fragments per 32-channel chunk
 
@@ -90,6 +106,11 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int ns = wave % NS, ph = wave / NS;
+#if OFD_WP_STAMPS
+    unsigned long long stamps[STAMP_SLOTS] = {};
+    stamps[14] = __builtin_amdgcn_s_memrealtime();
+    WP_STAMP(0);
+#endif
 
     // XCD-aware tile order (blocks that share an XCD get a contiguous run of tiles: halo rows of neighbours hit one L2)
     const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
@@ -188,8 +209,12 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
         for (int k = 0; k < 16; ++k) acc[r][k] = 0.0f;
 
     u4 xs[C::XPT];
+    WP_STAMP(1);
     load_x(0, xs);
+    WP_DRAIN_VM();
+    WP_STAMP(2);
     write_x(0, xs, smem);
+    WP_STAMP(3);
 
     const int xrow_off = half * C::US + (8 * ph * IW + l31) * 16;
     // one 32-channel chunk: 144 MFMAs per wave between two workgroup barriers.  LAST (the peeled final chunk) fetches and stages
@@ -200,6 +225,7 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
         const int kn = LAST ? kc : kc + 1;
         if constexpr (!LAST) load_x(kn, xs);
         __syncthreads();                              // tile kc complete; every wave is done reading the other buffer (chunk kc-1)
+        WP_STAMP(LAST ? 8 : 4);
         const unsigned char* xrow = smem + (kc & 1) * C::XB + xrow_off;
         unsigned char* xnext = smem + ((kc + 1) & 1) * C::XB;
 #pragma unroll
@@ -220,8 +246,9 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
             for (int r = 0; r < 8; ++r)
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky], x[r + ky], acc[r], 0, 0, 0);
-            if constexpr (!LAST) { if (g == 1) write_x(kn, xs, xnext); }
+            if constexpr (!LAST) { if (g == 1) { WP_STAMP(5); write_x(kn, xs, xnext); WP_STAMP(6); } }
         }
+        WP_STAMP(LAST ? 9 : 7);
     };
 #if OFD_WP_PEEL
     for (int kc = 0; kc < n32 - 1; ++kc) chunk(kc, std::false_type{});
@@ -402,6 +429,19 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
         }
     }
 
+#if OFD_WP_STAMPS
+    WP_STAMP(10);
+    WP_DRAIN_VM();
+    WP_STAMP(11);
+    stamps[15] = __builtin_amdgcn_s_memrealtime();
+    stamps[13] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_ID (wave / SIMD / CU / SE ...)
+    {
+        const unsigned wv = (blockIdx.x + gridDim.x * blockIdx.y) * (NTHREADS / 64) + wave;
+        if (lane == 0 && wv < (unsigned)STAMP_WAVES)
+#pragma unroll
+            for (int i = 0; i < STAMP_SLOTS; ++i) g_wp_stamps[(size_t)wv * STAMP_SLOTS + i] = stamps[i];
+    }
+#endif
     if (P.gn_partial) {
         // layout of conv_igemm.hip, [b][8-row tile][4 slots][Cout/8][2], consumed by gn_finalize: this wave owns octets
         // cb/8 .. cb/8 + 3 of the 8-row tile (ph); its sums go to slot ns, every other (slot, octet) of the workgroup's channel
@@ -867,6 +907,12 @@ __global__ void __launch_bounds__(512, 2) conv_up2_phases_wp_kernel(const ConvPa
 }
 
 }  // namespace wp
+
+#if OFD_WP_STAMPS
+extern "C" int ofd_dbg_wp_stamps(void* dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wp::g_wp_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // 3x3, stride 1, sources of mode 0 (same size) or 1 (nearest x2): called from conv_forward_impl
 int launch_conv3x3_wp(const ConvParams& P0, bool wide, hipStream_t s) {

@@ -780,14 +780,26 @@ extern "C" int ofd_unet_forward(ofd_unet* u, const float* x, int Cx, const float
         c0.signal_at = u->split_offset; c0.signal_ev = u->ev_phase;
         OFD_HIP(hipEventRecord(u->ev_fork, s1));                       // the inputs are ready on the caller's stream
         OFD_HIP(hipStreamWaitEvent(u->s2, u->ev_fork, 0));
-        int rc = run_forward(c0, x, Cx, cond, Cc, t, out, H, W, te0, ts0);
-        if (!c0.signalled) OFD_HIP(hipEventRecord(u->ev_phase, s1));
-        u->taps_half0 = u->taps;
-        OFD_HIP(hipStreamWaitEvent(u->s2, u->ev_phase, 0));
-        int rc1 = run_forward(c1, x + (size_t)hb * Cx * plane, Cx, cond ? cond + (size_t)hb * Cc * plane : nullptr, Cc, t ? t + hb : nullptr,
-                              out + (size_t)hb * u->cfg.out_dim * plane, H, W, te1, ts1);
-        OFD_HIP(hipEventRecord(u->ev_join, u->s2));
-        OFD_HIP(hipStreamWaitEvent(s1, u->ev_join, 0));                // the caller's stream owns the whole output again
+        // From here on work may be queued on the library's own stream s2: EVERY path below reaches the join (record on s2, wait on the
+        // caller's stream) before returning, so that s2 never holds work on the caller's workspace / output that the caller's stream is not
+        // ordered behind -- also when a launch or an event call in between fails.  Half 1 is not launched when half 0 failed.
+        int rc = run_forward(c0, x, Cx, cond, Cc, t, out, H, W, te0, ts0), rc1 = OFD_OK;
+        hipError_t he = hipSuccess;
+        if (rc == OFD_OK) {
+            if (!c0.signalled) he = hipEventRecord(u->ev_phase, s1);
+            u->taps_half0 = u->taps;
+            if (he == hipSuccess) he = hipStreamWaitEvent(u->s2, u->ev_phase, 0);
+            if (he == hipSuccess)
+                rc1 = run_forward(c1, x + (size_t)hb * Cx * plane, Cx, cond ? cond + (size_t)hb * Cc * plane : nullptr, Cc, t ? t + hb : nullptr,
+                                  out + (size_t)hb * u->cfg.out_dim * plane, H, W, te1, ts1);
+        }
+        hipError_t hj = hipEventRecord(u->ev_join, u->s2);
+        if (hj == hipSuccess) hj = hipStreamWaitEvent(s1, u->ev_join, 0);          // the caller's stream owns the whole output again
+        if (hj != hipSuccess) (void)hipStreamSynchronize(u->s2);                    // the join itself failed: drain s2 before handing control back
+        if (he != hipSuccess || hj != hipSuccess) {
+            set_error("unet_forward (split streams): %s", hipGetErrorString(he != hipSuccess ? he : hj));
+            if (rc == OFD_OK && rc1 == OFD_OK) rc = OFD_ERR_HIP;
+        }
         u->last_split = true;
         return rc != OFD_OK ? rc : rc1;
     }
@@ -886,8 +898,44 @@ extern "C" int ofd_unet_prof_dump_path(ofd_unet* u, const char* path) {
     u->dump_path = path ? path : "";
     return OFD_OK;
 }
+namespace ofd {
+// name of a profile class = the kernel that serves it under the switches this process runs with (the same environment variables, read the same
+// way, as the dispatch in conv_igemm.hip:conv_forward_impl and conv_wp.hip:launch_conv3x3_wp), followed by the layer group in brackets
+const char* prof_class_name(int cls) {
+    static std::string names[PC_COUNT];
+    static bool built = false;
+    if (!built) {
+        auto env = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+        const int wp = env("OFD_CONV_WP", 7), wp16 = env("OFD_CONV_WP16", 1), bn256 = env("OFD_CONV_WP_BN256", 0);
+        const bool phase_wp = env("OFD_PHASE_WP", 1) != 0;
+        names[PC_CONV3] = std::string(!(wp & 1) ? "conv_igemm_kernel<3,128>" : (wp16 && !bn256 ? "conv3x3_wp16_kernel" : (bn256 ? "conv3x3_wp_kernel<8,1>|<4,1>" : "conv3x3_wp_kernel<4,1>"))) +
+                          " [3x3, Cout a multiple of 128]";
+        names[PC_CONV3_64] = std::string((wp & 2) ? "conv3x3_wp_kernel<2,2>" : "conv_igemm_kernel<3,64>") + " [3x3, Cin > 64 -> 64]";
+        names[PC_CONV3_PP] = std::string((wp & 4) ? "conv3x3_wp_kernel<2,2>" : "conv3x3_c64_pingpong_kernel") + " [3x3, 64 -> 64]";
+        names[PC_CONV1] = "conv1x1_wp_kernel | conv_igemm_kernel<1,BN> [1x1]";
+        names[PC_CONV7] = "conv_igemm_kernel<8,64>|<7,64> [7x7 init conv]";
+        names[PC_GN] = "gn_finalize";
+        names[PC_RESOUT] = "resblock_out";
+        names[PC_LN] = "layernorm_c";
+        names[PC_LINATTN] = "la_ctx_fused + la_out_fused | lc_* [LinearAttention]";
+        names[PC_FLASH] = "flash_attn_d32 [mid attention]";
+        names[PC_MISC] = "misc";
+        names[PC_WGRAD3] = "conv_wgrad3 [3x3 weight gradients]";
+        names[PC_WGRAD1] = "conv_wgrad1 [1x1 / 7x7 weight gradients]";
+        names[PC_DGRAD3] = "conv3x3 data gradients [forward kernels on dY]";
+        names[PC_DGRAD1] = "conv1x1 data gradients";
+        names[PC_GNBWD] = "gn_silu_backward";
+        names[PC_LABWD] = "linear_attention_backward";
+        names[PC_FLASHBWD] = "flash_attention_backward";
+        names[PC_CONVUP] = std::string(phase_wp ? "conv_up2_phases_wp_kernel" : "conv_igemm_kernel<2,BN>") + " [Upsample x2 + 3x3 as four 2x2 phase convs]";
+        built = true;
+    }
+    return (cls >= 0 && cls < PC_COUNT) ? names[cls].c_str() : "";
+}
+}  // namespace ofd
+
 extern "C" int ofd_unet_prof_count(const ofd_unet* u) { return u ? PC_COUNT : 0; }
-extern "C" const char* ofd_unet_prof_name(const ofd_unet* u, int i) { return (u && i >= 0 && i < PC_COUNT) ? kProfNames[i] : ""; }
+extern "C" const char* ofd_unet_prof_name(const ofd_unet* u, int i) { return (u && i >= 0 && i < PC_COUNT) ? prof_class_name(i) : ""; }
 
 static int prof_resolve(ofd_unet* u) {
     FILE* dump = u->dump_path.empty() ? nullptr : fopen(u->dump_path.c_str(), "a");
@@ -895,7 +943,7 @@ static int prof_resolve(ofd_unet* u) {
         OFD_HIP(hipEventSynchronize(r.e1));
         float ms = 0.0f;
         OFD_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
-        if (dump) fprintf(dump, "%s,%s,%.4f,%.6g,%.6g\n", kProfNames[r.cls], r.label.c_str(), ms, r.flops, r.bytes);
+        if (dump) fprintf(dump, "%s,%s,%.4f,%.6g,%.6g\n", prof_class_name(r.cls), r.label.c_str(), ms, r.flops, r.bytes);
         u->acc_ms[r.cls] += ms;
         u->acc_flops[r.cls] += r.flops;
         u->acc_bytes[r.cls] += r.bytes;

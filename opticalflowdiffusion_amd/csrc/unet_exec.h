@@ -37,12 +37,10 @@ struct Tensor {
 };
 
 enum ProfClass { PC_CONV3 = 0, PC_CONV3_64, PC_CONV3_PP, PC_CONV1, PC_CONV7, PC_GN, PC_RESOUT, PC_LN, PC_LINATTN, PC_FLASH, PC_MISC, PC_WGRAD3, PC_WGRAD1, PC_DGRAD3, PC_DGRAD1, PC_GNBWD, PC_LABWD, PC_FLASHBWD, PC_CONVUP, PC_COUNT };
-// (class = what the executor asked for; the 3x3 classes name the kernel that serves them by default: conv_wp.hip, OFD_CONV_WP / OFD_PHASE_WP;
-//  the 64 -> 64 layers were the ping-pong kernel's until r03)
-static const char* const kProfNames[PC_COUNT] = {"conv3x3_wp16_kernel", "conv3x3_wp_kernel<2,2>", "conv3x3_wp_kernel<2,2> (64->64)", "conv1x1_igemm", "conv7x7_igemm", "gn_finalize", "resblock_out",
-                                           "layernorm_c", "linear_attention_core", "flash_attention_d32", "misc", "conv_wgrad_kernel<3>", "conv_wgrad_kernel<1>",
-                                           "conv3x3_dgrad", "conv1x1_dgrad", "gn_silu_backward", "linear_attention_backward", "flash_attention_backward",
-                                           "conv_up2_phases_wp_kernel (up-sample conv as 4 phase convs)"};
+// class = the group of layers the executor asked for.  The NAME of a class is the kernel that serves it under the library's current switches
+// (prof_class_name, unet.hip): `<kernel family> [<layer group>]` -- classes served by the same kernel share the text before " [", which is
+// what bench.py groups by when it picks the dominant kernel.
+const char* prof_class_name(int cls);
 
 struct ProfRec {
     int cls;
