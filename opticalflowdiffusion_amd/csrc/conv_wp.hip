@@ -750,6 +750,350 @@ static int launch16(const ConvParams& P, hipStream_t s) {
     return OFD_OK;
 }
 
+// ---- producer / consumer form of the 64 -> 64 3x3 (r04) -----------------------------------------------------------------------------
+// What the in-kernel stamps of conv3x3_wp_kernel<2,2> say (tools/probe/wp_stamps.py, 64 -> 64 at 16 x 440 x 1024): a wave lives 41-48 k cycles
+// per tile and spends a third of them in its MFMA phases; the rest is serial in the same wave -- tile decode 2.5 k, the first tile's
+// global loads 5-8 k (the latency of a tile's loads under load: more than one chunk of MFMAs), its staging 0.6 k (9.5 k with the GroupNorm +
+// SiLU prologue), barriers 3 k, epilogue 6-11 k -- and with two waves per SIMD, both in the same program, the matrix pipe idles whenever both
+// are outside their MFMA phase: MFMA-busy 0.34-0.41.  The layer itself is close to HBM-bound: 1.9 GB at the ~5 TB/s a 1 : 1 read / write
+// mix streams = 0.4 ms against 0.3 ms of MFMAs, so nothing may be serial with the memory stream.
+// Here the halves of the work run in DIFFERENT waves of one persistent 512-thread workgroup (one per CU):
+//   * waves 0-3, the consumers (one per SIMD): the MFMA chunk body of conv3x3_wp_kernel and its epilogue, nothing else -- no global
+//     loads at all inside the MFMA stream: the 9 x 64 x 64 weights (73.7 KB) are staged ONCE per workgroup into LDS, fragment-major (a
+//     fragment = one conflict-free ds_read_b128 per lane), the bias lives in registers, the accumulators start at the bias.  (A first
+//     version read the weights from L2 as conv3x3_wp_kernel does: in-order return put every weight fragment behind the epilogue's stores
+//     and the chunks ran at 50-85 cycles per MFMA; same-box ablation without the refills: 0.68 -> 0.58 ms);
+//   * waves 4-7, the producers (the other wave of each SIMD): fetch the input tile of chunk i + 3 into registers (three register sets: a
+//     tile's loads take 5-8 k cycles under load), apply the prologue to chunk i + 1 and write it to the other LDS buffer while the
+//     consumers multiply chunk i.  Their VALU stream fills the 24 issue cycles an MFMA leaves free on the SIMD;
+//   * ONE workgroup barrier per chunk (144 MFMAs per consumer wave), passed by the consumers as soon as their LDS reads of the chunk
+//     are issued: the epilogue of a tile runs behind the barrier, beside the producers' staging of the next tile;
+//   * the chunk stream runs across tiles (a persistent grid of one workgroup per CU walks the pixel tiles in the XCD-aware order of
+//     conv3x3_wp_kernel): tile decode, first-tile latency and pipeline fill are paid once per launch, not per tile.
+// Serves Cin = Cout = 64 from one same-size source with the plain / prologue / GroupNorm-statistics epilogues (inference and the training
+// forward: 12 of the 43 3x3 launches of a denoise step); everything else stays on conv3x3_wp_kernel.  OFD_CONV_PC=0 switches it off.
+//
+// OFD_PC_ABL (diagnostic builds, wrong results): 2 the producers fetch nothing (they stage whatever their registers hold), 8 no MFMAs
+#ifndef OFD_PC_ABL
+#define OFD_PC_ABL 0
+#endif
+#if OFD_WP_STAMPS
+// diagnostic build: the producers stamp step PC_STAMP_STEP of their walk (1 step start, 2 loads issued, 3 chunk staged, 4 barrier passed), the
+// consumers the item that step belongs to (5 item start, 6 / 8 chunk issued, 7 / 9 barrier passed, 10 epilogue issued)
+#define PC_STAMP_STEP 24
+#define PC_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PC_STAMP_P(k) do { if (i == PC_STAMP_STEP) PC_STAMP(k); } while (0)
+#define PC_STAMP_C(k) do { if (item_no == PC_STAMP_STEP / 2) PC_STAMP(k); } while (0)
+#define PC_STAMP_FLUSH() do { stamps[15] = __builtin_amdgcn_s_memrealtime(); const unsigned wv = blockIdx.x * 8 + (threadIdx.x >> 6);            \
+        if ((threadIdx.x & 63) == 0 && wv < (unsigned)STAMP_WAVES) for (int q_ = 0; q_ < STAMP_SLOTS; ++q_) g_wp_stamps[(size_t)wv * STAMP_SLOTS + q_] = stamps[q_]; } while (0)
+#else
+#define PC_STAMP(i) do { } while (0)
+#define PC_STAMP_P(k) do { } while (0)
+#define PC_STAMP_C(k) do { } while (0)
+#define PC_STAMP_FLUSH() do { } while (0)
+#endif
+
+struct PcCfg {
+    using C = Cfg<2, 2>;                               // consumers: 2 channel slices x 2 row blocks = a 16 x 32 pixel tile x 64 channels
+    static constexpr int NPROD = 256;
+    static constexpr int XPT = (C::NPIX * NC + NPROD - 1) / NPROD;
+    static constexpr int WFRAGS = 2 * FRAGS;           // weight fragments of a 32-channel slice: 2 chunks x 18
+    static constexpr int WBYTES = WFRAGS * 2 * 1024;   // [chunk * 18 + fragment][slice][lane][16 B]
+    static constexpr int LDS_BYTES = 2 * C::XB + WBYTES;
+};
+
+template <bool PRO>
+__global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) {
+    using C = PcCfg::C;
+    constexpr int NPROD = PcCfg::NPROD, XPT = PcCfg::XPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const wlds = smem + 2 * C::XB;
+    const int tid = threadIdx.x;
+#if OFD_WP_STAMPS
+    unsigned long long stamps[STAMP_SLOTS] = {};
+    stamps[14] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
+    const int tpi = P.tiles_x * tiles_y, ntiles = tpi * P.B, G = gridDim.x;
+    // item j (a pixel tile) -> (sample, tile origin), XCD-aware as conv3x3_wp_kernel: blocks that share an XCD (j % 8) walk a contiguous
+    // run of tiles, so the halo rows of neighbours hit one L2.  G is a multiple of 8.
+    auto decode = [&](int j, int& b, int& oy0, int& ox0) -> bool {
+        if (j >= ntiles) return false;
+        int tile = j;
+        if (ntiles >= 8) {
+            const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
+            tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        b = tile / tpi;
+        const int t_in = tile - b * tpi;
+        oy0 = (t_in / P.tiles_x) * C::ROWS;
+        ox0 = (t_in % P.tiles_x) * TW;
+        return true;
+    };
+    const int nit = blockIdx.x < ntiles ? (ntiles - 1 - blockIdx.x) / G + 1 : 0;     // items of this workgroup: j = blockIdx.x + k G
+    const int T = 2 * nit;                                                            // chunks it walks: both roles execute 1 + T barriers
+    if (T == 0) return;
+
+    // ---- the weights, once: fragment (kc, fi = (ks, kx, ky)) of slice ns for lane (l31, half) = 16 bytes at
+    //      [(ky * 3 + kx) * 8 + kc * 4 + ks * 2 + half][32 ns + l31][8] of the prepared tensor -> wlds[((kc * 18 + fi) * 2 + ns) * 1024 + lane * 16]
+    {
+        constexpr int UNITS = PcCfg::WFRAGS * 2 * 64;  // 4608 16-byte units, 9 per thread
+        u4 wv[UNITS / 512];
+#pragma unroll
+        for (int i = 0; i < UNITS / 512; ++i) {
+            const int u = tid + i * 512, ln = u & 63, fr = u >> 6, ns_ = fr & 1, f = fr >> 1, kc = f / FRAGS, fi = f - kc * FRAGS;
+            const int g = fi / 3, ky = fi - g * 3, ks = g / 3, kx = g - ks * 3;
+            const int row = (ky * 3 + kx) * 8 + kc * NC + ks * 2 + (ln >> 5);
+            wv[i] = *(const u4*)(P.weight + ((size_t)row * 64 + 32 * ns_ + (ln & 31)) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < UNITS / 512; ++i) *(u4*)(wlds + (size_t)(tid + i * 512) * 16) = wv[i];
+    }
+
+    if (tid >= 256) {
+        // =========================================================== producers
+        const int ptid = tid - 256;
+        const int c8 = ptid % NC;
+        int tyx[XPT];                                  // tile-relative (row << 8 | column) of this thread's units, halo included
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int p = min(ptid / NC + i * (NPROD / NC), C::NPIX - 1);
+            const int ty = p / IW;
+            tyx[i] = (ty << 8) | (p - ty * IW);
+        }
+        const ConvSrcDev& S = P.src[0];
+        int lj = blockIdx.x, lkc = 0, lb, loy0, lox0;     // load cursor: the chunk whose global loads are issued next
+        bool lvalid = decode(lj, lb, loy0, lox0);
+        auto advance = [&]() {
+            if (++lkc == 2) { lkc = 0; lj += G; lvalid = decode(lj, lb, loy0, lox0); }
+        };
+        auto issue = [&](u4 (&xs)[XPT], unsigned& okmask, float (&ps)[8], float (&pb)[8]) {
+            const bf16_t* base = S.ptr + (size_t)lb * S.SH * S.SW * S.src_channels + S.ch_offset + lkc * CK + c8 * 8;
+            okmask = 0;
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int iy = loy0 - 1 + (tyx[i] >> 8), ix = lox0 - 1 + (tyx[i] & 0xff);
+                const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+                okmask |= (ok ? 1u : 0u) << i;
+                const int sy = min(max(iy, 0), P.H - 1), sx = min(max(ix, 0), P.W - 1);
+                if (!(OFD_PC_ABL & 2)) xs[i] = *(const u4*)(base + ((size_t)sy * S.SW + sx) * S.src_channels);
+                else asm volatile("" : "+v"(xs[i]) : "v"(sy), "v"(sx));
+            }
+            if constexpr (PRO) {
+                const float* sp = P.in_scale + (size_t)lb * P.Cin_total + lkc * CK + c8 * 8;
+                const float* bp = P.in_shift + (size_t)lb * P.Cin_total + lkc * CK + c8 * 8;
+                *(float4*)&ps[0] = *(const float4*)sp; *(float4*)&ps[4] = *(const float4*)(sp + 4);
+                *(float4*)&pb[0] = *(const float4*)bp; *(float4*)&pb[4] = *(const float4*)(bp + 4);
+            }
+        };
+        auto stage = [&](const u4 (&xs)[XPT], const unsigned okmask, const float (&ps)[8], const float (&pb)[8], unsigned char* xbuf) {
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int p = min(ptid / NC + i * (NPROD / NC), C::NPIX - 1);
+                u4 v = xs[i];
+                if constexpr (PRO) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float lo = silu_f(bf2f((bf16_t)(v[j] & 0xffffu)) * ps[2 * j] + pb[2 * j]);
+                        const float hi = silu_f(bf2f((bf16_t)(v[j] >> 16)) * ps[2 * j + 1] + pb[2 * j + 1]);
+                        v[j] = f2bf2(lo, hi);
+                    }
+                }
+                const bool ok = (okmask >> i) & 1u;   // zero padding is applied AFTER the prologue (DD:181-187 -> DD:114)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
+                *(u4*)(xbuf + c8 * C::US + p * 16) = v;
+            }
+        };
+        // three register sets: chunk c lives in set c % 3 from its fetch (three steps before the consumers need it) to its staging
+        u4 x0[XPT], x1[XPT], x2[XPT];
+        unsigned ok0 = 0, ok1 = 0, ok2 = 0;
+        float ps0[8], pb0[8], ps1[8], pb1[8], ps2[8], pb2[8];
+        bool v0 = false, v1 = false, v2 = false;
+        issue(x0, ok0, ps0, pb0); advance(); v0 = true;                      // chunk 0
+        if (lvalid) { issue(x1, ok1, ps1, pb1); advance(); v1 = true; }     // chunk 1
+        if (lvalid) { issue(x2, ok2, ps2, pb2); advance(); v2 = true; }     // chunk 2
+        stage(x0, ok0, ps0, pb0, smem); v0 = false;
+        PC_STAMP(0);
+        __syncthreads();                                                     // barrier 0: chunk 0 and the weights are staged
+        // step i (the consumers multiply chunk i from buffer i % 2): fetch chunk i + 3 -> set i % 3, stage chunk i + 1 (set (i + 1) % 3) ->
+        // buffer (i + 1) % 2.  Period 6.
+#define PC_STEP(XL, OKL, PSL, PBL, VL, XS, OKS, PSS, PBS, VS, BUF)                                  \
+        {                                                                                           \
+            if (i >= T) break;                                                                      \
+            PC_STAMP_P(1);                                                                          \
+            if (lvalid) { issue(XL, OKL, PSL, PBL); advance(); VL = true; }                         \
+            PC_STAMP_P(2);                                                                          \
+            if (VS) { stage(XS, OKS, PSS, PBS, smem + (BUF) * C::XB); VS = false; }                 \
+            PC_STAMP_P(3);                                                                          \
+            __syncthreads();                                                                        \
+            PC_STAMP_P(4);                                                                          \
+            ++i;                                                                                    \
+        }
+        for (int i = 0; i < T;) {
+            PC_STEP(x0, ok0, ps0, pb0, v0, x1, ok1, ps1, pb1, v1, 1)
+            PC_STEP(x1, ok1, ps1, pb1, v1, x2, ok2, ps2, pb2, v2, 0)
+            PC_STEP(x2, ok2, ps2, pb2, v2, x0, ok0, ps0, pb0, v0, 1)
+            PC_STEP(x0, ok0, ps0, pb0, v0, x1, ok1, ps1, pb1, v1, 0)
+            PC_STEP(x1, ok1, ps1, pb1, v1, x2, ok2, ps2, pb2, v2, 1)
+            PC_STEP(x2, ok2, ps2, pb2, v2, x0, ok0, ps0, pb0, v0, 0)
+        }
+#undef PC_STEP
+        PC_STAMP_FLUSH();
+        return;
+    }
+
+    // =============================================================== consumers
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ns = wave & 1, ph = wave >> 1;
+    const int cb = 32 * ns;                           // this wave's 32 output channels
+    __builtin_amdgcn_s_setprio(2);                     // the MFMA stream goes first; the producer wave of this SIMD fills its gaps
+
+    float4 bias4[4];                                  // register 4 g + k of an accumulator row = channel cb + 8 g + 4 half + k
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = P.bias ? *(const float4*)(P.bias + cb + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x16 acc[8];
+    auto init_acc = [&]() {                            // accumulators start at the bias
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { acc[r][4 * g] = bias4[g].x; acc[r][4 * g + 1] = bias4[g].y; acc[r][4 * g + 2] = bias4[g].z; acc[r][4 * g + 3] = bias4[g].w; }
+    };
+    init_acc();
+
+    const int xrow_off = half * C::US + (8 * ph * IW + l31) * 16;
+    const unsigned char* const wfrag = wlds + ns * 1024 + lane * 16;
+    // one 32-channel chunk: 144 MFMAs, operands from LDS only
+    auto chunk = [&](const int kc, const unsigned char* xbase) {
+        const unsigned char* xrow = xbase + xrow_off;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            const int ks = g / 3, kx = g % 3;
+            bf16x8 x[10];
+#pragma unroll
+            for (int jr = 0; jr < 10; ++jr) x[jr] = *(const bf16x8*)(xrow + (jr * IW + kx) * 16 + ks * 2 * C::US);
+            bf16x8 a[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) a[ky] = *(const bf16x8*)(wfrag + (kc * FRAGS + g * 3 + ky) * 2048);
+            if (OFD_PC_ABL & 8) {
+#pragma unroll
+                for (int jr = 0; jr < 10; ++jr) asm volatile("" :: "v"(x[jr]));
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) asm volatile("" :: "v"(a[ky]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky], x[r + ky], acc[r], 0, 0, 0);
+            }
+        }
+    };
+
+    int j = blockIdx.x, b, oy0, ox0;
+    decode(j, b, oy0, ox0);                            // (T > 0: the first item is valid)
+    const int tiles8 = (P.H + 7) / 8;
+    __syncthreads();                                   // barrier 0: chunk 0 and the weights are staged
+    int item_no = 0;
+    (void)item_no;
+    while (true) {
+        PC_STAMP_C(5);
+        chunk(0, smem);
+        PC_STAMP_C(6);
+        __syncthreads();
+        PC_STAMP_C(7);
+        chunk(1, smem + C::XB);
+        PC_STAMP_C(8);
+        __syncthreads();
+        PC_STAMP_C(9);
+        // ---- epilogue of the tile (behind the barrier: the producers are already staging the next tile): bf16 16-byte stores (one
+        //      v_permlane32_swap per dword pairs two register quads), GroupNorm partial sums of the values as stored
+        __builtin_amdgcn_s_setprio(0);
+        float stat[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) stat[i] = 0.0f;
+        const int oyb = oy0 + 8 * ph, ox = ox0 + l31;
+        const bool okx = ox < P.W && !(P.dbg & 16);
+        bf16_t* orow = P.out + (((size_t)b * P.H + min(oyb, P.H - 1)) * P.W + min(ox, P.W - 1)) * 64 + cb + 8 * half;
+        const size_t ostride = (size_t)P.W * 64;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const bool ok = okx && oyb + r < P.H;
+            uint2 q[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                q[g] = make_uint2(f2bf2(acc[r][4 * g], acc[r][4 * g + 1]), f2bf2(acc[r][4 * g + 2], acc[r][4 * g + 3]));
+                if (P.gn_partial && ok) {
+                    const bf16x2 one = __builtin_bit_cast(bf16x2, 0x3f803f80u);
+                    const bf16x2 va = __builtin_bit_cast(bf16x2, q[g].x), vb = __builtin_bit_cast(bf16x2, q[g].y);
+                    stat[g * 2] = __builtin_amdgcn_fdot2_f32_bf16(vb, one, __builtin_amdgcn_fdot2_f32_bf16(va, one, stat[g * 2], false), false);
+                    stat[g * 2 + 1] = __builtin_amdgcn_fdot2_f32_bf16(vb, vb, __builtin_amdgcn_fdot2_f32_bf16(va, va, stat[g * 2 + 1], false), false);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
+                const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
+                if (ok) *(uint4*)(orow + 8 * g) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            }
+            orow += ostride;
+        }
+        if (P.gn_partial) {
+            // layout of conv3x3_wp_kernel: [b][8-row tile][tile column][4 slots][Cout/8][2]; this wave's sums go to slot ns, every other
+            // (slot, octet) of the workgroup's channel block is written as zero by the wave whose slot it is (slots ns, ns + 2)
+            wave_reduce8(stat);
+            const int ty8 = oy0 / 8 + ph;
+            if (ty8 < tiles8) {
+                constexpr int OCT = 8, PER_WAVE = 2 * OCT * 2;
+                const int slot_i = lane / (OCT * 2), o = (lane % (OCT * 2)) >> 1, which = lane & 1;
+                const float total = __shfl(stat[0], ((o & 3) * 2 + which) * 8, 64);      // value index k lives in lanes 8k .. 8k+7
+                if (lane < PER_WAVE) {
+                    const int slot = ns + slot_i * 2;
+                    const bool own = slot_i == 0 && (o >> 2) == ns;
+                    const size_t base = ((((size_t)b * tiles8 + ty8) * P.tiles_x + ox0 / TW) * 4 + slot) * 8 * 2;
+                    P.gn_partial[base + o * 2 + which] = own ? total : 0.0f;
+                }
+            }
+        }
+        PC_STAMP_C(10);
+        ++item_no;
+        j += G;
+        if (!decode(j, b, oy0, ox0)) break;
+        init_acc();
+        __builtin_amdgcn_s_setprio(2);
+    }
+    PC_STAMP_FLUSH();
+}
+
+// 64 -> 64, one same-size source, plain / prologue / statistics epilogue: the shapes conv3x3_pc_kernel serves
+static bool pc_serves(const ConvParams& P) {
+    return P.Cout == 64 && P.Cin_total == 64 && P.n_src == 1 && P.src[0].mode == 0 && P.total_chunks == 1 && !P.residual && !P.residual_b && !P.res_act &&
+           !P.split && !P.pool2 && !P.out2 && P.W <= 8160 /* tile-relative columns are packed into 8 bits + origin */;
+}
+
+template <bool PRO>
+static int launch_pc(const ConvParams& P, hipStream_t s) {
+    using C = PcCfg::C;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        OFD_HIP(hipGetDevice(&dev));
+        OFD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        OFD_HIP(hipFuncSetAttribute((const void*)conv3x3_pc_kernel<PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, PcCfg::LDS_BYTES));
+        static const int g_env = getenv("OFD_CONV_PC_GRID") ? atoi(getenv("OFD_CONV_PC_GRID")) : 0;
+        if (g_env > 0) cus = g_env;
+        cus = cus / 8 * 8;
+        if (cus < 8) cus = 8;
+    }
+    const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
+    const int ntiles = P.tiles_x * tiles_y * P.B;
+    const int grid = ntiles < cus ? (ntiles + 7) / 8 * 8 : cus;      // one 512-thread workgroup per CU; a multiple of 8 (the kernel's item order relies on it)
+    conv3x3_pc_kernel<PRO><<<grid, 512, PcCfg::LDS_BYTES, s>>>(P);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
 // ---- Upsample(x2, nearest) + 3x3 (DD:89-93) as its four 2x2 phase convs on the LOW-RES tensor, all four in one workgroup (r03) ---------
 // Output pixel (2y + py, 2x + px) reads low-res rows y - 1 + py + {0, 1} and columns x - 1 + px + {0, 1} with the collapsed weights of
 // ofd_conv_upsample_phase_weight_prep (4 x [2x2 taps][Cin/8][Cout][8]): 2.25x fewer MACs than the 3x3 over the up-sampled tensor.  The
@@ -926,6 +1270,9 @@ int launch_conv3x3_wp(const ConvParams& P0, bool wide, hipStream_t s) {
     static const int wp16 = getenv("OFD_CONV_WP16") ? atoi(getenv("OFD_CONV_WP16")) : 1;
     if (wide && wp16 && !P.residual && !P.residual_b && !P.res_act && !P.split && !P.pool2 && !P.out2)
         return P.in_scale ? wp::launch16<true>(P, s) : wp::launch16<false>(P, s);
+    // producer / consumer form for the 64 -> 64 layers with plain / prologue / statistics epilogues (OFD_CONV_PC=0: off)
+    static const int pc = getenv("OFD_CONV_PC") ? atoi(getenv("OFD_CONV_PC")) : 1;
+    if (!wide && pc && wp::pc_serves(P)) return P.in_scale ? wp::launch_pc<true>(P, s) : wp::launch_pc<false>(P, s);
     if (P.in_scale) return wide ? wp::launch<4, 1, true>(P, s) : wp::launch<2, 2, true>(P, s);
     return wide ? wp::launch<4, 1, false>(P, s) : wp::launch<2, 2, false>(P, s);
 }

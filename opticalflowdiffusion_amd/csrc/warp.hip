@@ -1223,6 +1223,192 @@ __global__ void __launch_bounds__(TH * 16) grid_warp_ring_kernel(const float* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead loads of the last items land before the workgroup gives its LDS back
 }
 
+// Band variant (C = 3; r04).  The memory-only forms of the decompositions (tools/probe/gw_stream_probe.hip: window DMA, flow loads and stores of a
+// launch with no arithmetic and no waits) say what the 64 x 64 tile kernels above are bound by: 69-71 us against 53-55 us for a linear copy of
+// the same planes -- every tile fetches a window 2.9 x its own size, and although L2 serves most of the overlap the window traffic is what the
+// launch is made of (the tile kernels measure 70-73 us: at their pattern's bound, which is why three schedules of them changed nothing).
+// Wide-short TILES are worse (8 x 512: 87 us; the window is 7 x the tile); what streams is a workgroup that owns a COLUMN BAND and slides down
+// it, fetching every source row once per band: 58-64 us memory-only.  LDS holds the three channels, so the band is 128 columns wide:
+//   * workgroup = (sample, band of 128 columns, segment of rows): 1024 threads, one pixel each per step of 8 output rows (wave = half a row);
+//   * the window of a step is 7 groups of 8 source rows (rows y - 24 .. y + 31 of the band's columns x - 24 .. x + 151, three channels);
+//     LDS is a ring of 9 such groups (3 x 72 x 176 floats = 152 KB): step s gathers from groups s .. s + 6 while group s + 8 -- needed two
+//     steps later -- arrives by LDS-DMA (global_load_lds_dwordx4) into the slot group s - 1 has left; ONE barrier and ONE counted vmcnt wait per
+//     step (per wave the VMEM order of a step is [flow of the next step: 2] [DMA: 1 or 2 pieces] [stores: 3 or 6]; "flow(s) and group s + 6
+//     have landed" = all but the youngest d + S operations have);
+//   * a source row enters LDS once per band and segment: window traffic 1.4 x (column halo) x 1.2 (the 24 + 31 warm-up rows of a segment)
+//     of the image instead of 2.9 x;
+//   * same arithmetic, operation order and border rules as the kernels above: bit-identical results.
+// Flow loads and the LDS reads of the common path are inline asm (a load the compiler can see makes it drain the LDS-DMA in flight); rows past
+// the end of a segment / columns past the image repeat the last row / column (the same values stored to the same place).
+constexpr int GB_W = 128, GB_TH = 8, GB_SLOTS = 9, GB_NEED = 7, GB_RX = 24, GB_RYUP = 24, GB_THREADS = 1024;
+constexpr int GB_WW = GB_W + 2 * GB_RX, GB_ROWS = GB_SLOTS * GB_TH, GB_CH = GB_ROWS * GB_WW;     // 176 columns, 72 rows, floats per channel ring
+constexpr int GB_LDS_BYTES = 3 * GB_CH * 4;
+constexpr int GB_GRP = GB_TH * GB_WW;                      // floats of one channel of a group: 1408 = 5.5 wave-pieces of 256 floats
+
+template <bool MASK>
+__global__ void __launch_bounds__(GB_THREADS) grid_warp_band_kernel(const float* __restrict__ second, const float* __restrict__ flow,
+                                                                    float* __restrict__ out, float* __restrict__ mask, int B, int H, int W,
+                                                                    int bands, int nseg, int seg_rows) {
+    extern __shared__ __attribute__((aligned(16))) float win[];
+    constexpr int C = 3, S = MASK ? 6 : 3;
+    const size_t plane = (size_t)H * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // block -> (sample, band, segment); the workgroups of one XCD (block % 8) take neighbouring units: the column halos two bands share and the
+    // warm-up rows two segments share come from that XCD's L2
+    int j = blockIdx.x;
+    {
+        const int g = (int)gridDim.x;
+        if ((g & 7) == 0) j = (j & 7) * (g >> 3) + (j >> 3);
+    }
+    const int seg = j % nseg, band = (j / nseg) % bands, n = j / (nseg * bands);
+    if (n >= B) return;
+    const int r0 = seg * seg_rows, r1 = min(r0 + seg_rows, H);
+    if (r0 >= r1) return;
+    const int ox0 = band * GB_W, wx0 = ox0 - GB_RX, rbase = r0 - GB_RYUP;
+    const int nsteps = (r1 - r0 + GB_TH - 1) / GB_TH;
+
+    // ---- window pieces of this wave: piece id 0..14 = full piece k = id % 5 of channel id / 5, 15..17 = the half piece (k = 5, lanes 0..31) of
+    //      channel id - 15.  Wave w issues piece w; waves 0 and 1 also pieces 16 and 17.
+    const bool two = wave < 2;
+    auto piece_geom = [&](int id, int& c, int& k, bool& half) { half = id >= 15; c = half ? id - 15 : id / 5; k = half ? 5 : id % 5; };
+    int c_a, k_a, c_b = 0, k_b = 0;
+    bool half_a, half_b = true;
+    piece_geom(wave, c_a, k_a, half_a);
+    if (two) piece_geom(16 + wave, c_b, k_b, half_b);
+    auto lane_rc = [&](int k, int& row, int& col) { const int f = 256 * k + 4 * lane; row = f / GB_WW; col = f - row * GB_WW; };
+    int prow_a, pcol_a, prow_b, pcol_b;
+    lane_rc(k_a, prow_a, pcol_a);
+    lane_rc(k_b, prow_b, pcol_b);
+    const float* const img_n = second + (size_t)n * C * plane;
+    auto dma_piece = [&](int q, int c, int k, bool half, int prow, int pcol) {        // this wave's piece of group q -> slot q % 9
+        const int gy = min(max(rbase + q * GB_TH + min(prow, GB_TH - 1), 0), H - 1), gx = min(max(wx0 + pcol, 0), W - 4);
+        const float* src = img_n + (size_t)c * plane + (size_t)gy * W + gx;
+        float* dst = win + c * GB_CH + (q % GB_SLOTS) * GB_GRP + 256 * k;
+        if (!half || lane < 32) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    auto dma_group = [&](int q) {
+        dma_piece(q, c_a, k_a, half_a, prow_a, pcol_a);
+        if (two) dma_piece(q, c_b, k_b, half_b, prow_b, pcol_b);
+    };
+
+    // ---- this thread's pixel of a step: row ty of the 8, column tx of the band (clamped into the image: duplicates store the same value)
+    const int ty = wave >> 1, tx = (wave & 1) * 64 + lane;
+    const int xc = min(ox0 + tx, W - 1);
+    const float* const flow_n = flow + (size_t)n * 2 * plane;
+    float f0, f1;
+    auto flow_issue = [&](int s) {                            // two loads the compiler does not count
+        const int yy = min(r0 + s * GB_TH + ty, r1 - 1);
+        const unsigned off = (unsigned)(yy * W + xc) * 4u;
+        const float* p0 = flow_n;
+        const float* p1 = flow_n + plane;
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(f0) : "v"(off), "s"(p0) : "memory");
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(f1) : "v"(off), "s"(p1) : "memory");
+    };
+    const unsigned win_addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)win;
+    const float dwf = (float)max(W - 1, 1), dhf = (float)max(H - 1, 1), rwf = 1.0f / dwf, rhf = 1.0f / dhf;
+    const int ixlo = max(0, wx0);
+    const unsigned ixspan = (unsigned)(min(W, wx0 + GB_WW) - 2 - ixlo);
+
+    // ---- fill: groups 0 .. 7 (step 0 needs 0 .. 6), the flow of step 0
+    flow_issue(0);
+    for (int q = 0; q < GB_SLOTS - 1; ++q) dma_group(q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(f0), "+v"(f1) :: "memory");
+
+    for (int s = 0; s < nsteps; ++s) {
+        __builtin_amdgcn_s_barrier();                          // group s + 6 is complete; everybody is done with step s - 1 (the slot of group s - 1 is free)
+        const int ystep = r0 + s * GB_TH, wy0 = rbase + s * GB_TH;
+        const int yy = min(ystep + ty, r1 - 1);
+        // coordinates of this pixel (WP:105-109 -> ATen's un-normalisation), from the flow registers
+        float ix, iy;
+        grid_coords_rcp(f0, f1, xc, yy, H, W, dwf, rwf, dhf, rhf, ix, iy);
+        // the next step's flow, then the window group two steps ahead (in this order: the wait at the top of the next step leaves the DMA in flight)
+        flow_issue(min(s + 1, nsteps - 1));
+        dma_group(s + GB_SLOTS - 1);
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        const bool finite = fabsf(ix) < 1.0e9f && fabsf(iy) < 1.0e9f;
+        const int x0 = finite ? (int)fx0 : -10, y0 = finite ? (int)fy0 : -10;
+        const float wxa = fx0 + 1.0f - ix, wxb = ix - fx0, wya = fy0 + 1.0f - iy, wyb = iy - fy0;
+        const float w0 = wxa * wya, w1 = wxb * wya, w2 = wxa * wyb, w3 = wxb * wyb;
+        const int lx = x0 - wx0, lt = y0 - wy0;               // window coordinates of the north-west corner: column 0..175, row 0..55 of the step's window
+        const int iylo = max(0, wy0);
+        const unsigned iyspan = (unsigned)(min(H, wy0 + GB_NEED * GB_TH) - 2 - iylo);
+        // both corners inside the image AND inside the staged window, per axis as ONE range test
+        const bool inner = (unsigned)(x0 - ixlo) <= ixspan && (unsigned)(y0 - iylo) <= iyspan;
+        const unsigned sbase = (unsigned)((s % GB_SLOTS) * GB_TH);
+        auto ring_row = [&](int t) { const unsigned r = sbase + (unsigned)t; return min(r, r - (unsigned)GB_ROWS); };       // (t in 0..56: one wrap at most)
+        const size_t pix = (size_t)yy * W + xc;
+        float m = 1.0f;
+        float o[C];
+        if (inner) {
+            const unsigned li = ring_row(lt) * GB_WW + (unsigned)lx;
+            unsigned ls = li + GB_WW;
+            ls = min(ls, ls - (unsigned)GB_CH);                // the south row of ring row 71 is ring row 0
+            f32x2v top[C], bot[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const unsigned a0 = win_addr + (li + c * GB_CH) * 4u, a1 = win_addr + (ls + c * GB_CH) * 4u;
+                asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read2_b32 %1, %3 offset1:1" : "=&v"(top[c]), "=&v"(bot[c]) : "v"(a0), "v"(a1) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(top[0]), "+v"(top[1]), "+v"(top[2]), "+v"(bot[0]), "+v"(bot[1]), "+v"(bot[2]) :: "memory");
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float acc = top[c].x * w0;
+                acc += top[c].y * w1;
+                acc += bot[c].x * w2;
+                acc += bot[c].y * w3;
+                o[c] = acc;
+            }
+        } else {
+            const bool bx0 = x0 >= 0 && x0 < W, bx1 = x0 + 1 >= 0 && x0 + 1 < W, by0 = y0 >= 0 && y0 < H, by1 = y0 + 1 >= 0 && y0 + 1 < H;
+            const unsigned inb = (bx0 && by0 ? 1u : 0u) | (bx1 && by0 ? 2u : 0u) | (bx0 && by1 ? 4u : 0u) | (bx1 && by1 ? 8u : 0u);
+            float ms = 0.0f;                                   // sum of in-bounds weights = grid_sample(ones)
+            if (bx0 && by0) ms += wxa * wya;
+            if (bx1 && by0) ms += wxb * wya;
+            if (bx0 && by1) ms += wxa * wyb;
+            if (bx1 && by1) ms += wxb * wyb;
+            if (ms < 0.999f) ms = 0.0f;                        // WP:116-117
+            if (ms > 0.0f) ms = 1.0f;
+            m = ms;
+            const bool cxa = lx >= 0 && lx < GB_WW, cxb = lx + 1 >= 0 && lx + 1 < GB_WW;
+            const bool rya = lt >= 0 && lt < GB_NEED * GB_TH, ryb = lt + 1 >= 0 && lt + 1 < GB_NEED * GB_TH;
+            const unsigned inw = (cxa && rya ? 1u : 0u) | (cxb && rya ? 2u : 0u) | (cxa && ryb ? 4u : 0u) | (cxb && ryb ? 8u : 0u);
+            const int gi = y0 * W + x0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float* sp = img_n + (size_t)c * plane;
+                float cv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool in_win = (inw >> k) & 1u, in_img = (inb >> k) & 1u;
+                    const unsigned idx = in_win ? ring_row(lt + (k >> 1)) * GB_WW + (unsigned)(lx + (k & 1)) + c * GB_CH : 0u;
+                    float v1 = win[idx];
+                    asm volatile("" : "+v"(v1));                               // (see grid_warp_tile_kernel)
+                    if (in_img && !in_win) v1 = sp[(size_t)(gi + (k & 1) + (k >> 1) * W)];      // beyond the staged window: rare
+                    cv[k] = v1;
+                }
+                // only in-bounds corners contribute (zeros padding); ATen's nw, ne, sw, se order
+                float acc = 0.0f;
+                if (inb & 1u) acc += cv[0] * w0;
+                if (inb & 2u) acc += cv[1] * w1;
+                if (inb & 4u) acc += cv[2] * w2;
+                if (inb & 8u) acc += cv[3] * w3;
+                o[c] = acc;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            out[((size_t)n * C + c) * plane + pix] = o[c];
+            if constexpr (MASK) mask[((size_t)n * C + c) * plane + pix] = m;
+        }
+        // the next step's flow and window group s + 7 have landed once all but the youngest (pieces of this step + stores) operations have
+        if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + S) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 + S) : "memory");
+        asm volatile("" : "+v"(f0), "+v"(f1) :: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead groups land before the workgroup gives its LDS back
+}
+
 // Gradient of warp_backward_flow's output with respect to the flow (ATen grid_sampler_2d_backward's grid gradient chained
 // through the reference's normalisation WP:108-109; the thresholded mask has no gradient).  A gather: one thread per pixel.
 __global__ void __launch_bounds__(256) grid_warp_flowgrad_kernel(const float* __restrict__ second, const float* __restrict__ flow,
@@ -1959,7 +2145,29 @@ extern "C" int ofd_grid_warp_fwd(const float* second, const float* flow, float* 
         // 0 (default) = the tile kernel above
         static const int ring = getenv("OFD_GW_RING") ? atoi(getenv("OFD_GW_RING")) : 0;
         static const int gdbg = getenv("OFD_GW_DBG") ? atoi(getenv("OFD_GW_DBG")) : 0;      // timing ablations only
-        if (C == 3 && ring == 2) {
+        // band form (grid_warp_band_kernel): C = 3 at sizes where a launch fills the chip; OFD_GW_BAND=0 restores the tile kernel
+        const int band = getenv("OFD_GW_BAND") ? atoi(getenv("OFD_GW_BAND")) : 1;        // (read per call: the tests compare the two forms in one process)
+        if (C == 3 && band && ring == 0 && W >= GB_W && H >= 4 * GB_TH && (long)H * W < (1L << 29)) {
+            static bool battr = false;
+            if (!battr) {
+                OFD_HIP(hipFuncSetAttribute((const void*)grid_warp_band_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS_BYTES));
+                OFD_HIP(hipFuncSetAttribute((const void*)grid_warp_band_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS_BYTES));
+                battr = true;
+            }
+            // segments: enough workgroups for one per CU, rows per segment a multiple of the step; a segment re-fetches 55 warm-up rows
+            const int bands = cdiv(W, GB_W);
+            static const int seg_env = getenv("OFD_GW_BAND_NSEG") ? atoi(getenv("OFD_GW_BAND_NSEG")) : 0;
+            int nseg = seg_env > 0 ? seg_env : cdiv(256, B * bands);
+            const int max_seg = H / (8 * GB_TH) > 0 ? H / (8 * GB_TH) : 1;                  // at least 64 rows per segment
+            if (nseg > max_seg) nseg = max_seg;
+            if (nseg < 1) nseg = 1;
+            const int seg_rows = cdiv(cdiv(H, nseg), GB_TH) * GB_TH;
+            nseg = cdiv(H, seg_rows);
+            const int gridb = B * bands * nseg;
+            if (mask) grid_warp_band_kernel<true><<<gridb, GB_THREADS, GB_LDS_BYTES, s_>>>(second, flow, out, mask, B, H, W, bands, nseg, seg_rows);
+            else grid_warp_band_kernel<false><<<gridb, GB_THREADS, GB_LDS_BYTES, s_>>>(second, flow, out, mask, B, H, W, bands, nseg, seg_rows);
+        }
+        else if (C == 3 && ring == 2) {
             using R = GwRing<32, 2>;
             static bool rattr = false;
             if (!rattr) {

@@ -261,13 +261,14 @@ def test_grid_sample_warp_full_size_properties(ofd):
     assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), 1.0) + 1e-2
 
 
-@pytest.mark.parametrize("B,H,W", [(16, 440, 1024), (3, 100, 1000), (1, 64, 64)])
+@pytest.mark.parametrize("B,H,W", [(16, 440, 1024), (3, 100, 1000), (1, 64, 64), (2, 40, 132), (1, 97, 260)])
 def test_grid_sample_warp_ring_kernel_against_the_oracle_at_size(ofd, B, H, W):
-    """The C = 3 grid_sample warp runs as a RING over (tile, channel) items (warp.hip: grid_warp_ring_kernel): counted waits, look-ahead
-    window loads across tile and sample seams, stores parked for threads outside the image.  At the BASELINE size every persistent
-    workgroup walks seven tiles; (3, 100, 1000) has partial tiles on both axes; one sample carries displacements beyond the staged
-    window (the global-load fallback) and non-finite flows.  Against the CPU oracle (the torch op the reference calls, WP:95-119):
-    mask bit-equal, values within 2e-6; the mask-less entry point (mask = NULL) returns the same image to the bit."""
+    """The C = 3 grid_sample warp at sizes: the BAND kernel (warp.hip: grid_warp_band_kernel, r04: a workgroup slides down a 128-column band
+    over a 72-row LDS ring, counted waits, look-ahead window groups) where W >= 128 and H >= 32, else the 64 x 64 tile kernel.  At the
+    BASELINE size every workgroup walks a 224-row segment of a band; (3, 100, 1000) has a partial band and a partial last step; (2, 40, 132)
+    a 4-column band; (1, 97, 260) an odd height; one sample carries displacements beyond the staged window (the global-load fallback) and
+    non-finite flows.  Against the CPU oracle (the torch op the reference calls, WP:95-119): mask bit-equal, values within 2e-6; the
+    mask-less entry point (mask = NULL) returns the same image to the bit."""
     from opticalflowdiffusion_amd._lib import lib, check, ptr, stream
     g = torch.Generator().manual_seed(B * 1000 + H)
     img = torch.rand(B, 3, H, W, generator=g)
@@ -289,6 +290,35 @@ def test_grid_sample_warp_ring_kernel_against_the_oracle_at_size(ofd, B, H, W):
     check(lib().ofd_grid_warp_fwd(ptr(img_d), ptr(flow_d), ptr(o2), None, B, 3, H, W, stream()))
     torch.cuda.synchronize()
     assert torch.equal(o2, o)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 40, 132), (1, 97, 260), (3, 100, 1000), (4, 440, 1024)])
+def test_grid_sample_warp_band_kernel_equals_the_tile_kernel(ofd, B, H, W):
+    """grid_warp_band_kernel (the default for C = 3 at W >= 128) against grid_warp_tile_kernel (OFD_GW_BAND=0) on the same inputs: same
+    arithmetic in the same order, so image and mask are equal to the bit -- also where corners leave the staged window (|flow| up to 45 px),
+    at the image border, with NaN / inf flows and at a segment seam."""
+    import os
+    g = torch.Generator().manual_seed(7 * B + H)
+    img = torch.rand(B, 3, H, W, generator=g).cuda()
+    flow = torch.nn.functional.avg_pool2d(torch.randn(B, 2, H, W, generator=g) * 8 * 9, 9, 1, 4).clamp(-20, 20)
+    flow[-1] = (torch.rand(2, H, W, generator=g) * 2 - 1) * 45.0
+    flow[0, :, H // 3, W // 2] = float("nan")
+    flow[0, 0, H // 2, W // 3] = float("inf")
+    flow = flow.cuda()
+    old = os.environ.get("OFD_GW_BAND")
+    try:
+        os.environ["OFD_GW_BAND"] = "1"
+        o1, m1 = ofd.warp(None, img, flow, mode="backward")
+        os.environ["OFD_GW_BAND"] = "0"
+        o0, m0 = ofd.warp(None, img, flow, mode="backward")
+    finally:
+        if old is None:
+            os.environ.pop("OFD_GW_BAND", None)
+        else:
+            os.environ["OFD_GW_BAND"] = old
+    torch.cuda.synchronize()
+    assert torch.equal(m1, m0)
+    assert torch.equal(o1, o0), float((o1 - o0).abs().max())
 
 
 def test_splat_full_size_properties(ofd):

@@ -17,7 +17,7 @@ constexpr int RX = 24, RY = 21;
 
 struct Args {
     const float* img; const float* flow; float* out; float* mask;
-    int B, H, W, TH, TW, tiles_x, tiles_y, seg_rows, nseg, xcd_order;
+    int B, H, W, TH, TW, tiles_x, tiles_y, seg_rows, nseg, xcd_order, per_channel;
 };
 
 __device__ __forceinline__ void dma16(const float* src, float* lds) {
@@ -35,7 +35,7 @@ __device__ __forceinline__ void fetch_rows(const float* plane, int wy0, int rows
     }
 }
 
-__device__ __forceinline__ void tile_flow_and_stores(const Args& a, int n, int oy0, int ox0, int th) {
+__device__ __forceinline__ void tile_flow_and_stores(const Args& a, int n, int oy0, int ox0, int th, int c0 = 0, int c1 = 3) {
     const size_t plane = (size_t)a.H * a.W;
     const int vpr = a.TW / 4, nv = th * vpr;
     for (int v = threadIdx.x; v < nv; v += blockDim.x) {
@@ -46,8 +46,7 @@ __device__ __forceinline__ void tile_flow_and_stores(const Args& a, int n, int o
             const float4 f0 = *(const float4*)(a.flow + (size_t)n * 2 * plane + pix);
             const float4 f1 = *(const float4*)(a.flow + (size_t)n * 2 * plane + plane + pix);
             const float4 o = make_float4(f0.x + f1.x, f0.y + f1.y, f0.z + f1.z, f0.w + f1.w);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int c = c0; c < c1; ++c) {
                 *(float4*)(a.out + ((size_t)n * 3 + c) * plane + pix) = o;
                 *(float4*)(a.mask + ((size_t)n * 3 + c) * plane + pix) = o;
             }
@@ -83,15 +82,19 @@ __global__ void __launch_bounds__(1024) form_slide(const Args a, int lds_floats)
         const int g = gridDim.x;
         if ((g & 7) == 0) j = (j & 7) * (g >> 3) + (j >> 3);
     }
+    // per_channel: one workgroup per (sample, band, segment, channel), the three channel workgroups of a segment adjacent in the order
+    const int nch = a.per_channel ? 3 : 1;
+    const int ch = j % nch; j /= nch;
     const int seg = j % a.nseg, band = (j / a.nseg) % bands, n = j / (a.nseg * bands);
     if (n >= a.B) return;
+    const int c0 = a.per_channel ? ch : 0, c1 = a.per_channel ? ch + 1 : 3;
     const int r0 = seg * a.seg_rows, r1 = min(r0 + a.seg_rows, a.H), ox0 = band * a.TW;
-    // warm-up: rows r0 - RY .. r0 + RY of the three planes
-    for (int c = 0; c < 3; ++c) fetch_rows(a.img + ((size_t)n * 3 + c) * plane, r0 - RY, 2 * RY + 1, ox0 - RX, a.TW + 2 * RX, a.H, a.W, lds, lds_floats);
+    // warm-up: rows r0 - RY .. r0 + RY of the planes
+    for (int c = c0; c < c1; ++c) fetch_rows(a.img + ((size_t)n * 3 + c) * plane, r0 - RY, 2 * RY + 1, ox0 - RX, a.TW + 2 * RX, a.H, a.W, lds, lds_floats);
     for (int y = r0; y < r1; y += a.TH) {
         const int th = min(a.TH, r1 - y);
-        for (int c = 0; c < 3; ++c) fetch_rows(a.img + ((size_t)n * 3 + c) * plane, y + RY + 1, th, ox0 - RX, a.TW + 2 * RX, a.H, a.W, lds, lds_floats);
-        tile_flow_and_stores(a, n, y, ox0, th);
+        for (int c = c0; c < c1; ++c) fetch_rows(a.img + ((size_t)n * 3 + c) * plane, y + RY + 1, th, ox0 - RX, a.TW + 2 * RX, a.H, a.W, lds, lds_floats);
+        tile_flow_and_stores(a, n, y, ox0, th, c0, c1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -137,7 +140,8 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)form_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute((const void*)form_slide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const double bytes = 44.0 * B * plane;
-    Args a{img, flow, out, mask, B, H, W, 0, 0, 0, 0, 0, 0, 1};
+    Args a{img, flow, out, mask, B, H, W, 0, 0, 0, 0, 0, 0, 1, 0};
+    const bool round2 = argc > 1;
     {
         const float us = timed([&] { form_linear<<<2048, 256>>>(a); });
         printf("{\"form\": \"linear\", \"us\": %.1f, \"TBps_algorithmic\": %.2f}\n", us, bytes / us / 1e6);
@@ -146,6 +150,7 @@ int main(int argc, char** argv) {
     const std::vector<TC> tcs = {{64, 64, 1024, 144, 256}, {64, 64, 512, 72, 512}, {32, 128, 1024, 144, 256}, {32, 128, 512, 72, 512}, {16, 256, 1024, 144, 256},
                                  {16, 256, 512, 72, 512}, {8, 512, 1024, 144, 256}, {8, 512, 512, 72, 512}, {4, 1024, 1024, 144, 256}, {8, 256, 512, 72, 512},
                                  {16, 128, 512, 72, 512}, {16, 256, 256, 36, 1024}, {8, 1024, 512, 72, 512}};
+    if (!round2)
     for (const TC& t : tcs)
         for (int xo = 0; xo < 2; ++xo) {
             a.TH = t.th; a.TW = t.tw; a.tiles_x = (W + t.tw - 1) / t.tw; a.tiles_y = (H + t.th - 1) / t.th; a.xcd_order = xo;
@@ -154,15 +159,19 @@ int main(int argc, char** argv) {
             printf("{\"form\": \"tiles\", \"TH\": %d, \"TW\": %d, \"threads\": %d, \"lds_kb\": %d, \"grid\": %d, \"xcd_order\": %d, \"us\": %.1f, \"TBps_algorithmic\": %.2f}\n",
                    t.th, t.tw, t.threads, t.lds_kb, t.grid, xo, us, bytes / us / 1e6);
         }
-    struct SC { int th, tw, threads, lds_kb, nseg; };
-    const std::vector<SC> scs = {{8, 128, 512, 72, 4}, {8, 128, 256, 36, 8}, {8, 256, 512, 72, 8}, {4, 256, 512, 72, 8}, {16, 256, 512, 72, 8}, {8, 256, 1024, 144, 4},
-                                 {8, 512, 1024, 144, 8}, {8, 512, 512, 72, 16}, {4, 1024, 1024, 144, 16}, {2, 1024, 512, 72, 32}, {8, 256, 256, 36, 16},
-                                 {8, 1024, 1024, 144, 16}};
+    struct SC { int th, tw, threads, lds_kb, nseg, pc; };
+    const std::vector<SC> scs2 = {{8, 128, 1024, 128, 2, 0}, {16, 128, 1024, 156, 2, 0}, {8, 128, 1024, 128, 4, 0}, {8, 128, 512, 128, 2, 0}, {4, 128, 1024, 128, 2, 0},
+                                  {8, 256, 512, 72, 4, 1}, {8, 256, 512, 72, 8, 1}, {8, 256, 256, 72, 4, 1}, {16, 256, 512, 72, 4, 1}, {8, 256, 1024, 144, 4, 0},
+                                  {8, 256, 1024, 144, 2, 0}, {8, 512, 1024, 144, 4, 0}, {8, 512, 512, 72, 4, 1}, {8, 1024, 1024, 72, 4, 1}, {8, 1024, 512, 72, 8, 1}};
+    const std::vector<SC> scs1 = {{8, 128, 512, 72, 4, 0}, {8, 128, 256, 36, 8, 0}, {8, 256, 512, 72, 8, 0}, {4, 256, 512, 72, 8, 0}, {16, 256, 512, 72, 8, 0}, {8, 256, 1024, 144, 4, 0},
+                                 {8, 512, 1024, 144, 8, 0}, {8, 512, 512, 72, 16, 0}, {4, 1024, 1024, 144, 16, 0}, {2, 1024, 512, 72, 32, 0}, {8, 256, 256, 36, 16, 0},
+                                 {8, 1024, 1024, 144, 16, 0}};
+    const std::vector<SC>& scs = round2 ? scs2 : scs1;
     for (const SC& s : scs)
         for (int xo = 0; xo < 2; ++xo) {
             a.TH = s.th; a.TW = s.tw; a.nseg = s.nseg; a.seg_rows = ((H + s.nseg - 1) / s.nseg + s.th - 1) / s.th * s.th; a.xcd_order = xo;
-            a.nseg = (H + a.seg_rows - 1) / a.seg_rows;
-            const int grid = B * (W / s.tw) * a.nseg, ldsf = s.lds_kb * 1024 / 4;
+            a.nseg = (H + a.seg_rows - 1) / a.seg_rows; a.per_channel = s.pc;
+            const int grid = B * (W / s.tw) * a.nseg * (s.pc ? 3 : 1), ldsf = s.lds_kb * 1024 / 4;
             const float us = timed([&] { form_slide<<<grid, s.threads, s.lds_kb * 1024>>>(a, ldsf); });
             printf("{\"form\": \"slide\", \"TH\": %d, \"TW\": %d, \"threads\": %d, \"lds_kb\": %d, \"nseg\": %d, \"seg_rows\": %d, \"grid\": %d, \"xcd_order\": %d, \"us\": %.1f, "
                    "\"TBps_algorithmic\": %.2f}\n", s.th, s.tw, s.threads, s.lds_kb, a.nseg, a.seg_rows, grid, xo, us, bytes / us / 1e6);

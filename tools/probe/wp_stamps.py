@@ -41,6 +41,24 @@ for _ in range(20):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 
+if os.environ.get("OFD_CONV_PC", "1") != "0" and cout == 64:
+    # producer / consumer kernel (conv3x3_pc_kernel): producers stamp step 24 of their walk, consumers item 12 (see PC_STAMP_* in conv_wp.hip)
+    raw = ctypes.CDLL(L.LIB_PATH)
+    SL, NW = 16, 1 << 16
+    buf = np.zeros(SL * NW, dtype=np.uint64)
+    assert raw.ofd_dbg_wp_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes)) == 0
+    s = buf.reshape(NW, SL).astype(np.int64)
+    s = s[:256 * 8].reshape(256, 8, SL)
+    cons, prod = s[:, :4].reshape(-1, SL), s[:, 4:].reshape(-1, SL)
+    med = lambda a: float(np.median(a))
+    res = {"kernel": "conv3x3_pc_kernel", "shape": [cin, cout, H, W, B], "prologue": pro, "ms": ms,
+           "producer_step_cycles": {"fetch (issue global loads of chunk i + 3)": med(prod[:, 2] - prod[:, 1]), "stage chunk i + 1 (prologue + ds_write)": med(prod[:, 3] - prod[:, 2]),
+                                    "wait at the barrier": med(prod[:, 4] - prod[:, 3])},
+           "consumer_item_cycles": {"chunk 0 issued": med(cons[:, 6] - cons[:, 5]), "barrier": med(cons[:, 7] - cons[:, 6]), "chunk 1 issued": med(cons[:, 8] - cons[:, 7]),
+                                    "barrier ": med(cons[:, 9] - cons[:, 8]), "epilogue": med(cons[:, 10] - cons[:, 9]), "item": med(cons[:, 10] - cons[:, 5])},
+           "wave_life_cycles": med(s[:, :, 15].reshape(-1) - s[:, :, 14].reshape(-1)) * 20.0}
+    print(json.dumps(res))
+    sys.exit(0)
 raw = ctypes.CDLL(L.LIB_PATH)
 SL, NW = 16, 1 << 16
 buf = np.zeros(SL * NW, dtype=np.uint64)
