@@ -72,27 +72,28 @@ __device__ __forceinline__ bf16x8 as_frag(u4 v) { return __builtin_bit_cast(bf16
 // butterfly reduction of 8 per-lane values over the wave: afterwards the lanes with (lane & 7) == 0 ... hold in v[0] the total
 // of value index (lane >> 3) (same scheme as conv_igemm.hip's WaveReduce)
 __device__ __forceinline__ void wave_reduce8(float (&v)[8]) {
+    // r04: on the VALU's own cross-lane paths (v_permlane32_swap / v_permlane16_swap exchange two values between half-waves / 16-lane rows
+    // in one instruction, DPP inside a row) instead of ten ds_bpermute round trips through the LDS pipe
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bool up = (lane & 32) != 0;
-        const float send = up ? v[i] : v[i + 4], keep = up ? v[i + 4] : v[i];
-        v[i] = keep + __shfl_xor(send, 32, 64);
+    for (int i = 0; i < 4; ++i) {                     // lanes < 32 keep value i, lanes >= 32 value i + 4: each adds what the other half holds of it
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 4]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const bool up = (lane & 16) != 0;
-        const float send = up ? v[i] : v[i + 2], keep = up ? v[i + 2] : v[i];
-        v[i] = keep + __shfl_xor(send, 16, 64);
+    for (int i = 0; i < 2; ++i) {                     // rows 0, 2 keep value i, rows 1, 3 value i + 2
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 2]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
     {
-        const bool up = (lane & 8) != 0;
+        const bool up = (lane & 8) != 0;              // lanes 0-7 of a row keep value 0, lanes 8-15 value 1
         const float send = up ? v[0] : v[1], keep = up ? v[1] : v[0];
-        v[0] = keep + __shfl_xor(send, 8, 64);
+        v[0] = keep + __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(send), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
     }
-    v[0] += __shfl_xor(v[0], 4, 64);
-    v[0] += __shfl_xor(v[0], 2, 64);
-    v[0] += __shfl_xor(v[0], 1, 64);
+    // the eight lanes of a group: i + (7 - i), then pairs inside a quad, then the two quads' lanes 0 / 2: lane 8 k holds the total
+    v[0] += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v[0]), 0x141 /* row_half_mirror */, 0xf, 0xf, false));
+    v[0] += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v[0]), 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
+    v[0] += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v[0]), 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false));
 }
 
 // PRO: the GroupNorm-affine + SiLU prologue is compiled in (P.in_scale != nullptr).  The chunk body below is ONE basic block (no
@@ -513,6 +514,10 @@ static int launch(const ConvParams& P, hipStream_t s) {
 // Serves the plain / prologue / GroupNorm-statistics forms (the inference step and the training forward); residual, split and pooled
 // epilogues (data gradients) stay on conv3x3_wp_kernel<4,1>.  OFD_CONV_WP16=0 switches it off.
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+// OFD_WP16_ABL (diagnostic builds, wrong results): 1 no global input loads after a tile's first chunk, 2 the weight sets are never refilled
+#ifndef OFD_WP16_ABL
+#define OFD_WP16_ABL 0
+#endif
 
 template <bool PRO>
 __global__ void __launch_bounds__(256, 2) conv3x3_wp16_kernel(const ConvParams P) {
@@ -576,7 +581,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wp16_kernel(const ConvParams P
 #pragma unroll
         for (int i = 0; i < C::XPT; ++i) {
             const int sy = (pyx[i] >> 16) >> up, sx = (pyx[i] & 0xffff) >> up;
-            xs[i] = *(const u4*)(base + ((size_t)sy * S.SW + sx) * S.src_channels);
+            if (!(OFD_WP16_ABL & 1) || kc == 0) xs[i] = *(const u4*)(base + ((size_t)sy * S.SW + sx) * S.src_channels);
+            else asm volatile("" : "+v"(xs[i]) : "v"(sy), "v"(sx));
         }
     };
     auto write_x = [&](int kc, const u4 (&xs)[C::XPT], unsigned char* xbuf) {
@@ -624,7 +630,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wp16_kernel(const ConvParams P
     const int xrow_off = lg * C::US + l15 * 16;       // octet lg, pixel l15 of a 16-pixel group
     // one kernel column of one chunk: 96 MFMAs with the weights in `cur`; `nxt` receives the next column's
     auto column = [&](const unsigned char* xrow, const int kx, u4 (&cur)[6], u4 (&nxt)[6], const int nkc, const int nkx, const bool fetch) {
-        if (fetch) {
+        if (fetch && !(OFD_WP16_ABL & 2)) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) nxt[i] = load_w(nkc, nkx, i);
         }
@@ -773,9 +779,13 @@ static int launch16(const ConvParams& P, hipStream_t s) {
 // Serves Cin = Cout = 64 from one same-size source with the plain / prologue / GroupNorm-statistics epilogues (inference and the training
 // forward: 12 of the 43 3x3 launches of a denoise step); everything else stays on conv3x3_wp_kernel.  OFD_CONV_PC=0 switches it off.
 //
-// OFD_PC_ABL (diagnostic builds, wrong results): 2 the producers fetch nothing (they stage whatever their registers hold), 8 no MFMAs
+// OFD_PC_ABL (diagnostic builds, wrong results): 2 the producers fetch nothing (they stage whatever their registers hold), 8 no MFMAs,
+// 16 no epilogue stores (statistics kept: the accumulators stay live)
 #ifndef OFD_PC_ABL
 #define OFD_PC_ABL 0
+#endif
+#ifndef OFD_PC_PRIO
+#define OFD_PC_PRIO 2
 #endif
 #if OFD_WP_STAMPS
 // diagnostic build: the producers stamp step PC_STAMP_STEP of their walk (1 step start, 2 loads issued, 3 chunk staged, 4 barrier passed), the
@@ -797,9 +807,10 @@ struct PcCfg {
     using C = Cfg<2, 2>;                               // consumers: 2 channel slices x 2 row blocks = a 16 x 32 pixel tile x 64 channels
     static constexpr int NPROD = 256;
     static constexpr int XPT = (C::NPIX * NC + NPROD - 1) / NPROD;
-    static constexpr int WFRAGS = 2 * FRAGS;           // weight fragments of a 32-channel slice: 2 chunks x 18
-    static constexpr int WBYTES = WFRAGS * 2 * 1024;   // [chunk * 18 + fragment][slice][lane][16 B]
-    static constexpr int LDS_BYTES = 2 * C::XB + WBYTES;
+    static constexpr int WSLOT = FRAGS * 2 * 1024;     // weights of one 32-channel chunk: [fragment][slice][lane][16 B] = 36.9 KB
+    static constexpr int MAX_ITEMS = 512;              // item descriptors of a workgroup, decoded once (16 bytes each)
+    static constexpr int ITEMS_OFF = 2 * C::XB + 2 * WSLOT;
+    static constexpr int LDS_BYTES = ITEMS_OFF + MAX_ITEMS * 16;
 };
 
 template <bool PRO>
@@ -815,12 +826,18 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
 #endif
 
     const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
-    const int tpi = P.tiles_x * tiles_y, ntiles = tpi * P.B, G = gridDim.x;
-    // item j (a pixel tile) -> (sample, tile origin), XCD-aware as conv3x3_wp_kernel: blocks that share an XCD (j % 8) walk a contiguous
-    // run of tiles, so the halo rows of neighbours hit one L2.  G is a multiple of 8.
-    auto decode = [&](int j, int& b, int& oy0, int& ox0) -> bool {
-        if (j >= ntiles) return false;
-        int tile = j;
+    const int tpi = P.tiles_x * tiles_y, ntiles = tpi * P.B, ny = P.Cout / C::BN, G = gridDim.x;
+    const int nitems = (ntiles + 7) / 8 * 8 * ny;     // item j -> XCD j % 8, channel block (j / 8) % ny, tile slot j / 8 / ny (as conv3x3_wp_kernel, cy_fast)
+    const int n32 = P.total_chunks * 2;
+    // item j -> (sample, tile origin, channel block), XCD-aware as conv3x3_wp_kernel: blocks that share an XCD (j % 8) walk a contiguous run
+    // of tiles (the halo rows of neighbours hit one L2), the channel blocks of a tile back to back.  G is a multiple of 8: once an item of
+    // this workgroup is past the end, every later one is too.
+    auto decode = [&](int j, int& b, int& oy0, int& ox0, int& cy) -> bool {
+        if (j >= nitems) return false;
+        const int g = j >> 3;
+        cy = ny > 1 ? g % ny : 0;
+        int tile = (ny > 1 ? g / ny : g) * 8 + (j & 7);
+        if (tile >= ntiles) return false;
         if (ntiles >= 8) {
             const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
             tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -831,25 +848,29 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
         ox0 = (t_in % P.tiles_x) * TW;
         return true;
     };
-    const int nit = blockIdx.x < ntiles ? (ntiles - 1 - blockIdx.x) / G + 1 : 0;     // items of this workgroup: j = blockIdx.x + k G
-    const int T = 2 * nit;                                                            // chunks it walks: both roles execute 1 + T barriers
-    if (T == 0) return;
-
-    // ---- the weights, once: fragment (kc, fi = (ks, kx, ky)) of slice ns for lane (l31, half) = 16 bytes at
-    //      [(ky * 3 + kx) * 8 + kc * 4 + ks * 2 + half][32 ns + l31][8] of the prepared tensor -> wlds[((kc * 18 + fi) * 2 + ns) * 1024 + lane * 16]
-    {
-        constexpr int UNITS = PcCfg::WFRAGS * 2 * 64;  // 4608 16-byte units, 9 per thread
-        u4 wv[UNITS / 512];
-#pragma unroll
-        for (int i = 0; i < UNITS / 512; ++i) {
-            const int u = tid + i * 512, ln = u & 63, fr = u >> 6, ns_ = fr & 1, f = fr >> 1, kc = f / FRAGS, fi = f - kc * FRAGS;
-            const int g = fi / 3, ky = fi - g * 3, ks = g / 3, kx = g - ks * 3;
-            const int row = (ky * 3 + kx) * 8 + kc * NC + ks * 2 + (ln >> 5);
-            wv[i] = *(const u4*)(P.weight + ((size_t)row * 64 + 32 * ns_ + (ln & 31)) * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < UNITS / 512; ++i) *(u4*)(wlds + (size_t)(tid + i * 512) * 16) = wv[i];
+    // the items of this workgroup (j = blockIdx.x + k G), decoded ONCE into LDS: the walk reads a descriptor instead of dividing
+    const int nit = blockIdx.x < nitems ? min((nitems - 1 - (int)blockIdx.x) / G + 1, PcCfg::MAX_ITEMS) : 0;
+    int4* const items = (int4*)(smem + PcCfg::ITEMS_OFF);
+    for (int k = tid; k < nit; k += 512) {
+        int b_, y_, x_, c_;
+        const bool ok = decode(blockIdx.x + k * G, b_, y_, x_, c_);
+        items[k] = make_int4(ok ? b_ : -1, y_, x_, c_);
     }
+    __syncthreads();
+    int nvalid_items = 0;
+    if (nit > 0) {                                     // (valid items come first: see decode)
+        int lo = 0, hi = nit;                          // first invalid index
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (items[mid].x >= 0) lo = mid + 1; else hi = mid; }
+        nvalid_items = lo;
+    }
+    const int T = n32 * nvalid_items;                  // chunks it walks: both roles execute 1 + T barriers
+    if (T == 0) return;
+    auto item_at = [&](int k, int& b, int& oy0, int& ox0, int& cy) -> bool {
+        if (k >= nvalid_items) return false;
+        const int4 d = items[k];
+        b = d.x; oy0 = d.y; ox0 = d.z; cy = d.w;
+        return true;
+    };
 
     if (tid >= 256) {
         // =========================================================== producers
@@ -862,21 +883,30 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
             const int ty = p / IW;
             tyx[i] = (ty << 8) | (p - ty * IW);
         }
-        const ConvSrcDev& S = P.src[0];
-        int lj = blockIdx.x, lkc = 0, lb, loy0, lox0;     // load cursor: the chunk whose global loads are issued next
-        bool lvalid = decode(lj, lb, loy0, lox0);
+        // load cursor: the chunk whose global loads are issued next.  Past the workgroup's last chunk it stays there (the loads are repeated
+        // into registers nobody stages for a consumer): no step of the walk is conditional, so a step is one basic block
+        int lk = 0, lkc = 0, lb, loy0, lox0, lcy;
+        item_at(0, lb, loy0, lox0, lcy);
         auto advance = [&]() {
-            if (++lkc == 2) { lkc = 0; lj += G; lvalid = decode(lj, lb, loy0, lox0); }
+            if (++lkc == n32) {
+                if (item_at(lk + 1, lb, loy0, lox0, lcy)) { lkc = 0; ++lk; }
+                else lkc = n32 - 1;
+            }
         };
         auto issue = [&](u4 (&xs)[XPT], unsigned& okmask, float (&ps)[8], float (&pb)[8]) {
-            const bf16_t* base = S.ptr + (size_t)lb * S.SH * S.SW * S.src_channels + S.ch_offset + lkc * CK + c8 * 8;
+            const int k64 = lkc >> 1;
+            int si = 0, first = 0;                     // the source that owns 64-channel chunk k64 (concatenated inputs, DD:405)
+            while (k64 >= first + P.src[si].chunks) { first += P.src[si].chunks; ++si; }
+            const ConvSrcDev& S = P.src[si];
+            const bf16_t* base = S.ptr + (size_t)lb * S.SH * S.SW * S.src_channels + S.ch_offset + (k64 - first) * 64 + (lkc & 1) * CK + c8 * 8;
+            const int up = S.mode == 1 ? 1 : 0;       // nearest x2 up-sampling of the source (DD:91) is a shift of the coordinates
             okmask = 0;
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
                 const int iy = loy0 - 1 + (tyx[i] >> 8), ix = lox0 - 1 + (tyx[i] & 0xff);
                 const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
                 okmask |= (ok ? 1u : 0u) << i;
-                const int sy = min(max(iy, 0), P.H - 1), sx = min(max(ix, 0), P.W - 1);
+                const int sy = min(max(iy, 0), P.H - 1) >> up, sx = min(max(ix, 0), P.W - 1) >> up;
                 if (!(OFD_PC_ABL & 2)) xs[i] = *(const u4*)(base + ((size_t)sy * S.SW + sx) * S.src_channels);
                 else asm volatile("" : "+v"(xs[i]) : "v"(sy), "v"(sx));
             }
@@ -910,34 +940,34 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
         u4 x0[XPT], x1[XPT], x2[XPT];
         unsigned ok0 = 0, ok1 = 0, ok2 = 0;
         float ps0[8], pb0[8], ps1[8], pb1[8], ps2[8], pb2[8];
-        bool v0 = false, v1 = false, v2 = false;
-        issue(x0, ok0, ps0, pb0); advance(); v0 = true;                      // chunk 0
-        if (lvalid) { issue(x1, ok1, ps1, pb1); advance(); v1 = true; }     // chunk 1
-        if (lvalid) { issue(x2, ok2, ps2, pb2); advance(); v2 = true; }     // chunk 2
-        stage(x0, ok0, ps0, pb0, smem); v0 = false;
+        issue(x0, ok0, ps0, pb0); advance();                                 // chunk 0
+        issue(x1, ok1, ps1, pb1); advance();                                 // chunk 1
+        issue(x2, ok2, ps2, pb2); advance();                                 // chunk 2
+        stage(x0, ok0, ps0, pb0, smem);
         PC_STAMP(0);
-        __syncthreads();                                                     // barrier 0: chunk 0 and the weights are staged
+        __syncthreads();                                                     // barrier 0: chunk 0 and its weights are staged
         // step i (the consumers multiply chunk i from buffer i % 2): fetch chunk i + 3 -> set i % 3, stage chunk i + 1 (set (i + 1) % 3) ->
-        // buffer (i + 1) % 2.  Period 6.
-#define PC_STEP(XL, OKL, PSL, PBL, VL, XS, OKS, PSS, PBS, VS, BUF)                                  \
+        // buffer (i + 1) % 2.  Period 6.  (Past the end of the walk a step stages stale registers into the buffer nobody reads.)
+#define PC_STEP(XL, OKL, PSL, PBL, XS, OKS, PSS, PBS, BUF)                                          \
         {                                                                                           \
             if (i >= T) break;                                                                      \
             PC_STAMP_P(1);                                                                          \
-            if (lvalid) { issue(XL, OKL, PSL, PBL); advance(); VL = true; }                         \
+            issue(XL, OKL, PSL, PBL);                                                               \
             PC_STAMP_P(2);                                                                          \
-            if (VS) { stage(XS, OKS, PSS, PBS, smem + (BUF) * C::XB); VS = false; }                 \
+            stage(XS, OKS, PSS, PBS, smem + (BUF) * C::XB);                                         \
+            advance();                                                                              \
             PC_STAMP_P(3);                                                                          \
             __syncthreads();                                                                        \
             PC_STAMP_P(4);                                                                          \
             ++i;                                                                                    \
         }
         for (int i = 0; i < T;) {
-            PC_STEP(x0, ok0, ps0, pb0, v0, x1, ok1, ps1, pb1, v1, 1)
-            PC_STEP(x1, ok1, ps1, pb1, v1, x2, ok2, ps2, pb2, v2, 0)
-            PC_STEP(x2, ok2, ps2, pb2, v2, x0, ok0, ps0, pb0, v0, 1)
-            PC_STEP(x0, ok0, ps0, pb0, v0, x1, ok1, ps1, pb1, v1, 0)
-            PC_STEP(x1, ok1, ps1, pb1, v1, x2, ok2, ps2, pb2, v2, 1)
-            PC_STEP(x2, ok2, ps2, pb2, v2, x0, ok0, ps0, pb0, v0, 0)
+            PC_STEP(x0, ok0, ps0, pb0, x1, ok1, ps1, pb1, 1)
+            PC_STEP(x1, ok1, ps1, pb1, x2, ok2, ps2, pb2, 0)
+            PC_STEP(x2, ok2, ps2, pb2, x0, ok0, ps0, pb0, 1)
+            PC_STEP(x0, ok0, ps0, pb0, x1, ok1, ps1, pb1, 0)
+            PC_STEP(x1, ok1, ps1, pb1, x2, ok2, ps2, pb2, 1)
+            PC_STEP(x2, ok2, ps2, pb2, x0, ok0, ps0, pb0, 0)
         }
 #undef PC_STEP
         PC_STAMP_FLUSH();
@@ -945,28 +975,57 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
     }
 
     // =============================================================== consumers
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int ns = wave & 1, ph = wave >> 1;
-    const int cb = 32 * ns;                           // this wave's 32 output channels
-    __builtin_amdgcn_s_setprio(2);                     // the MFMA stream goes first; the producer wave of this SIMD fills its gaps
+    if (OFD_PC_PRIO) __builtin_amdgcn_s_setprio(OFD_PC_PRIO);      // the MFMA stream goes first; the producer wave of this SIMD fills its gaps
 
-    float4 bias4[4];                                  // register 4 g + k of an accumulator row = channel cb + 8 g + 4 half + k
+    // ---- weights: chunk c of the walk lives in LDS slot c % 2, fragment-major [fragment (ks, kx, ky)][slice][lane][16 B].  The two
+    //      consumer waves of a slice fetch nine fragments each by LDS-DMA one chunk ahead (issued from inline asm: a DMA the compiler can
+    //      see makes it drain vmcnt in front of every LDS read of the MFMA loop); a slot that already holds the chunk is left alone (the
+    //      64 -> 64 layers: both chunks resident for the whole launch).
+    const int cin8 = P.Cin_total / 8;
+    const unsigned wlds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wlds;
+    int held0 = -1, held1 = -1;                        // (cy << 16 | kc) each slot holds
+    const unsigned w_lane = (unsigned)((half * P.Cout + 32 * ns + l31) * 16);      // this lane's 16 bytes of a fragment: row + half, column 32 ns + l31
+    auto weights_dma = [&](const int slot, const int cy_, const int kc) {
+        const int key = (cy_ << 16) | kc;
+        int& held = slot ? held1 : held0;
+        if (held == key) return;
+        held = key;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bias4[g] = P.bias ? *(const float4*)(P.bias + cb + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
-    f32x16 acc[8];
-    auto init_acc = [&]() {                            // accumulators start at the bias
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { acc[r][4 * g] = bias4[g].x; acc[r][4 * g + 1] = bias4[g].y; acc[r][4 * g + 2] = bias4[g].z; acc[r][4 * g + 3] = bias4[g].w; }
+        for (int q = 0; q < FRAGS / 2; ++q) {
+            const int fi = ph * (FRAGS / 2) + q;
+            const int g = fi / 3, ky = fi - g * 3, ks = g / 3, kx = g - ks * 3;
+            const int row = (ky * 3 + kx) * cin8 + kc * NC + ks * 2;
+            const bf16_t* sbase = P.weight + ((size_t)row * P.Cout + cy_ * C::BN) * 8;              // (uniform)
+            const unsigned dst = wlds_addr + (unsigned)(((slot * FRAGS + fi) * 2 + ns) * 1024);       // (uniform)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(w_lane), "s"(sbase) : "memory");
+        }
     };
-    init_acc();
+    auto weights_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+    int ik = 0, b, oy0, ox0, cy;
+    item_at(0, b, oy0, ox0, cy);                       // (T > 0: the first item is valid)
+    weights_dma(0, cy, 0);
+
+    f32x16 biasv;                                     // register 4 g + k of an accumulator row = channel cb + 8 g + 4 half + k
+    auto load_bias = [&](int cy_) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = P.bias ? *(const float4*)(P.bias + cy_ * C::BN + 32 * ns + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+            biasv[4 * g] = b4.x; biasv[4 * g + 1] = b4.y; biasv[4 * g + 2] = b4.z; biasv[4 * g + 3] = b4.w;
+        }
+    };
+    load_bias(cy);
+    f32x16 acc[8];
 
     const int xrow_off = half * C::US + (8 * ph * IW + l31) * 16;
     const unsigned char* const wfrag = wlds + ns * 1024 + lane * 16;
     // one 32-channel chunk: 144 MFMAs, operands from LDS only
-    auto chunk = [&](const int kc, const unsigned char* xbase) {
+    // (FIRST: the first chunk of an item -- its first MFMA per accumulator row takes the bias as its C operand: no accumulator initialisation)
+    auto chunk = [&](const int slot, const unsigned char* xbase, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const unsigned char* xrow = xbase + xrow_off;
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
@@ -976,7 +1035,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
             for (int jr = 0; jr < 10; ++jr) x[jr] = *(const bf16x8*)(xrow + (jr * IW + kx) * 16 + ks * 2 * C::US);
             bf16x8 a[3];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) a[ky] = *(const bf16x8*)(wfrag + (kc * FRAGS + g * 3 + ky) * 2048);
+            for (int ky = 0; ky < 3; ++ky) a[ky] = *(const bf16x8*)(wfrag + (slot * FRAGS + g * 3 + ky) * 2048);
             if (OFD_PC_ABL & 8) {
 #pragma unroll
                 for (int jr = 0; jr < 10; ++jr) asm volatile("" :: "v"(x[jr]));
@@ -986,37 +1045,47 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky], x[r + ky], acc[r], 0, 0, 0);
+                    for (int ky = 0; ky < 3; ++ky)
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky], x[r + ky], (FIRST && g == 0 && ky == 0) ? biasv : acc[r], 0, 0, 0);
             }
         }
     };
 
-    int j = blockIdx.x, b, oy0, ox0;
-    decode(j, b, oy0, ox0);                            // (T > 0: the first item is valid)
     const int tiles8 = (P.H + 7) / 8;
-    __syncthreads();                                   // barrier 0: chunk 0 and the weights are staged
+    weights_landed();
+    __syncthreads();                                   // barrier 0: chunk 0 and its weights are staged
     int item_no = 0;
     (void)item_no;
     while (true) {
         PC_STAMP_C(5);
-        chunk(0, smem);
-        PC_STAMP_C(6);
-        __syncthreads();
-        PC_STAMP_C(7);
-        chunk(1, smem + C::XB);
-        PC_STAMP_C(8);
-        __syncthreads();
-        PC_STAMP_C(9);
+        int nb, noy0, nox0, ncy;
+        const bool nvalid = item_at(ik + 1, nb, noy0, nox0, ncy);
+        for (int kc = 0; kc < n32; kc += 2) {
+            // (n32 is even: an item starts on slot / buffer 0)
+            weights_dma(1, cy, kc + 1);                // the next chunk's weights fly while this one is multiplied
+            if (kc == 0) chunk(0, smem, std::true_type{}); else chunk(0, smem, std::false_type{});
+            PC_STAMP_C(6);
+            weights_landed();
+            __syncthreads();
+            PC_STAMP_C(7);
+            if (kc + 2 < n32) weights_dma(0, cy, kc + 2);
+            else if (nvalid) weights_dma(0, ncy, 0);
+            chunk(1, smem + C::XB, std::false_type{});
+            PC_STAMP_C(8);
+            weights_landed();
+            __syncthreads();
+            PC_STAMP_C(9);
+        }
         // ---- epilogue of the tile (behind the barrier: the producers are already staging the next tile): bf16 16-byte stores (one
         //      v_permlane32_swap per dword pairs two register quads), GroupNorm partial sums of the values as stored
-        __builtin_amdgcn_s_setprio(0);
+        if (OFD_PC_PRIO) __builtin_amdgcn_s_setprio(0);
         float stat[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) stat[i] = 0.0f;
-        const int oyb = oy0 + 8 * ph, ox = ox0 + l31;
+        const int oyb = oy0 + 8 * ph, ox = ox0 + l31, cb = cy * C::BN + 32 * ns;
         const bool okx = ox < P.W && !(P.dbg & 16);
-        bf16_t* orow = P.out + (((size_t)b * P.H + min(oyb, P.H - 1)) * P.W + min(ox, P.W - 1)) * 64 + cb + 8 * half;
-        const size_t ostride = (size_t)P.W * 64;
+        bf16_t* orow = P.out + (((size_t)b * P.H + min(oyb, P.H - 1)) * P.W + min(ox, P.W - 1)) * P.Cout + cb + 8 * half;
+        const size_t ostride = (size_t)P.W * P.Cout;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const bool ok = okx && oyb + r < P.H;
@@ -1035,7 +1104,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
             for (int g = 0; g < 4; g += 2) {
                 const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
                 const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
-                if (ok) *(uint4*)(orow + 8 * g) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                if (ok && !(OFD_PC_ABL & 16)) *(uint4*)(orow + 8 * g) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                else if (OFD_PC_ABL & 16) asm volatile("" :: "v"(rx[0]), "v"(ry[0]), "v"(rx[1]), "v"(ry[1]));
             }
             orow += ostride;
         }
@@ -1051,25 +1121,27 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
                 if (lane < PER_WAVE) {
                     const int slot = ns + slot_i * 2;
                     const bool own = slot_i == 0 && (o >> 2) == ns;
-                    const size_t base = ((((size_t)b * tiles8 + ty8) * P.tiles_x + ox0 / TW) * 4 + slot) * 8 * 2;
-                    P.gn_partial[base + o * 2 + which] = own ? total : 0.0f;
+                    const size_t base = ((((size_t)b * tiles8 + ty8) * P.tiles_x + ox0 / TW) * 4 + slot) * (P.Cout / 8) * 2;
+                    P.gn_partial[base + (cy * C::BN / 8 + o) * 2 + which] = own ? total : 0.0f;
                 }
             }
         }
         PC_STAMP_C(10);
         ++item_no;
-        j += G;
-        if (!decode(j, b, oy0, ox0)) break;
-        init_acc();
-        __builtin_amdgcn_s_setprio(2);
+        if (!nvalid) break;
+        ++ik; b = nb; oy0 = noy0; ox0 = nox0;
+        if (ncy != cy) { cy = ncy; load_bias(cy); }
+        if (OFD_PC_PRIO) __builtin_amdgcn_s_setprio(OFD_PC_PRIO);
     }
     PC_STAMP_FLUSH();
 }
 
-// 64 -> 64, one same-size source, plain / prologue / statistics epilogue: the shapes conv3x3_pc_kernel serves
+// 64-channel output blocks, same-size or nearest-x2 sources, plain / prologue / statistics epilogue: the shapes conv3x3_pc_kernel serves
 static bool pc_serves(const ConvParams& P) {
-    return P.Cout == 64 && P.Cin_total == 64 && P.n_src == 1 && P.src[0].mode == 0 && P.total_chunks == 1 && !P.residual && !P.residual_b && !P.res_act &&
-           !P.split && !P.pool2 && !P.out2 && P.W <= 8160 /* tile-relative columns are packed into 8 bits + origin */;
+    for (int i = 0; i < P.n_src; ++i)
+        if (P.src[i].mode != 0 && P.src[i].mode != 1) return false;
+    return P.Cout % 64 == 0 && !P.residual && !P.residual_b && !P.res_act && !P.split && !P.pool2 && !P.out2 &&
+           P.W <= 8160 /* tile-relative columns are packed into 8 bits + origin */;
 }
 
 template <bool PRO>
@@ -1087,8 +1159,10 @@ static int launch_pc(const ConvParams& P, hipStream_t s) {
         if (cus < 8) cus = 8;
     }
     const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
-    const int ntiles = P.tiles_x * tiles_y * P.B;
-    const int grid = ntiles < cus ? (ntiles + 7) / 8 * 8 : cus;      // one 512-thread workgroup per CU; a multiple of 8 (the kernel's item order relies on it)
+    const int ntiles = P.tiles_x * tiles_y * P.B, ny = P.Cout / C::BN;
+    const int nitems = (ntiles + 7) / 8 * 8 * ny;
+    const int grid = nitems < cus ? nitems : cus;      // one 512-thread workgroup per CU; a multiple of 8 (the kernel's item order relies on it)
+    if ((long)grid * PcCfg::MAX_ITEMS < nitems) return 1;      // more items per workgroup than its descriptor table holds: not served
     conv3x3_pc_kernel<PRO><<<grid, 512, PcCfg::LDS_BYTES, s>>>(P);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
@@ -1272,7 +1346,10 @@ int launch_conv3x3_wp(const ConvParams& P0, bool wide, hipStream_t s) {
         return P.in_scale ? wp::launch16<true>(P, s) : wp::launch16<false>(P, s);
     // producer / consumer form for the 64 -> 64 layers with plain / prologue / statistics epilogues (OFD_CONV_PC=0: off)
     static const int pc = getenv("OFD_CONV_PC") ? atoi(getenv("OFD_CONV_PC")) : 1;
-    if (!wide && pc && wp::pc_serves(P)) return P.in_scale ? wp::launch_pc<true>(P, s) : wp::launch_pc<false>(P, s);
+    if (!wide && pc && wp::pc_serves(P)) {
+        const int r = P.in_scale ? wp::launch_pc<true>(P, s) : wp::launch_pc<false>(P, s);
+        if (r != 1) return r;
+    }
     if (P.in_scale) return wide ? wp::launch<4, 1, true>(P, s) : wp::launch<2, 2, true>(P, s);
     return wide ? wp::launch<4, 1, false>(P, s) : wp::launch<2, 2, false>(P, s);
 }

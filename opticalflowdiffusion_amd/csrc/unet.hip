@@ -910,8 +910,8 @@ const char* prof_class_name(int cls) {
         const bool phase_wp = env("OFD_PHASE_WP", 1) != 0;
         names[PC_CONV3] = std::string(!(wp & 1) ? "conv_igemm_kernel<3,128>" : (wp16 && !bn256 ? "conv3x3_wp16_kernel" : (bn256 ? "conv3x3_wp_kernel<8,1>|<4,1>" : "conv3x3_wp_kernel<4,1>"))) +
                           " [3x3, Cout a multiple of 128]";
-        names[PC_CONV3_64] = std::string((wp & 2) ? "conv3x3_wp_kernel<2,2>" : "conv_igemm_kernel<3,64>") + " [3x3, Cin > 64 -> 64]";
         const bool pc = env("OFD_CONV_PC", 1) != 0;
+        names[PC_CONV3_64] = std::string((wp & 2) ? (pc ? "conv3x3_pc_kernel" : "conv3x3_wp_kernel<2,2>") : "conv_igemm_kernel<3,64>") + " [3x3, Cin > 64 -> 64]";
         names[PC_CONV3_PP] = std::string((wp & 4) ? (pc ? "conv3x3_pc_kernel" : "conv3x3_wp_kernel<2,2>") : "conv3x3_c64_pingpong_kernel") + " [3x3, 64 -> 64]";
         names[PC_CONV1] = "conv1x1_wp_kernel | conv_igemm_kernel<1,BN> [1x1]";
         names[PC_CONV7] = "conv_igemm_kernel<8,64>|<7,64> [7x7 init conv]";
