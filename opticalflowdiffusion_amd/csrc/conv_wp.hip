@@ -867,8 +867,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
     if (T == 0) return;
     auto item_at = [&](int k, int& b, int& oy0, int& ox0, int& cy) -> bool {
         if (k >= nvalid_items) return false;
-        const int4 d = items[k];
-        b = d.x; oy0 = d.y; ox0 = d.z; cy = d.w;
+        const int4 d = items[k];                       // (the same for every lane: scalar registers from here on)
+        b = __builtin_amdgcn_readfirstlane(d.x); oy0 = __builtin_amdgcn_readfirstlane(d.y);
+        ox0 = __builtin_amdgcn_readfirstlane(d.z); cy = __builtin_amdgcn_readfirstlane(d.w);
         return true;
     };
 
@@ -1168,6 +1169,346 @@ static int launch_pc(const ConvParams& P, hipStream_t s) {
     return OFD_OK;
 }
 
+// ---- producer / consumer form of the 128-channel-block 3x3 (r04) -----------------------------------------------------------------------
+// conv3x3_wp16_kernel with its global loads taken out of the MFMA stream (same-box ablations of that kernel, profiles/r04_wp16_ablations.txt:
+// without the weight refills -11 %, without the input loads -2..6 %, without both -14..18 %: a wave's weight fragments come from L2 but return
+// in order behind the HBM loads of its own input tile).  One persistent 512-thread workgroup per CU:
+//   * waves 0-3, the consumers: wave = 32 output channels x 8 rows x 32 pixels on MFMA 16x16x32, the column body of conv3x3_wp16_kernel, both
+//     operands from LDS.  Weights: a PRIVATE ring of four kernel-column slots per wave (6 fragments = 6 KB each), filled by LDS-DMA the wave
+//     itself issues two columns (192 MFMAs) ahead and waits for with a counted vmcnt -- no barrier, no registers, and the only other VMEM
+//     operations of the wave are the stores of a tile's epilogue;
+//   * waves 4-7, the producers: input tile of chunk i + 3 into registers, prologue + LDS write of chunk i + 1 (as conv3x3_pc_kernel);
+//   * one workgroup barrier per 32-channel chunk (288 MFMAs per consumer wave); items = (8 x 32 pixel tile, 128-channel block), the channel
+//     blocks of a tile back to back, XCD-aware order; item descriptors decoded once into LDS.
+// Plain / prologue / statistics epilogues, same-size or nearest-x2 sources.  Parity-green and SLOWER than conv3x3_wp16_kernel (see launch_conv3x3_wp):
+// opt-in, OFD_CONV_PCW=1.
+struct PcwCfg {
+    using C = Cfg<4, 1>;
+    static constexpr int NPROD = 256;
+    static constexpr int XPT = (C::NPIX * NC + NPROD - 1) / NPROD;
+    static constexpr int WCOL = 6 * 1024, WSLOTS = 4, WWAVE = WSLOTS * WCOL;      // a wave's weight ring: 4 columns x 6 fragments x 1 KB
+    static constexpr int W_OFF = 2 * C::XB, ITEMS_OFF = W_OFF + 4 * WWAVE, MAX_ITEMS = 512;
+    static constexpr int LDS_BYTES = ITEMS_OFF + MAX_ITEMS * 16;
+};
+
+template <bool PRO>
+__global__ void __launch_bounds__(512, 2) conv3x3_pcw_kernel(const ConvParams P) {
+    using C = PcwCfg::C;
+    constexpr int NPROD = PcwCfg::NPROD, XPT = PcwCfg::XPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+
+    const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
+    const int tpi = P.tiles_x * tiles_y, ntiles = tpi * P.B, ny = P.Cout / C::BN, G = gridDim.x;
+    const int nitems = (ntiles + 7) / 8 * 8 * ny;
+    const int n32 = P.total_chunks * 2;
+    auto decode = [&](int j, int& b, int& oy0, int& ox0, int& cy) -> bool {
+        if (j >= nitems) return false;
+        const int g = j >> 3;
+        cy = ny > 1 ? g % ny : 0;
+        int tile = (ny > 1 ? g / ny : g) * 8 + (j & 7);
+        if (tile >= ntiles) return false;
+        if (ntiles >= 8) {
+            const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
+            tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        b = tile / tpi;
+        const int t_in = tile - b * tpi;
+        oy0 = (t_in / P.tiles_x) * C::ROWS;
+        ox0 = (t_in % P.tiles_x) * TW;
+        return true;
+    };
+    const int nit = blockIdx.x < nitems ? min((nitems - 1 - (int)blockIdx.x) / G + 1, PcwCfg::MAX_ITEMS) : 0;
+    int4* const items = (int4*)(smem + PcwCfg::ITEMS_OFF);
+    for (int k = tid; k < nit; k += 512) {
+        int b_, y_, x_, c_;
+        const bool ok = decode(blockIdx.x + k * G, b_, y_, x_, c_);
+        items[k] = make_int4(ok ? b_ : -1, y_, x_, c_);
+    }
+    __syncthreads();
+    int nvalid_items = 0;
+    if (nit > 0) {
+        int lo = 0, hi = nit;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (items[mid].x >= 0) lo = mid + 1; else hi = mid; }
+        nvalid_items = lo;
+    }
+    const int T = n32 * nvalid_items;                  // chunks this workgroup walks: both roles execute 1 + T barriers
+    if (T == 0) return;
+    auto item_at = [&](int k, int& b, int& oy0, int& ox0, int& cy) -> bool {
+        if (k >= nvalid_items) return false;
+        const int4 d = items[k];                       // (the same for every lane: scalar registers from here on)
+        b = __builtin_amdgcn_readfirstlane(d.x); oy0 = __builtin_amdgcn_readfirstlane(d.y);
+        ox0 = __builtin_amdgcn_readfirstlane(d.z); cy = __builtin_amdgcn_readfirstlane(d.w);
+        return true;
+    };
+
+    if (tid >= 256) {
+        // =========================================================== producers (as conv3x3_pc_kernel, 10 x 34 pixel tiles)
+        const int ptid = tid - 256;
+        const int c8 = ptid % NC;
+        int tyx[XPT];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int p = min(ptid / NC + i * (NPROD / NC), C::NPIX - 1);
+            const int ty = p / IW;
+            tyx[i] = (ty << 8) | (p - ty * IW);
+        }
+        int lk = 0, lkc = 0, lb, loy0, lox0, lcy;
+        item_at(0, lb, loy0, lox0, lcy);
+        auto advance = [&]() {
+            if (++lkc == n32) {
+                if (item_at(lk + 1, lb, loy0, lox0, lcy)) { lkc = 0; ++lk; }
+                else lkc = n32 - 1;
+            }
+        };
+        auto issue = [&](u4 (&xs)[XPT], unsigned& okmask, float (&ps)[8], float (&pb)[8]) {
+            const int k64 = lkc >> 1;
+            int si = 0, first = 0;
+            while (k64 >= first + P.src[si].chunks) { first += P.src[si].chunks; ++si; }
+            const ConvSrcDev& S = P.src[si];
+            const bf16_t* base = S.ptr + (size_t)lb * S.SH * S.SW * S.src_channels + S.ch_offset + (k64 - first) * 64 + (lkc & 1) * CK + c8 * 8;
+            const int up = S.mode == 1 ? 1 : 0;
+            okmask = 0;
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int iy = loy0 - 1 + (tyx[i] >> 8), ix = lox0 - 1 + (tyx[i] & 0xff);
+                const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+                okmask |= (ok ? 1u : 0u) << i;
+                const int sy = min(max(iy, 0), P.H - 1) >> up, sx = min(max(ix, 0), P.W - 1) >> up;
+                xs[i] = *(const u4*)(base + ((size_t)sy * S.SW + sx) * S.src_channels);
+            }
+            if constexpr (PRO) {
+                const float* sp = P.in_scale + (size_t)lb * P.Cin_total + lkc * CK + c8 * 8;
+                const float* bp = P.in_shift + (size_t)lb * P.Cin_total + lkc * CK + c8 * 8;
+                *(float4*)&ps[0] = *(const float4*)sp; *(float4*)&ps[4] = *(const float4*)(sp + 4);
+                *(float4*)&pb[0] = *(const float4*)bp; *(float4*)&pb[4] = *(const float4*)(bp + 4);
+            }
+        };
+        auto stage = [&](const u4 (&xs)[XPT], const unsigned okmask, const float (&ps)[8], const float (&pb)[8], unsigned char* xbuf) {
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int p = min(ptid / NC + i * (NPROD / NC), C::NPIX - 1);
+                u4 v = xs[i];
+                if constexpr (PRO) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float lo = silu_f(bf2f((bf16_t)(v[j] & 0xffffu)) * ps[2 * j] + pb[2 * j]);
+                        const float hi = silu_f(bf2f((bf16_t)(v[j] >> 16)) * ps[2 * j + 1] + pb[2 * j + 1]);
+                        v[j] = f2bf2(lo, hi);
+                    }
+                }
+                const bool ok = (okmask >> i) & 1u;   // zero padding is applied AFTER the prologue (DD:181-187 -> DD:114)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
+                *(u4*)(xbuf + c8 * C::US + p * 16) = v;
+            }
+        };
+        u4 x0[XPT], x1[XPT], x2[XPT];
+        unsigned ok0 = 0, ok1 = 0, ok2 = 0;
+        float ps0[8], pb0[8], ps1[8], pb1[8], ps2[8], pb2[8];
+        issue(x0, ok0, ps0, pb0); advance();
+        issue(x1, ok1, ps1, pb1); advance();
+        issue(x2, ok2, ps2, pb2); advance();
+        stage(x0, ok0, ps0, pb0, smem);
+        __syncthreads();                                                     // barrier 0: chunk 0 is staged
+#define PCW_STEP(XL, OKL, PSL, PBL, XS, OKS, PSS, PBS, BUF)                                         \
+        {                                                                                           \
+            if (i >= T) break;                                                                      \
+            issue(XL, OKL, PSL, PBL);                                                               \
+            stage(XS, OKS, PSS, PBS, smem + (BUF) * C::XB);                                         \
+            advance();                                                                              \
+            __syncthreads();                                                                        \
+            ++i;                                                                                    \
+        }
+        for (int i = 0; i < T;) {
+            PCW_STEP(x0, ok0, ps0, pb0, x1, ok1, ps1, pb1, 1)
+            PCW_STEP(x1, ok1, ps1, pb1, x2, ok2, ps2, pb2, 0)
+            PCW_STEP(x2, ok2, ps2, pb2, x0, ok0, ps0, pb0, 1)
+            PCW_STEP(x0, ok0, ps0, pb0, x1, ok1, ps1, pb1, 0)
+            PCW_STEP(x1, ok1, ps1, pb1, x2, ok2, ps2, pb2, 1)
+            PCW_STEP(x2, ok2, ps2, pb2, x0, ok0, ps0, pb0, 0)
+        }
+#undef PCW_STEP
+        return;
+    }
+
+    // =============================================================== consumers
+    const int lane = tid & 63, ns = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;           // column of a 16-wide tile; k-group (octet) of an operand / row group of an accumulator
+    __builtin_amdgcn_s_setprio(2);
+
+    // ---- weights: fragment (kx, ky, h) of 32-channel chunk kc = rows [tap][kc * 4 + lg][cb + 16 h + l15][8] of the prepared tensor.  The wave's
+    //      ring: column c of its walk (a column = one kx of one chunk: 6 fragments, i = ky * 2 + h) in slot c % 4, two columns ahead of its use
+    const int cin8 = P.Cin_total / 8;
+    unsigned char* const wring = smem + PcwCfg::W_OFF + ns * PcwCfg::WWAVE;
+    const unsigned wring_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wring;
+    const unsigned w_lane0 = (unsigned)((lg * P.Cout + 32 * ns + l15) * 16), w_lane1 = w_lane0 + 256u;      // h = 0 / 1
+    int wk = 0, wkc = 0, wkx = 0, wcol = 0, wb_, wy_, wx_, wcy;       // weight cursor: (item, chunk, kernel column) of the column fetched next; its index
+    item_at(0, wb_, wy_, wx_, wcy);
+    auto weights_issue = [&]() {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int ky = i >> 1, h = i & 1;
+            const int row = (ky * 3 + wkx) * cin8 + wkc * NC;
+            const bf16_t* sbase = P.weight + ((size_t)row * P.Cout + wcy * C::BN) * 8;                        // (uniform)
+            const unsigned dst = wring_addr + (unsigned)((wcol & (PcwCfg::WSLOTS - 1)) * PcwCfg::WCOL + i * 1024);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(h ? w_lane1 : w_lane0), "s"(sbase) : "memory");
+        }
+        ++wcol;
+        if (++wkx == 3) {
+            wkx = 0;
+            if (++wkc == n32) {
+                if (item_at(wk + 1, wb_, wy_, wx_, wcy)) { wkc = 0; ++wk; }
+                else { wkc = n32 - 1; wkx = 2; }               // past the end: the last column again (into a slot nobody reads any more)
+            }
+        }
+    };
+    weights_issue();
+    weights_issue();
+
+    int ik = 0, b, oy0, ox0, cy;
+    item_at(0, b, oy0, ox0, cy);
+    f32x4 bias4[2];
+    auto load_bias = [&](int cy_) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 t = P.bias ? *(const float4*)(P.bias + cy_ * C::BN + 32 * ns + 16 * h + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bias4[h][0] = t.x; bias4[h][1] = t.y; bias4[h][2] = t.z; bias4[h][3] = t.w;
+        }
+    };
+    load_bias(cy);
+    f32x4 acc[8][2][2];                               // [row][pixel half][channel half]
+
+    const int xrow_off = lg * C::US + l15 * 16;       // octet lg, pixel l15 of a 16-pixel group
+    int ccol = 0;                                     // index of the column multiplied next (slot ccol % 4)
+    // one kernel column of one chunk: 96 MFMAs; FIRST: the first column of an item (the bias is the first MFMA's C operand)
+    auto column = [&](const unsigned char* xrow, const int kx, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        weights_issue();                               // column ccol + 2
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");          // column ccol has landed (all but the two columns issued after it)
+        const unsigned char* wsl = wring + (ccol & (PcwCfg::WSLOTS - 1)) * PcwCfg::WCOL + lane * 16;
+        ++ccol;
+        bf16x8 w[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = *(const bf16x8*)(wsl + i * 1024);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {          // rows 4 hf .. 4 hf + 3 need staged rows 4 hf .. 4 hf + 5
+                bf16x8 x[6];
+#pragma unroll
+                for (int jr = 0; jr < 6; ++jr) x[jr] = *(const bf16x8*)(xrow + ((4 * hf + jr) * IW + kx + 16 * p) * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            acc[4 * hf + r][p][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ky * 2 + h], x[r + ky], (FIRST && ky == 0) ? bias4[h] : acc[4 * hf + r][p][h], 0, 0, 0);
+            }
+    };
+
+    const bf16x2 one = __builtin_bit_cast(bf16x2, 0x3f803f80u);
+    const int tiles8 = (P.H + 7) / 8;
+    __syncthreads();                                   // barrier 0: chunk 0 is staged
+    while (true) {
+        int nb, noy0, nox0, ncy;
+        const bool nvalid = item_at(ik + 1, nb, noy0, nox0, ncy);
+        for (int kc = 0; kc < n32; kc += 2) {
+            const unsigned char* xr0 = smem + xrow_off;
+            if (kc == 0) column(xr0, 0, std::true_type{}); else column(xr0, 0, std::false_type{});
+            column(xr0, 1, std::false_type{});
+            column(xr0, 2, std::false_type{});
+            __syncthreads();
+            const unsigned char* xr1 = smem + C::XB + xrow_off;
+            column(xr1, 0, std::false_type{});
+            column(xr1, 1, std::false_type{});
+            column(xr1, 2, std::false_type{});
+            __syncthreads();
+        }
+        // ---- epilogue (as conv3x3_wp16_kernel): bf16, 16-byte stores, GroupNorm partial sums of the values as stored
+        __builtin_amdgcn_s_setprio(0);
+        const int cb = cy * C::BN + 32 * ns;
+        float st[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+        const int c_store = cb + 16 * (lg & 1) + 8 * (lg >> 1);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int oy = oy0 + r;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int ox = ox0 + 16 * p + l15;
+                const bool ok = oy < P.H && ox < P.W && !(P.dbg & 16);
+                const size_t pix = ((size_t)b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1);
+                uint2 q[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 a = acc[r][p][h];
+                    q[h] = make_uint2(f2bf2(a[0], a[1]), f2bf2(a[2], a[3]));
+                    if (P.gn_partial && ok) {
+                        const bf16x2 va = __builtin_bit_cast(bf16x2, q[h].x), vb = __builtin_bit_cast(bf16x2, q[h].y);
+                        st[h][0] = __builtin_amdgcn_fdot2_f32_bf16(vb, one, __builtin_amdgcn_fdot2_f32_bf16(va, one, st[h][0], false), false);
+                        st[h][1] = __builtin_amdgcn_fdot2_f32_bf16(vb, vb, __builtin_amdgcn_fdot2_f32_bf16(va, va, st[h][1], false), false);
+                    }
+                }
+                const auto rx = __builtin_amdgcn_permlane16_swap(q[0].x, q[1].x, false, false);
+                const auto ry = __builtin_amdgcn_permlane16_swap(q[0].y, q[1].y, false, false);
+                if (ok) *(uint4*)(P.out + pix * P.Cout + c_store) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            }
+        }
+        if (P.gn_partial) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int w_ = 0; w_ < 2; ++w_) {
+                    float v = st[h][w_];
+                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
+                    st[h][w_] = v;
+                }
+            const int ty8 = oy0 / 8;
+            if (ty8 < tiles8) {
+                constexpr int OCT = C::BN / 8, PER_WAVE = OCT * 2;
+                const int o = (lane % PER_WAVE) >> 1, which = lane & 1;
+                const int oo = o & 3, hh = oo >> 1, mm = oo & 1;
+                const float t00 = __shfl(st[0][0], mm * 32, 64), t01 = __shfl(st[0][1], mm * 32, 64);
+                const float t10 = __shfl(st[1][0], mm * 32, 64), t11 = __shfl(st[1][1], mm * 32, 64);
+                const float total = hh ? (which ? t11 : t10) : (which ? t01 : t00);
+                if (lane < PER_WAVE) {
+                    const bool own = (o >> 2) == ns;
+                    const size_t base = ((((size_t)b * tiles8 + ty8) * P.tiles_x + ox0 / TW) * 4 + ns) * (P.Cout / 8) * 2;
+                    P.gn_partial[base + (cy * C::BN / 8 + o) * 2 + which] = own ? total : 0.0f;
+                }
+            }
+        }
+        if (!nvalid) break;
+        ++ik; b = nb; oy0 = noy0; ox0 = nox0;
+        if (ncy != cy) { cy = ncy; load_bias(cy); }
+        __builtin_amdgcn_s_setprio(2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the look-ahead weight columns land before the workgroup gives its LDS back
+}
+
+template <bool PRO>
+static int launch_pcw(const ConvParams& P, hipStream_t s) {
+    using C = PcwCfg::C;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        OFD_HIP(hipGetDevice(&dev));
+        OFD_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        OFD_HIP(hipFuncSetAttribute((const void*)conv3x3_pcw_kernel<PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, PcwCfg::LDS_BYTES));
+        cus = cus / 8 * 8;
+        if (cus < 8) cus = 8;
+    }
+    const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
+    const int ntiles = P.tiles_x * tiles_y * P.B, ny = P.Cout / C::BN;
+    const int nitems = (ntiles + 7) / 8 * 8 * ny;
+    const int grid = nitems < cus ? nitems : cus;
+    if ((long)grid * PcwCfg::MAX_ITEMS < nitems) return 1;     // more items per workgroup than its descriptor table holds: not served
+    conv3x3_pcw_kernel<PRO><<<grid, 512, PcwCfg::LDS_BYTES, s>>>(P);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
 // ---- Upsample(x2, nearest) + 3x3 (DD:89-93) as its four 2x2 phase convs on the LOW-RES tensor, all four in one workgroup (r03) ---------
 // Output pixel (2y + py, 2x + px) reads low-res rows y - 1 + py + {0, 1} and columns x - 1 + px + {0, 1} with the collapsed weights of
 // ofd_conv_upsample_phase_weight_prep (4 x [2x2 taps][Cin/8][Cout][8]): 2.25x fewer MACs than the 3x3 over the up-sampled tensor.  The
@@ -1340,6 +1681,20 @@ int launch_conv3x3_wp(const ConvParams& P0, bool wide, hipStream_t s) {
     // 256-channel blocks (8 waves over one staged tile: half the tile loads, LDS writes and prologue arithmetic per MFMA): OFD_CONV_WP_BN256=1
     static const int bn256 = getenv("OFD_CONV_WP_BN256") ? atoi(getenv("OFD_CONV_WP_BN256")) : 0;
     if (wide && bn256 && P.Cout % 256 == 0) return P.in_scale ? wp::launch<8, 1, true>(P, s) : wp::launch<8, 1, false>(P, s);
+    // producer / consumer kernel on the wide layers too, as Cout / 64 channel blocks per pixel tile (A/B switch: OFD_CONV_PC=2)
+    static const int pcw = getenv("OFD_CONV_PC") ? atoi(getenv("OFD_CONV_PC")) : 1;
+    if (wide && pcw == 2 && wp::pc_serves(P)) {
+        const int r = P.in_scale ? wp::launch_pc<true>(P, s) : wp::launch_pc<false>(P, s);
+        if (r != 1) return r;
+    }
+    // producer / consumer form of the 128-channel-block kernel: opt-in (OFD_CONV_PCW=1).  Same-box A/B against conv3x3_wp16_kernel
+    // (profiles/r04_pcw_ab.txt): 3-7 % SLOWER per layer, class 8.75 -> 9.2 ms per step -- with one MFMA wave per SIMD every barrier, column
+    // start and epilogue of that wave is matrix-pipe idle time, which two independent 4-wave workgroups per CU cover for each other
+    static const int pcwide = getenv("OFD_CONV_PCW") ? atoi(getenv("OFD_CONV_PCW")) : 0;
+    if (wide && pcwide && wp::pc_serves(P) && P.Cout % 128 == 0) {
+        const int r = P.in_scale ? wp::launch_pcw<true>(P, s) : wp::launch_pcw<false>(P, s);
+        if (r != 1) return r;
+    }
     // MFMA 16x16x32 form of the 128-channel-block kernel for the plain / prologue / statistics epilogues (OFD_CONV_WP16=0: off)
     static const int wp16 = getenv("OFD_CONV_WP16") ? atoi(getenv("OFD_CONV_WP16")) : 1;
     if (wide && wp16 && !P.residual && !P.residual_b && !P.res_act && !P.split && !P.pool2 && !P.out2)

@@ -908,7 +908,8 @@ const char* prof_class_name(int cls) {
         auto env = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
         const int wp = env("OFD_CONV_WP", 7), wp16 = env("OFD_CONV_WP16", 1), bn256 = env("OFD_CONV_WP_BN256", 0);
         const bool phase_wp = env("OFD_PHASE_WP", 1) != 0;
-        names[PC_CONV3] = std::string(!(wp & 1) ? "conv_igemm_kernel<3,128>" : (wp16 && !bn256 ? "conv3x3_wp16_kernel" : (bn256 ? "conv3x3_wp_kernel<8,1>|<4,1>" : "conv3x3_wp_kernel<4,1>"))) +
+        const bool pcw = env("OFD_CONV_PCW", 0) != 0;
+        names[PC_CONV3] = std::string(!(wp & 1) ? "conv_igemm_kernel<3,128>" : (bn256 ? "conv3x3_wp_kernel<8,1>|<4,1>" : (pcw ? "conv3x3_pcw_kernel" : (wp16 ? "conv3x3_wp16_kernel" : "conv3x3_wp_kernel<4,1>")))) +
                           " [3x3, Cout a multiple of 128]";
         const bool pc = env("OFD_CONV_PC", 1) != 0;
         names[PC_CONV3_64] = std::string((wp & 2) ? (pc ? "conv3x3_pc_kernel" : "conv3x3_wp_kernel<2,2>") : "conv_igemm_kernel<3,64>") + " [3x3, Cin > 64 -> 64]";
