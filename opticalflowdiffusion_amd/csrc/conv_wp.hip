@@ -937,15 +937,52 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
                 *(u4*)(xbuf + c8 * C::US + p * 16) = v;
             }
         };
+        // ---- weights: chunk c of the walk lives in LDS slot c % 2, fragment-major [fragment (ks, kx, ky)][slice][lane][16 B] (a consumer's
+        //      fragment = one conflict-free ds_read_b128 per lane).  The producers fetch the NEXT chunk's 36 fragments by LDS-DMA, nine per
+        //      wave, at the top of a step, and wait for them (counted: this step's input loads stay in flight) before its barrier.  Issued from
+        //      inline asm: a DMA the compiler can see makes it drain vmcnt in front of every LDS access.  An LDS-DMA costs its wave 60-180 issue
+        //      cycles: the consumers issued their own in a first version and lost a fifth of every chunk to it.  A slot that already holds the
+        //      chunk is left alone (the 64 -> 64 layers: both chunks resident for the whole launch).
+        const int pw = __builtin_amdgcn_readfirstlane(ptid >> 6), plane_ = ptid & 63;
+        const int cin8 = P.Cin_total / 8;
+        const unsigned wlds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wlds;
+        int held0 = -1, held1 = -1;                    // (cy << 16 | kc) each slot holds
+        int sk = 0, skc = 0, scy, sb_, sy_, sx_;       // stage cursor: the chunk staged next (its weights are fetched with it)
+        item_at(0, sb_, sy_, sx_, scy);
+        auto stage_advance = [&]() {
+            if (++skc == n32) {
+                if (item_at(sk + 1, sb_, sy_, sx_, scy)) { skc = 0; ++sk; }
+                else skc = n32 - 1;
+            }
+        };
+        auto weights_dma = [&](const int slot) -> bool {      // the stage cursor's chunk -> slot; false: the slot holds it already
+            const int key = (scy << 16) | skc;
+            int& held = slot ? held1 : held0;
+            if (held == key) return false;
+            held = key;
+#pragma unroll
+            for (int q = 0; q < FRAGS * 2 / 4; ++q) {
+                const int fr = pw * (FRAGS * 2 / 4) + q, fi = fr >> 1, ns_ = fr & 1;      // (fragment, slice)
+                const int g = fi / 3, ky = fi - g * 3, ks = g / 3, kx = g - ks * 3;
+                const int row = (ky * 3 + kx) * cin8 + skc * NC + ks * 2;
+                const bf16_t* sbase = P.weight + ((size_t)row * P.Cout + scy * C::BN + 32 * ns_) * 8;                 // (uniform)
+                const unsigned dst = wlds_addr + (unsigned)(((slot * FRAGS + fi) * 2 + ns_) * 1024);                  // (uniform)
+                const unsigned voff = (unsigned)(((plane_ >> 5) * P.Cout + (plane_ & 31)) * 16);                     // row + half, column l31
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(sbase) : "memory");
+            }
+            return true;
+        };
         // three register sets: chunk c lives in set c % 3 from its fetch (three steps before the consumers need it) to its staging
         u4 x0[XPT], x1[XPT], x2[XPT];
         unsigned ok0 = 0, ok1 = 0, ok2 = 0;
         float ps0[8], pb0[8], ps1[8], pb1[8], ps2[8], pb2[8];
+        weights_dma(0); stage_advance();                                     // chunk 0's weights
         issue(x0, ok0, ps0, pb0); advance();                                 // chunk 0
         issue(x1, ok1, ps1, pb1); advance();                                 // chunk 1
         issue(x2, ok2, ps2, pb2); advance();                                 // chunk 2
         stage(x0, ok0, ps0, pb0, smem);
         PC_STAMP(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                                     // barrier 0: chunk 0 and its weights are staged
         // step i (the consumers multiply chunk i from buffer i % 2): fetch chunk i + 3 -> set i % 3, stage chunk i + 1 (set (i + 1) % 3) ->
         // buffer (i + 1) % 2.  Period 6.  (Past the end of the walk a step stages stale registers into the buffer nobody reads.)
@@ -953,11 +990,14 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
         {                                                                                           \
             if (i >= T) break;                                                                      \
             PC_STAMP_P(1);                                                                          \
+            const bool wd_ = weights_dma(BUF);          /* chunk i + 1 -> slot (i + 1) % 2 */        \
+            stage_advance();                                                                        \
             issue(XL, OKL, PSL, PBL);                                                               \
             PC_STAMP_P(2);                                                                          \
             stage(XS, OKS, PSS, PBS, smem + (BUF) * C::XB);                                         \
             advance();                                                                              \
             PC_STAMP_P(3);                                                                          \
+            if (wd_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XPT + (PRO ? 4 : 0)) : "memory");     \
             __syncthreads();                                                                        \
             PC_STAMP_P(4);                                                                          \
             ++i;                                                                                    \
@@ -981,34 +1021,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
     const int ns = wave & 1, ph = wave >> 1;
     if (OFD_PC_PRIO) __builtin_amdgcn_s_setprio(OFD_PC_PRIO);      // the MFMA stream goes first; the producer wave of this SIMD fills its gaps
 
-    // ---- weights: chunk c of the walk lives in LDS slot c % 2, fragment-major [fragment (ks, kx, ky)][slice][lane][16 B].  The two
-    //      consumer waves of a slice fetch nine fragments each by LDS-DMA one chunk ahead (issued from inline asm: a DMA the compiler can
-    //      see makes it drain vmcnt in front of every LDS read of the MFMA loop); a slot that already holds the chunk is left alone (the
-    //      64 -> 64 layers: both chunks resident for the whole launch).
-    const int cin8 = P.Cin_total / 8;
-    const unsigned wlds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wlds;
-    int held0 = -1, held1 = -1;                        // (cy << 16 | kc) each slot holds
-    const unsigned w_lane = (unsigned)((half * P.Cout + 32 * ns + l31) * 16);      // this lane's 16 bytes of a fragment: row + half, column 32 ns + l31
-    auto weights_dma = [&](const int slot, const int cy_, const int kc) {
-        const int key = (cy_ << 16) | kc;
-        int& held = slot ? held1 : held0;
-        if (held == key) return;
-        held = key;
-#pragma unroll
-        for (int q = 0; q < FRAGS / 2; ++q) {
-            const int fi = ph * (FRAGS / 2) + q;
-            const int g = fi / 3, ky = fi - g * 3, ks = g / 3, kx = g - ks * 3;
-            const int row = (ky * 3 + kx) * cin8 + kc * NC + ks * 2;
-            const bf16_t* sbase = P.weight + ((size_t)row * P.Cout + cy_ * C::BN) * 8;              // (uniform)
-            const unsigned dst = wlds_addr + (unsigned)(((slot * FRAGS + fi) * 2 + ns) * 1024);       // (uniform)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(w_lane), "s"(sbase) : "memory");
-        }
-    };
-    auto weights_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-
     int ik = 0, b, oy0, ox0, cy;
     item_at(0, b, oy0, ox0, cy);                       // (T > 0: the first item is valid)
-    weights_dma(0, cy, 0);
 
     f32x16 biasv;                                     // register 4 g + k of an accumulator row = channel cb + 8 g + 4 half + k
     auto load_bias = [&](int cy_) {
@@ -1053,7 +1067,6 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
     };
 
     const int tiles8 = (P.H + 7) / 8;
-    weights_landed();
     __syncthreads();                                   // barrier 0: chunk 0 and its weights are staged
     int item_no = 0;
     (void)item_no;
@@ -1063,17 +1076,12 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
         const bool nvalid = item_at(ik + 1, nb, noy0, nox0, ncy);
         for (int kc = 0; kc < n32; kc += 2) {
             // (n32 is even: an item starts on slot / buffer 0)
-            weights_dma(1, cy, kc + 1);                // the next chunk's weights fly while this one is multiplied
             if (kc == 0) chunk(0, smem, std::true_type{}); else chunk(0, smem, std::false_type{});
             PC_STAMP_C(6);
-            weights_landed();
             __syncthreads();
             PC_STAMP_C(7);
-            if (kc + 2 < n32) weights_dma(0, cy, kc + 2);
-            else if (nvalid) weights_dma(0, ncy, 0);
             chunk(1, smem + C::XB, std::false_type{});
             PC_STAMP_C(8);
-            weights_landed();
             __syncthreads();
             PC_STAMP_C(9);
         }
