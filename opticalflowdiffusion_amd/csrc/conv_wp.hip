@@ -823,6 +823,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
 #if OFD_WP_STAMPS
     unsigned long long stamps[STAMP_SLOTS] = {};
     stamps[14] = __builtin_amdgcn_s_memrealtime();
+    stamps[12] = __builtin_amdgcn_s_memtime();
 #endif
 
     const int tiles_y = (P.H + C::ROWS - 1) / C::ROWS;
@@ -1068,6 +1069,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
 
     const int tiles8 = (P.H + 7) / 8;
     __syncthreads();                                   // barrier 0: chunk 0 and its weights are staged
+    PC_STAMP(11);
     int item_no = 0;
     (void)item_no;
     while (true) {
@@ -1093,6 +1095,37 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
         for (int i = 0; i < 8; ++i) stat[i] = 0.0f;
         const int oyb = oy0 + 8 * ph, ox = ox0 + l31, cb = cy * C::BN + 32 * ns;
         const bool okx = ox < P.W && !(P.dbg & 16);
+        // stores through a buffer descriptor of the sample's plane: scalar base and row offsets, one 32-bit lane offset (an offset past the
+        // end is dropped by the hardware, so a tile at the right / bottom edge needs no branch around its stores)
+        const size_t oplane_b = (size_t)P.H * P.W * P.Cout * 2;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(P.out + (size_t)b * P.H * P.W * P.Cout), 0, (int)oplane_b, 0x00020000);
+        const unsigned olane = (unsigned)(((min(oyb, P.H - 1) * P.W + min(ox, P.W - 1)) * P.Cout + cb + 8 * half) * 2);
+        const unsigned ostride_b = (unsigned)(P.W * P.Cout * 2);
+        const bool full = ox0 + TW <= P.W && oyb + 8 <= P.H && !(P.dbg & 16) && oplane_b < (1ull << 31);      // (uniform) every pixel of this wave's block is inside
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                uint2 q[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    q[g] = make_uint2(f2bf2(acc[r][4 * g], acc[r][4 * g + 1]), f2bf2(acc[r][4 * g + 2], acc[r][4 * g + 3]));
+                    if (P.gn_partial) {
+                        const bf16x2 one = __builtin_bit_cast(bf16x2, 0x3f803f80u);
+                        const bf16x2 va = __builtin_bit_cast(bf16x2, q[g].x), vb = __builtin_bit_cast(bf16x2, q[g].y);
+                        stat[g * 2] = __builtin_amdgcn_fdot2_f32_bf16(vb, one, __builtin_amdgcn_fdot2_f32_bf16(va, one, stat[g * 2], false), false);
+                        stat[g * 2 + 1] = __builtin_amdgcn_fdot2_f32_bf16(vb, vb, __builtin_amdgcn_fdot2_f32_bf16(va, va, stat[g * 2 + 1], false), false);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 1].x, false, false);
+                    const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 1].y, false, false);
+                    u4 pk = {rx[0], ry[0], rx[1], ry[1]};
+                    if (!(OFD_PC_ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, (int)olane, (int)(r * ostride_b + 16 * g), 0);
+                    else asm volatile("" :: "v"(pk));
+                }
+            }
+        } else {
         bf16_t* orow = P.out + (((size_t)b * P.H + min(oyb, P.H - 1)) * P.W + min(ox, P.W - 1)) * P.Cout + cb + 8 * half;
         const size_t ostride = (size_t)P.W * P.Cout;
 #pragma unroll
@@ -1118,6 +1151,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
             }
             orow += ostride;
         }
+        }
         if (P.gn_partial) {
             // layout of conv3x3_wp_kernel: [b][8-row tile][tile column][4 slots][Cout/8][2]; this wave's sums go to slot ns, every other
             // (slot, octet) of the workgroup's channel block is written as zero by the wave whose slot it is (slots ns, ns + 2)
@@ -1136,6 +1170,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
             }
         }
         PC_STAMP_C(10);
+#if OFD_WP_STAMPS
+        if (tid == 0 && item_no < 64) g_wp_stamps[65536 + blockIdx.x * 64 + item_no] = __builtin_amdgcn_s_memtime();      // item end times of wave 0
+#endif
         ++item_no;
         if (!nvalid) break;
         ++ik; b = nb; oy0 = noy0; ox0 = nox0;
@@ -1708,7 +1745,7 @@ int launch_conv3x3_wp(const ConvParams& P0, bool wide, hipStream_t s) {
     if (wide && wp16 && !P.residual && !P.residual_b && !P.res_act && !P.split && !P.pool2 && !P.out2)
         return P.in_scale ? wp::launch16<true>(P, s) : wp::launch16<false>(P, s);
     // producer / consumer form for the 64 -> 64 layers with plain / prologue / statistics epilogues (OFD_CONV_PC=0: off)
-    static const int pc = getenv("OFD_CONV_PC") ? atoi(getenv("OFD_CONV_PC")) : 1;
+    const int pc = getenv("OFD_CONV_PC") ? atoi(getenv("OFD_CONV_PC")) : 1;          // (read per call: the tests compare the two kernels in one process)
     if (!wide && pc && wp::pc_serves(P)) {
         const int r = P.in_scale ? wp::launch_pc<true>(P, s) : wp::launch_pc<false>(P, s);
         if (r != 1) return r;

@@ -116,6 +116,57 @@ def test_conv3x3_plain_and_ws(L, B, H, W, Cin, Cout):
         assert torch.allclose(p[..., 1], (oc * oc).sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("B,H,W,cins,Cout,pro,up", [(2, 37, 70, (64,), 64, True, False), (1, 48, 96, (64, 64), 64, False, False), (2, 16, 64, (128,), 64, False, True),
+                                                   (1, 24, 40, (64, 128), 128, True, False), (3, 16, 32, (64,), 192, False, False), (1, 200, 352, (64,), 64, True, False)])
+def test_conv3x3_producer_consumer_kernel_forms(L, B, H, W, cins, Cout, pro, up):
+    """conv3x3_pc_kernel (conv_wp.hip, r04: the 64-channel-block 3x3 as a persistent producer / consumer workgroup) over the forms it serves:
+    one or two concatenated sources, a nearest-x2 source, the GroupNorm + SiLU prologue, several channel blocks per pixel tile (Cout 128 /
+    192 on grids too small for the 128-channel-block kernel), partial tiles on both axes, more tiles than workgroups (200 x 352: every
+    workgroup walks several items).  Against F.conv2d on the bf16-rounded operands AND against conv3x3_wp_kernel<2,2> (OFD_CONV_PC=0) on the
+    same inputs: values within the per-op tolerance, GroupNorm partial sums within 1e-4 of each other per (sample, 8-channel group)."""
+    import os
+    torch.manual_seed(17 + H)
+    srcs, xs = [], []
+    for c in cins:
+        hs, ws = (H // 2, W // 2) if up else (H, W)
+        x = q(torch.randn(B, c, hs, ws))
+        xs.append(F.interpolate(x, scale_factor=2, mode="nearest") if up else x)
+        srcs.append(dict(t=to_nhwc(x), upsample=1 if up else 0))
+    xcat = torch.cat(xs, 1)
+    Cin = xcat.shape[1]
+    w = torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout) * 0.1
+    a = s_ = None
+    xin = xcat
+    if pro:
+        a, s_ = torch.rand(B, Cin) + 0.5, torch.randn(B, Cin) * 0.3
+        xin = q(F.silu(xcat * a[:, :, None, None] + s_[:, :, None, None]))
+    ref = F.conv2d(xin, q(w), b, padding=1)
+    wprep = prep_weight(L, w, 3)
+    outs = {}
+    old = os.environ.get("OFD_CONV_PC")
+    try:
+        for pc in ("1", "0"):
+            os.environ["OFD_CONV_PC"] = pc
+            outs[pc] = run_conv(L, B, H, W, 3, srcs, Cout, wprep, bias=b, in_scale=a, in_shift=s_, want_gn=True)
+    finally:
+        if old is None:
+            os.environ.pop("OFD_CONV_PC", None)
+        else:
+            os.environ["OFD_CONV_PC"] = old
+    tol = 2e-3 if pro else PER_OP_TOL
+    for pc in ("1", "0"):
+        check_close(from_nhwc(outs[pc][0]), ref, tol=tol, what=f"OFD_CONV_PC={pc}")
+    assert rel_l2(from_nhwc(outs["1"][0]), from_nhwc(outs["0"][0])) < 2e-3
+    tiles = math.ceil(H / 8) * math.ceil(W / 32)
+    p1 = outs["1"][1].cpu().reshape(B, tiles * 4, Cout // 8, 2).sum(1)
+    p0 = outs["0"][1].cpu().reshape(B, tiles * 4, Cout // 8, 2).sum(1)
+    o = from_nhwc(outs["1"][0]).reshape(B, Cout // 8, 8, H, W)
+    assert torch.allclose(p1[..., 0], o.sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(p1[..., 1], (o * o).sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(p1, p0, rtol=2e-2, atol=0.5)           # (two kernels, two bf16 roundings of nearly equal sums)
+
+
 def test_conv3x3_concat_prologue_upsample_epilogues(L):
     torch.manual_seed(1)
     B, H, W = 2, 16, 32

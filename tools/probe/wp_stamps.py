@@ -57,6 +57,17 @@ if os.environ.get("OFD_CONV_PC", "1") != "0" and cout == 64:
            "consumer_item_cycles": {"chunk 0 issued": med(cons[:, 6] - cons[:, 5]), "barrier": med(cons[:, 7] - cons[:, 6]), "chunk 1 issued": med(cons[:, 8] - cons[:, 7]),
                                     "barrier ": med(cons[:, 9] - cons[:, 8]), "epilogue": med(cons[:, 10] - cons[:, 9]), "item": med(cons[:, 10] - cons[:, 5])},
            "wave_life_cycles": med(s[:, :, 15].reshape(-1) - s[:, :, 14].reshape(-1)) * 20.0}
+    it = buf[65536:65536 + 256 * 64].reshape(256, 64).astype(np.int64)
+    t0 = s[:, 0, 14] * 0 + it[:, :1]                      # first item end as the origin of a workgroup's walk
+    n_it = int((it[0] > 0).sum())
+    if n_it > 2:
+        d_it = np.diff(it[:, :n_it], axis=1)              # cycles per item, per workgroup
+        res["item_cycles_by_index_median"] = [float(np.median(d_it[:, k])) for k in range(0, n_it - 1, max(1, (n_it - 1) // 14))]
+        res["items"] = n_it
+        c0 = s[:, 0, :]                                   # consumer wave 0 of every workgroup
+        res["startup_cycles_median"] = {"kernel entry -> barrier 0 passed": float(np.median(c0[:, 11] - c0[:, 12])), "kernel entry -> first item done": float(np.median(it[:, 0] - c0[:, 12])),
+                                         "last item done -> wave exit (x clock ratio)": None}
+        res["walk_cycles_median"] = float(np.median(it[:, n_it - 1] - c0[:, 12]))
     print(json.dumps(res))
     sys.exit(0)
 raw = ctypes.CDLL(L.LIB_PATH)
