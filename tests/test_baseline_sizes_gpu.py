@@ -118,3 +118,55 @@ def test_c3_ddim_50_steps_bs64_and_splat_reconstruction():
     assert rec.shape == (B, 3, H, W) and bool(torch.isfinite(rec[~holes]).all())
     assert bool((holes.all(dim=1) == holes.any(dim=1)).all())                           # a hole is a hole in every channel (WP:154)
     assert float(holes.float().mean()) < 0.5
+
+
+@pytest.mark.parametrize("cin,pro", [(64, True), (64, False), (128, False)])
+def test_full_size_3x3_producer_consumer_kernel_against_the_wave_private_kernel(cin, pro):
+    """The 64-channel-block 3x3 layers of the benchmark shape (16 x 440 x 1024: every persistent workgroup of conv3x3_pc_kernel walks 56 tiles,
+    chunk stream across tile and sample seams, the last tile row half empty) against conv3x3_wp_kernel<2,2> (OFD_CONV_PC=0) on the same
+    inputs: two kernels, one operation -- values within the per-op tolerance of each other, GroupNorm partial sums equal per (sample, group)
+    to 1e-3, and the sums equal to those of the values as stored."""
+    import ctypes, math, os
+    from opticalflowdiffusion_amd import _lib as L
+    lib = L.lib()
+    B, Cout = 16, 64
+    g = torch.Generator(device="cuda").manual_seed(5 + cin)
+    x = torch.randn(B, H, W, cin, device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn(Cout, cin, 3, 3, device="cuda", generator=g) / math.sqrt(cin * 9)
+    wp = torch.empty(lib.ofd_conv_weight_elems(Cout, cin, 3), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.ofd_conv_weight_prep(L.ptr(w), L.ptr(wp), Cout, cin, cin, 3, -1.0, 0, L.stream()))
+    bias = torch.randn(Cout, device="cuda", generator=g) * 0.1
+    sc = torch.rand(B, cin, device="cuda", generator=g) + 0.5
+    sh = torch.randn(B, cin, device="cuda", generator=g) * 0.3
+    outs = {}
+    old = os.environ.get("OFD_CONV_PC")
+    try:
+        for pc in ("1", "0"):
+            os.environ["OFD_CONV_PC"] = pc
+            out = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device="cuda")
+            gn = torch.full((lib.ofd_conv_gn_partial_count(B, H, W, Cout),), float("nan"), device="cuda")
+            a = L.ConvArgs()
+            a.B, a.H, a.W, a.ksize, a.n_src, a.Cout = B, H, W, 3, 1, Cout
+            a.src[0].src = x.data_ptr(); a.src[0].channels = cin; a.src[0].src_channels = cin
+            a.weight = wp.data_ptr(); a.bias = bias.data_ptr(); a.out = out.data_ptr(); a.gn_partial = gn.data_ptr()
+            if pro:
+                a.in_scale = sc.data_ptr(); a.in_shift = sh.data_ptr()
+            L.check(lib.ofd_conv_forward(ctypes.byref(a), L.stream()))
+            torch.cuda.synchronize()
+            outs[pc] = (out.float(), gn)
+    finally:
+        if old is None:
+            os.environ.pop("OFD_CONV_PC", None)
+        else:
+            os.environ["OFD_CONV_PC"] = old
+    o1, o0 = outs["1"][0], outs["0"][0]
+    assert bool(torch.isfinite(o1).all())
+    assert float((o1 - o0).norm() / o0.norm()) < 2e-3
+    tiles = math.ceil(H / 8) * math.ceil(W / 32)
+    p1 = outs["1"][1].reshape(B, tiles * 4, Cout // 8, 2).sum(1)
+    p0 = outs["0"][1].reshape(B, tiles * 4, Cout // 8, 2).sum(1)
+    assert bool(torch.isfinite(p1).all())
+    assert torch.allclose(p1, p0, rtol=1e-3, atol=2.0)
+    oc = o1.reshape(B, H, W, Cout // 8, 8)
+    assert torch.allclose(p1[..., 0], oc.sum(dim=(1, 2, 4)), rtol=1e-4, atol=1.0)
+    assert torch.allclose(p1[..., 1], (oc * oc).sum(dim=(1, 2, 4)), rtol=1e-4, atol=1.0)
