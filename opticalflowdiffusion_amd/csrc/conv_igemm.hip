@@ -1115,6 +1115,7 @@ int launch_conv3x3_c64_rw(const ConvParams& P, hipStream_t s);     // conv_rw.hi
 int launch_conv3x3_wp(const ConvParams& P, bool wide, hipStream_t s);   // conv_wp.hip
 int launch_conv1x1_wp(const ConvParams& P, hipStream_t s);              // conv1_wp.hip: 1 = shape not served
 int launch_conv_up2_phases_wp(const ConvParams& P, hipStream_t s);      // conv_wp.hip: 1 = shape not served
+int launch_conv7x7_c8_persist(const ConvParams& P, hipStream_t s);      // conv7.hip: 1 = shape not served
 
 static int conv_wp_bits() {
     static int use_wp = -1;
@@ -1258,6 +1259,10 @@ int conv_forward_impl(const ofd_conv_args* a, hipStream_t s, int cout0, int pool
         if (r != 1) return r;
     }
     if (a->ksize == 2) return wide ? launch_conv<2, 128>(P, s) : launch_conv<2, 64>(P, s);
+    if (k7p) {                                           // weights resident in LDS, a workgroup walks many tiles (conv7.hip): OFD_CONV7_PERSIST=0 switches it off
+        const int r = launch_conv7x7_c8_persist(P, s);
+        if (r != 1) return r;
+    }
     return k7p ? launch_conv<8, 64>(P, s) : launch_conv<7, 64>(P, s);
 }
 

@@ -915,7 +915,7 @@ const char* prof_class_name(int cls) {
         names[PC_CONV3_64] = std::string((wp & 2) ? (pc ? "conv3x3_pc_kernel" : "conv3x3_wp_kernel<2,2>") : "conv_igemm_kernel<3,64>") + " [3x3, Cin > 64 -> 64]";
         names[PC_CONV3_PP] = std::string((wp & 4) ? (pc ? "conv3x3_pc_kernel" : "conv3x3_wp_kernel<2,2>") : "conv3x3_c64_pingpong_kernel") + " [3x3, 64 -> 64]";
         names[PC_CONV1] = "conv1x1_wp_kernel | conv_igemm_kernel<1,BN> [1x1]";
-        names[PC_CONV7] = "conv_igemm_kernel<8,64>|<7,64> [7x7 init conv]";
+        names[PC_CONV7] = std::string(env("OFD_CONV7_PERSIST", 1) ? "conv7x7_c8_persist_kernel" : "conv_igemm_kernel<8,64>") + " [7x7 init conv]";
         names[PC_GN] = "gn_finalize";
         names[PC_RESOUT] = "resblock_out";
         names[PC_LN] = "layernorm_c";

@@ -291,6 +291,38 @@ def test_conv7x7_init(L, Cin):
         assert float((out8.float() - out.float()).abs().max()) <= 2.0 ** -7 * float(out.float().abs().max())
 
 
+@pytest.mark.parametrize("B,H,W,bias", [(2, 24, 40, True), (1, 37, 70, False), (3, 8, 32, True), (2, 200, 352, True), (1, 440, 1024, True)])
+def test_conv7x7_persistent_kernel_against_the_generic_kernel(L, B, H, W, bias):
+    """conv7x7_c8_persist_kernel (conv7.hip: the 8-channel 7x7 with the weights resident in LDS, a workgroup walking many tiles) against
+    F.conv2d on the bf16-rounded operands and against the generic kernel (OFD_CONV7_PERSIST=0) on the same inputs: partial tiles on both
+    axes, a single tile row, fewer tiles than workgroups (every workgroup one tile) and many tiles per workgroup (200 x 352, 440 x 1024:
+    both LDS input buffers and the XCD-ordered walk in use)."""
+    import os
+    torch.manual_seed(5 + H)
+    x = q(torch.randn(B, 5, H, W))
+    w = torch.randn(64, 5, 7, 7) / math.sqrt(5 * 49)
+    b = torch.randn(64) * 0.1 if bias else None
+    ref = F.conv2d(x, q(w), b, padding=3)
+    xp = torch.zeros(B, 8, H, W)
+    xp[:, :5] = x
+    wprep = prep_weight(L, w, 7, cin_pad=8)
+    outs = {}
+    old = os.environ.get("OFD_CONV7_PERSIST")
+    try:
+        for sw in ("1", "0"):
+            os.environ["OFD_CONV7_PERSIST"] = sw
+            outs[sw] = run_conv(L, B, H, W, 7, [dict(t=to_nhwc(xp))], 64, wprep, bias=b)[0]
+    finally:
+        if old is None:
+            os.environ.pop("OFD_CONV7_PERSIST", None)
+        else:
+            os.environ["OFD_CONV7_PERSIST"] = old
+    for sw in ("1", "0"):
+        check_close(from_nhwc(outs[sw]), ref, what=f"OFD_CONV7_PERSIST={sw}")
+    # same products, the bias added before instead of after the accumulation: at most one bf16 ulp apart
+    assert float((outs["1"].float() - outs["0"].float()).abs().max()) <= 2.0 ** -7 * float(outs["0"].float().abs().max())
+
+
 # ------------------------------------------------------------------------------- whole forward
 def default_init_params(ch, seed=0):
     g = torch.Generator().manual_seed(seed)
