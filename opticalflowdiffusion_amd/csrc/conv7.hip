@@ -3,12 +3,17 @@
 // The generic kernel (conv_igemm.hip, Cfg<8, 64>) runs one 8x32-pixel tile per workgroup and re-streams the 57 KB of weights
 // through a double-buffered LDS slab per tile: 28,160 tiles x 57 KB of L2 -> LDS traffic and 8 workgroup barriers per tile for
 // 112 MFMAs per wave.  Here the weights stay in LDS for the whole launch (all 7 kernel rows x 8 tap columns x 8 channels x 64
-// outputs = 57,344 B) and a workgroup walks many tiles:
-//   * the input tile (+halo: 14 x 39 pixels x 16 B = 8.7 KB) is double buffered; the global loads of tile i + 1 are issued
-//     before the MFMAs of tile i and written to the other buffer after tile i's epilogue -- ONE barrier per tile;
-//   * no barrier inside a tile: every operand address is a compile-time offset from two base registers;
-//   * two workgroups per CU (74.8 KB LDS each): one's epilogue (the 0.92 GB output stream at full resolution) overlaps the
-//     other's MFMAs.
+// outputs = 57,344 B), a workgroup walks many tiles, and its four waves never meet after the weights are in:
+//   * a wave owns two output rows x 32 pixels of the tile and keeps ITS OWN input image (8 rows x 39 pixels x 16 B = 5 KB) in a
+//     private LDS region: the global loads of the next tile's image are issued before the MFMAs of this tile and written after the
+//     epilogue -- LDS operations of one wave execute in order, so no barrier and no second buffer;
+//   * every operand address of the 28 k-steps is a compile-time offset from two base registers, the operands of step s + 1 are
+//     read before the MFMAs of step s;
+//   * the epilogue transposes an output row (32 pixels x 64 channels) through the same private region (dead once the MFMAs have
+//     read it): consecutive lanes then store consecutive 16-byte units, 1 KB contiguous per instruction.  The accumulator layout
+//     stores 32 bytes per pixel and instruction, a pattern this 0.92 GB output stream runs at 3.2 TB/s with (the no-MFMA
+//     ablation of the first version: profiles/r04_conv7_persist_ablations.txt);
+//   * two workgroups per CU (77.8 KB LDS each).
 // Same tap-pair packing, operand images and MFMA order as the generic kernel; the bias is the accumulator's initial value instead of
 // an add after the last MFMA (one fp32 rounding apart before the rounding to bf16).
 #include <cstdlib>
@@ -27,12 +32,15 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int TH = 8, TW = 32, NTHREADS = 256;
-constexpr int IH = TH + 6, IW = TW + 6 + 1, NPIX = IH * IW;       // 14 x 39: the 8th tap column reads one pixel further right (zero weights)
-constexpr int XB = (NPIX + 1) * 16;                               // 8,752 B per input tile image: [pixel][8 channels]
+constexpr int IW = TW + 6 + 1;                                    // 39: the 8th tap column reads one pixel further right (zero weights)
+constexpr int WR = 8, WPIX = WR * IW;                             // input rows / pixels behind a wave's two output rows
+constexpr int OPITCH = 64 * 2 + 16;                               // transposition pitch of a pixel: conflict-free 16-byte writes
+constexpr int WXB = 5120;                                         // a wave's region: input image (4,992 B) | one transposed output row (4,608 B)
 constexpr int W_SLAB = 8 * 64 * 16;                               // one kernel row: 8 (tap column) rows x 64 outputs x 16 B
 constexpr int W_ALL = 7 * W_SLAB;                                 // 57,344 B
-constexpr int LDS_BYTES = W_ALL + 2 * XB;                         // 74,848 B
-constexpr int XPT = (NPIX + NTHREADS - 1) / NTHREADS;             // 3
+constexpr int LDS_BYTES = W_ALL + 4 * WXB;                        // 77,824 B
+constexpr int XPT = (WPIX + 63) / 64;                             // 5
+static_assert(WPIX * 16 <= WXB && 32 * OPITCH <= WXB, "a wave's LDS region");
 
 struct Tile { int b, oy0, ox0; };
 
@@ -43,22 +51,23 @@ __device__ __forceinline__ Tile tile_of(int v, int ntiles, int tiles_x, int tpi)
         const int q = ntiles / 8, r = ntiles % 8, xcd = v % 8, idx = v / 8;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    tile = min(tile, ntiles - 1);                                  // (past the end: a valid tile that is loaded, never stored)
+    tile = min(tile, ntiles - 1);                                  // (past the end: a valid tile, never loaded or stored)
     const int b = tile / tpi, t_in = tile - b * tpi;
     return {b, (t_in / tiles_x) * TH, (t_in % tiles_x) * TW};
 }
 
 struct XRegs { uint4 v[XPT]; unsigned ok; };
 
-__device__ __forceinline__ void load_x(XRegs& x, const ConvParams& P, const Tile& t, int tid) {
+// input rows [oy0 + 2 wave - 3, + 8) x columns [ox0 - 3, + 39) of the wave's strip: unit u = row * 39 + column, lane + 64 i
+__device__ __forceinline__ void load_x(XRegs& x, const ConvParams& P, const Tile& t, int wave, int lane) {
     const ConvSrcDev& S = P.src[0];
     const bf16_t* base = S.ptr + (size_t)t.b * P.H * P.W * S.src_channels + S.ch_offset;
     x.ok = 0;
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
-        const int p = min(tid + i * NTHREADS, NPIX - 1);
-        const int ty = p / IW, tx = p - ty * IW;
-        const int iy = t.oy0 - 3 + ty, ix = t.ox0 - 3 + tx;
+        const int u = min(lane + i * 64, WPIX - 1);
+        const int ty = u / IW, tx = u - ty * IW;
+        const int iy = t.oy0 + 2 * wave - 3 + ty, ix = t.ox0 - 3 + tx;
         const bool ok = iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
         x.ok |= (ok ? 1u : 0u) << i;
         const int cy = min(max(iy, 0), P.H - 1), cx = min(max(ix, 0), P.W - 1);
@@ -66,29 +75,22 @@ __device__ __forceinline__ void load_x(XRegs& x, const ConvParams& P, const Tile
     }
 }
 
-__device__ __forceinline__ void write_x(const XRegs& x, unsigned char* xbuf, int tid) {
+__device__ __forceinline__ void write_x(const XRegs& x, unsigned char* xw, int lane) {
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
-        const int p = min(tid + i * NTHREADS, NPIX - 1);           // (the surplus threads rewrite the last pixel with identical bytes)
+        const int u = min(lane + i * 64, WPIX - 1);                // (the surplus lanes rewrite the last pixel with identical bytes)
         const bool ok = (x.ok >> i) & 1u;
         uint4 v = x.v[i];
         v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-        *(uint4*)(xbuf + p * 16) = v;
+        *(uint4*)(xw + u * 16) = v;
     }
-}
-
-// only LDS traffic has to be complete at the barrier: the epilogue's stores and the prefetch of the next tile stay in flight
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
 }
 
 __global__ void __launch_bounds__(NTHREADS, 2) conv7x7_c8_persist_kernel(const ConvParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const lds_w = smem;
-    unsigned char* const lds_x = smem + W_ALL;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, half = lane >> 5;
+    unsigned char* const xw = smem + W_ALL + wave * WXB;
     const int tpi = P.tiles_x * P.tiles_y, ntiles = tpi * P.B;
     const int n_iter = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 
@@ -109,19 +111,18 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv7x7_c8_persist_kernel(const C
 
     XRegs xr;
     Tile cur = tile_of((int)blockIdx.x, ntiles, P.tiles_x, tpi);
-    load_x(xr, P, cur, tid);
-    write_x(xr, lds_x, tid);
-    __syncthreads();
+    load_x(xr, P, cur, wave, lane);
+    write_x(xr, xw, lane);
+    __syncthreads();                                              // the weights are in: the only workgroup barrier of the kernel
 
-    // a lane's two operand bases: its pixel column (+ the half-wave's tap of the pair) in rows 2*wave, 2*wave+1 of the tile; its
-    // weight row (half) and output column l31
-    const int xoff = half * 16 + (wave * 2 * IW + l31) * 16;
+    // a lane's two operand bases: its pixel column (+ the half-wave's tap of the pair) in the wave's image; its weight row (half) and
+    // output column l31
+    const unsigned char* const xrow = xw + (half + l31) * 16;
     const unsigned char* const wrow = lds_w + (half * 64 + l31) * 16;
 
     for (int it = 0; it < n_iter; ++it) {
-        const unsigned char* const xrow = lds_x + (it & 1) * XB + xoff;
         const Tile nxt = tile_of((int)blockIdx.x + (it + 1) * (int)gridDim.x, ntiles, P.tiles_x, tpi);
-        if (it + 1 < n_iter && !(OFD_C7_ABL & 4)) load_x(xr, P, nxt, tid);
+        if (it + 1 < n_iter && !(OFD_C7_ABL & 4)) load_x(xr, P, nxt, wave, lane);
 
         f32x16 acc[2][2];
 #pragma unroll
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv7x7_c8_persist_kernel(const C
             for (int pt = 0; pt < 2; ++pt) acc[nt][pt] = biasv[nt];
 
         // 28 k-steps (7 kernel rows x 4 tap pairs), operands of step s + 1 read before the MFMAs of step s.  The pixel operand of (row ky,
-        // output row pt = 1) is the one of (ky + 1, pt = 0): a tile row is read once and kept for the next kernel row.
+        // output row pt = 1) is the one of (ky + 1, pt = 0): an image row is read once and kept for the next kernel row.
         auto rdx = [&](int r, int ks) { return *(const bf16x8*)(xrow + (r * IW + 2 * ks) * 16); };
         auto rdw = [&](int ky, int ks, int nt) { return *(const bf16x8*)(wrow + ky * W_SLAB + (ks * 2 * 64 + nt * 32) * 16); };
         bf16x8 xkeep[2][4], wf[2][2], xn[2];
@@ -158,12 +159,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv7x7_c8_persist_kernel(const C
         }
         __builtin_amdgcn_s_setprio(0);
 
-        // ---- epilogue: bf16, 16-byte stores (one v_permlane32_swap per dword pairs the register quads g, g + 1 of the two half-waves)
+        // ---- epilogue, one output row (pt) at a time: bf16, a lane's 16-byte units (one v_permlane32_swap per dword pairs the register
+        // quads g, g + 1 of the two half-waves) into the wave's region at [pixel][channel], read back with unit (lane & 7) of pixel
+        // (lane >> 3) + 8 k per lane: 8 pixels = 1 KB contiguous per store instruction
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-            const int oy = cur.oy0 + wave * 2 + pt, ox = cur.ox0 + l31;
-            const bool ok = oy < P.H && ox < P.W;
-            bf16_t* const orow = P.out + (((size_t)cur.b * P.H + min(oy, P.H - 1)) * P.W + min(ox, P.W - 1)) * 64 + 8 * half;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -173,14 +173,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv7x7_c8_persist_kernel(const C
                     const uint32_t q1x = f2bf2(a[4 * g + 4], a[4 * g + 5]), q1y = f2bf2(a[4 * g + 6], a[4 * g + 7]);
                     const auto rx = __builtin_amdgcn_permlane32_swap(q0x, q1x, false, false);
                     const auto ry = __builtin_amdgcn_permlane32_swap(q0y, q1y, false, false);
-                    if (OFD_C7_ABL & 2) asm volatile("" ::"v"(rx[0]), "v"(ry[0]), "v"(rx[1]), "v"(ry[1]));
-                    else if (ok) *(uint4*)(orow + nt * 32 + 8 * g) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                    *(uint4*)(xw + l31 * OPITCH + (nt * 32 + 8 * g + 8 * half) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
                 }
+            const int oy = cur.oy0 + wave * 2 + pt;
+            bf16_t* const orow = P.out + (((size_t)cur.b * P.H + min(oy, P.H - 1)) * P.W + cur.ox0) * 64;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pl = (lane >> 3) + 8 * k, cu = lane & 7;
+                const uint4 v = *(const uint4*)(xw + pl * OPITCH + cu * 16);
+                if (OFD_C7_ABL & 2) asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                else if (oy < P.H && cur.ox0 + pl < P.W) *(uint4*)(orow + pl * 64 + cu * 8) = v;
+            }
         }
 
-        // ---- the next tile's input -> the other buffer (every wave finished reading it before the previous barrier)
-        if (it + 1 < n_iter) write_x(xr, lds_x + ((it + 1) & 1) * XB, tid);
-        lds_barrier();
+        // ---- the next tile's image (LDS operations of a wave execute in order: the reads above are done with the region)
+        if (it + 1 < n_iter) write_x(xr, xw, lane);
         cur = nxt;
     }
 }
