@@ -246,8 +246,9 @@ typedef struct {
     const float* res_scale;
     const float* res_shift;
     void* out;              /* bf16 NHWC (B,H,W,Cout) */
-    float* gn_partial;      /* optional: GroupNorm partial sums [b][tile][wave][Cout/8][2] (sum, sum of squares of
-                               the stored values), ofd_conv_gn_partial_count floats */
+    float* gn_partial;      /* optional: GroupNorm partial sums [b][8 groups][8x32 tile][4 wave slots][Cout/64][2] (sum, sum
+                               of squares of the stored values; group-major so that ofd_gn_finalize reads one contiguous
+                               run per (sample, group)), ofd_conv_gn_partial_count floats */
     void* out2;             /* split output (data gradients of a conv over two concatenated sources): channels */
     const void* residual2;  /*   [0, split) -> out / residual with pixel stride split, [split, Cout) -> out2 / residual2 */
     int split;              /*   with stride Cout - split; multiple of 64, 0 = off */

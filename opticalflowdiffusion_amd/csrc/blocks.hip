@@ -92,28 +92,25 @@ __global__ void __launch_bounds__(256) block_mlp_kernel(const float* __restrict_
 }
 
 // ---- GroupNorm(8) statistics -> per-(sample, channel) affine (DD:181-185) -------------------------
-// partial: [B][tiles*4 waves][C/8][2] from the conv epilogue.  y = x*a + s with
+// partial: [B][8 groups][slots = tiles * 4 waves][C/64][2] from the conv epilogue (gn_partial_index, conv_params.h).  y = x*a + s with
 //   a = gamma*rstd*(scale+1), s = (beta - mean*rstd*gamma)*(scale+1) + shift.   grid (B, 8)
-constexpr int GNF_NT = 1024;      // threads per (sample, group): the 7040 entries of a full-resolution group are one round of 8 loads per thread (256 threads: four dependent rounds, 9 us)
+constexpr int GNF_NT = 1024;      // threads per (sample, group): the 7040 entries of a full-resolution group are one round of loads
 __global__ void __launch_bounds__(GNF_NT) gn_finalize_kernel(const float* __restrict__ partial, int tiles, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ ss, int ss_stride, int ss_offset,
                                                           float* __restrict__ a_out, float* __restrict__ s_out, float* __restrict__ stats_out) {
     const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
-    const int gs = C / 8, octs = gs / 8, noct = C / 8;
-    // the entries of one group are 8 bytes every C/8 * 8 bytes: a latency chain if walked one load at a time (13 us per launch at full
-    // resolution, 38 launches per step) -- GU independent loads per thread are in flight together
+    const int gs = C / 8, octs = gs / 8;
+    // the (sum, sum of squares) pairs of this (sample, group) are one contiguous run; GU independent loads per thread are in flight together
+    // (walked one load at a time the run is a latency chain)
     constexpr int GU = 8;
     double s1 = 0.0, s2 = 0.0;
     const int total = tiles * octs;
+    const float2* run = (const float2*)partial + ((size_t)b * 8 + g) * total;
     for (int i0 = tid; i0 < total; i0 += GNF_NT * GU) {
         float2 v[GU];
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const int i = min(i0 + u * GNF_NT, total - 1);
-            const int tile = i / octs, o = g * octs + i % octs;
-            v[u] = *(const float2*)(partial + (((size_t)b * tiles + tile) * noct + o) * 2);
-        }
+        for (int u = 0; u < GU; ++u) v[u] = run[min(i0 + u * GNF_NT, total - 1)];
 #pragma unroll
         for (int u = 0; u < GU; ++u)
             if (i0 + u * GNF_NT < total) { s1 += (double)v[u].x; s2 += (double)v[u].y; }

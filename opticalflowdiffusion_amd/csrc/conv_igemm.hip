@@ -443,12 +443,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_igemm_kernel(const ConvParam
             if (ok) *(uint4*)(o_base + opix * o_stride + c0 - (second ? P.split : 0)) = v;
         }
     }
-    if (P.gn_partial) {   // per-wave partial sums: [b][tile][wave][Cout/8][2]; gn_finalize adds them up
+    if (P.gn_partial) {   // per-wave partial sums, slot (tile, wave) of the layout at gn_partial_index (conv_params.h); gn_finalize adds them up
         wave_reduce_multi<NV>(stat);
-        constexpr int SH_ = (NV == 32) ? 1 : 2;    // lane l holds value index l >> SH_
+        constexpr int SH_ = (NV == 32) ? 1 : 2;    // lane l holds value index l >> SH_ = (octet of the channel block) * 2 + (sum | sum of squares)
         if ((lane & ((1 << SH_) - 1)) == 0) {
-            const size_t base = (((size_t)b * (P.tiles_x * P.tiles_y) + t_in) * 4 + wave) * (P.Cout / 8) * 2;
-            P.gn_partial[base + (n0 / 8) * 2 + (lane >> SH_)] = stat[0];
+            const int vi = lane >> SH_;
+            P.gn_partial[gn_partial_index(b, P.tiles_x * P.tiles_y * 4, t_in * 4 + wave, P.Cout / 8, n0 / 8 + (vi >> 1)) + (vi & 1)] = stat[0];
         }
     }
 }
@@ -642,8 +642,8 @@ __device__ __forceinline__ void pp_epilogue(const f32x16 (&acc)[2][2], const Con
     if (P.gn_partial) {
         wave_reduce_multi<16>(stat);
         if ((lane & 3) == 0) {
-            const size_t base = (((size_t)T.b * (P.tiles_x * P.tiles_y) + T.t_in) * 4 + wv) * 16;
-            P.gn_partial[base + (lane >> 2)] = stat[0];
+            const int vi = lane >> 2;
+            P.gn_partial[gn_partial_index(T.b, P.tiles_x * P.tiles_y * 4, T.t_in * 4 + wv, 8, vi >> 1) + (vi & 1)] = stat[0];
         }
     }
 }
@@ -915,8 +915,8 @@ __device__ __forceinline__ void conv_tile_epilogue(const f32x16 (&acc)[BN / 32][
         wave_reduce_multi<NV>(stat);
         constexpr int SH_ = (NV == 32) ? 1 : 2;
         if ((lane & ((1 << SH_) - 1)) == 0) {
-            const size_t base = (((size_t)T.b * (P.tiles_x * P.tiles_y) + T.t_in) * 4 + wv) * (P.Cout / 8) * 2;
-            P.gn_partial[base + (n0 / 8) * 2 + (lane >> SH_)] = stat[0];
+            const int vi = lane >> SH_;
+            P.gn_partial[gn_partial_index(T.b, P.tiles_x * P.tiles_y * 4, T.t_in * 4 + wv, P.Cout / 8, n0 / 8 + (vi >> 1)) + (vi & 1)] = stat[0];
         }
     }
 }
@@ -1276,7 +1276,7 @@ extern "C" int ofd_conv_forward_pool2(const ofd_conv_args* a, void* stream) {
 }
 
 extern "C" size_t ofd_conv_gn_partial_count(int B, int H, int W, int Cout) {
-    return (size_t)B * cdiv(H, TH) * cdiv(W, TW) * 4 * (Cout / 8) * 2;     // [b][tile][wave][Cout/8][2]
+    return (size_t)B * cdiv(H, TH) * cdiv(W, TW) * 4 * (Cout / 8) * 2;     // [b][8 groups][tile][wave slot][Cout/64][2] (gn_partial_index)
 }
 
 extern "C" size_t ofd_conv_weight_elems(int Cout, int Cin_pad, int ksize) {

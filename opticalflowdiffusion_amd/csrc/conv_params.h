@@ -50,4 +50,15 @@ struct ConvParams {
     int dbg;            // diagnostic ablation bits (OFD_CONV_DBG), 0 in production
 };
 
+// GroupNorm partial sums written by the conv epilogues and added up by gn_finalize (blocks.hip), GROUP-major:
+//     [b][group 0..7][slot][octet within the group: Cout / 64 of them][sum, sum of squares]
+// slot = (8-row tile * tiles_x + tile column) * 4 + wave slot, `slots` of them per sample; noct = Cout / 8 octets (8-channel units), oct the
+// octet's index in the tensor.  One (sample, group) is one contiguous run, so its gn_finalize workgroup reads its own bytes only (with the
+// octet-major [b][slot][Cout/8][2] every one of a sample's 8 workgroups pulled every 64-byte line of the tensor: 17 us per launch at
+// 1 x 1080 x 1920, 38 launches per UNet forward).
+__host__ __device__ __forceinline__ size_t gn_partial_index(int b, int slots, int slot, int noct, int oct) {
+    const int octs = noct >> 3, g = oct / octs;
+    return ((((size_t)b * 8 + g) * slots + slot) * octs + (oct - g * octs)) * 2;
+}
+
 }  // namespace ofd

@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(RW_THREADS, 1) conv3x3_c64_rw_kernel(const Con
         }
         const int ty8 = ty16 * 2 + (rg >> 1);
         if (P.gn_partial && ty8 < P.tiles_y) {       // [b][8-row tile][wave slot][8 octets][2]: this wave's four octets, zeros for the other half
-            float* gp = P.gn_partial + (((size_t)b * tpi8 + (size_t)ty8 * P.tiles_x + txi) * 4 + (rg & 1) * 2 + nt) * 16;
+            const int slot = (ty8 * P.tiles_x + txi) * 4 + (rg & 1) * 2 + nt;       // (element address: gn_partial_index, conv_params.h)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float v = stat[i];
@@ -197,8 +197,8 @@ __global__ void __launch_bounds__(RW_THREADS, 1) conv3x3_c64_rw_kernel(const Con
                 float v = stat[0];
 #pragma unroll
                 for (int i = 1; i < 8; ++i) v = (lane == i) ? stat[i] : v;
-                gp[nt * 8 + lane] = v;
-                gp[(1 - nt) * 8 + lane] = 0.0f;
+                P.gn_partial[gn_partial_index(b, tpi8 * 4, slot, 8, nt * 4 + (lane >> 1)) + (lane & 1)] = v;
+                P.gn_partial[gn_partial_index(b, tpi8 * 4, slot, 8, (1 - nt) * 4 + (lane >> 1)) + (lane & 1)] = 0.0f;
             }
         }
     }

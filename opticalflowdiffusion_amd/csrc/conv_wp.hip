@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
     }
 #endif
     if (P.gn_partial) {
-        // layout of conv_igemm.hip, [b][8-row tile][4 slots][Cout/8][2], consumed by gn_finalize: this wave owns octets
+        // slots of conv_igemm.hip (4 per 8x32 tile; element address: gn_partial_index, conv_params.h), consumed by gn_finalize: this wave owns octets
         // cb/8 .. cb/8 + 3 of the 8-row tile (ph); its sums go to slot ns, every other (slot, octet) of the workgroup's channel
         // block is written as zero by the wave whose slot it is (slots ns, ns + NS, ...)
         wave_reduce8(stat);
@@ -454,8 +454,8 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
             const int slot = (lane & 31) >> 3, o = (lane & 7) >> 1, which = lane & 1;
             const float total = __shfl(stat[0], (o * 2 + which) * 8, 64);           // value index k lives in lanes 8k .. 8k+7
             if (ty8 < tiles8 && lane < 32) {
-                const size_t base = ((((size_t)b * tiles8 + ty8) * P.tiles_x + (t_in % P.tiles_x)) * 4 + slot) * (P.Cout / 8) * 2;
-                P.gn_partial[base + (cb / 8 + o) * 2 + which] = slot == 0 ? total : 0.0f;
+                P.gn_partial[gn_partial_index(b, tiles8 * P.tiles_x * 4, (ty8 * P.tiles_x + (t_in % P.tiles_x)) * 4 + slot, P.Cout / 8, cb / 8 + o) + which] =
+                    slot == 0 ? total : 0.0f;
             }
         } else if (ty8 < tiles8) {
             constexpr int OCT = C::BN / 8;                          // octets of the workgroup's channel block
@@ -466,8 +466,8 @@ __global__ void __launch_bounds__(64 * NS * PH, (NS * PH == 4) ? 2 : 1) conv3x3_
             if (lane < PER_WAVE) {
                 const int slot = ns + slot_i * NS;
                 const bool own = slot_i == 0 && (o >> 2) == ns;
-                const size_t base = ((((size_t)b * tiles8 + ty8) * P.tiles_x + (t_in % P.tiles_x)) * 4 + slot) * (P.Cout / 8) * 2;
-                P.gn_partial[base + (n0 / 8 + o) * 2 + which] = own ? total : 0.0f;
+                P.gn_partial[gn_partial_index(b, tiles8 * P.tiles_x * 4, (ty8 * P.tiles_x + (t_in % P.tiles_x)) * 4 + slot, P.Cout / 8, n0 / 8 + o) + which] =
+                    own ? total : 0.0f;
             }
         }
     }
@@ -720,7 +720,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wp16_kernel(const ConvParams P
                 v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
                 st[h][w] = v;
             }
-        // layout of conv3x3_wp_kernel: [b][8-row tile][4 slots][Cout/8][2]; this wave's octets cb/8 + o (o = 2 h + m, m = lg >> 1 of the holder):
+        // slots of conv3x3_wp_kernel (4 per 8-row tile and tile column; gn_partial_index); this wave's octets cb/8 + o (o = 2 h + m, m = lg >> 1 of the holder):
         // lane t < 32 writes float t of the wave's share (slot_i, octet o, which); the sums go to slot ns, zeros elsewhere
         const int ty8 = oy0 / 8, tiles8 = (P.H + 7) / 8;
         if (ty8 < tiles8) {
@@ -732,8 +732,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wp16_kernel(const ConvParams P
             const float total = hh ? (which ? t11 : t10) : (which ? t01 : t00);
             if (lane < PER_WAVE) {
                 const bool own = (o >> 2) == ns;
-                const size_t base = ((((size_t)b * tiles8 + ty8) * P.tiles_x + (t_in % P.tiles_x)) * 4 + ns) * (P.Cout / 8) * 2;
-                P.gn_partial[base + (cy * C::BN / 8 + o) * 2 + which] = own ? total : 0.0f;
+                P.gn_partial[gn_partial_index(b, tiles8 * P.tiles_x * 4, (ty8 * P.tiles_x + (t_in % P.tiles_x)) * 4 + ns, P.Cout / 8, cy * C::BN / 8 + o) + which] =
+                    own ? total : 0.0f;
             }
         }
     }
@@ -1153,7 +1153,7 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
         }
         }
         if (P.gn_partial) {
-            // layout of conv3x3_wp_kernel: [b][8-row tile][tile column][4 slots][Cout/8][2]; this wave's sums go to slot ns, every other
+            // slots of conv3x3_wp_kernel (4 per 8-row tile and tile column; gn_partial_index); this wave's sums go to slot ns, every other
             // (slot, octet) of the workgroup's channel block is written as zero by the wave whose slot it is (slots ns, ns + 2)
             wave_reduce8(stat);
             const int ty8 = oy0 / 8 + ph;
@@ -1164,8 +1164,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pc_kernel(const ConvParams P) 
                 if (lane < PER_WAVE) {
                     const int slot = ns + slot_i * 2;
                     const bool own = slot_i == 0 && (o >> 2) == ns;
-                    const size_t base = ((((size_t)b * tiles8 + ty8) * P.tiles_x + ox0 / TW) * 4 + slot) * (P.Cout / 8) * 2;
-                    P.gn_partial[base + (cy * C::BN / 8 + o) * 2 + which] = own ? total : 0.0f;
+                    P.gn_partial[gn_partial_index(b, tiles8 * P.tiles_x * 4, (ty8 * P.tiles_x + ox0 / TW) * 4 + slot, P.Cout / 8, cy * C::BN / 8 + o) + which] =
+                        own ? total : 0.0f;
                 }
             }
         }
@@ -1519,8 +1519,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_pcw_kernel(const ConvParams P)
                 const float total = hh ? (which ? t11 : t10) : (which ? t01 : t00);
                 if (lane < PER_WAVE) {
                     const bool own = (o >> 2) == ns;
-                    const size_t base = ((((size_t)b * tiles8 + ty8) * P.tiles_x + ox0 / TW) * 4 + ns) * (P.Cout / 8) * 2;
-                    P.gn_partial[base + (cy * C::BN / 8 + o) * 2 + which] = own ? total : 0.0f;
+                    P.gn_partial[gn_partial_index(b, tiles8 * P.tiles_x * 4, (ty8 * P.tiles_x + ox0 / TW) * 4 + ns, P.Cout / 8, cy * C::BN / 8 + o) + which] =
+                        own ? total : 0.0f;
                 }
             }
         }

@@ -163,8 +163,8 @@ def test_full_size_3x3_producer_consumer_kernel_against_the_wave_private_kernel(
     assert bool(torch.isfinite(o1).all())
     assert float((o1 - o0).norm() / o0.norm()) < 2e-3
     tiles = math.ceil(H / 8) * math.ceil(W / 32)
-    p1 = outs["1"][1].reshape(B, tiles * 4, Cout // 8, 2).sum(1)
-    p0 = outs["0"][1].reshape(B, tiles * 4, Cout // 8, 2).sum(1)
+    p1 = outs["1"][1].reshape(B, 8, tiles * 4, Cout // 64, 2).sum(2).reshape(B, Cout // 8, 2)     # (gn_partial_index, csrc/conv_params.h)
+    p0 = outs["0"][1].reshape(B, 8, tiles * 4, Cout // 64, 2).sum(2).reshape(B, Cout // 8, 2)
     assert bool(torch.isfinite(p1).all())
     assert torch.allclose(p1, p0, rtol=1e-3, atol=2.0)
     oc = o1.reshape(B, H, W, Cout // 8, 8)

@@ -53,6 +53,12 @@ def prep_weight(L, w, ksize, ws_eps=-1.0, cin_pad=None, unshuffle=0):
     return out
 
 
+def gn_octet_sums(gn, B, tiles, Cout):
+    """per-(sample, 8-channel octet) totals of the conv epilogue's GroupNorm partial sums: [b][8 groups][tiles * 4 wave slots][Cout / 64][2]
+    (gn_partial_index, csrc/conv_params.h) summed over the slots -> (B, Cout / 8, 2)"""
+    return gn.cpu().reshape(B, 8, tiles * 4, Cout // 64, 2).sum(2).reshape(B, Cout // 8, 2)
+
+
 def run_conv(L, B, H, W, ksize, srcs, Cout, weight, bias=None, in_scale=None, in_shift=None, residual=None,
              res_act=None, res_scale=None, res_shift=None, want_gn=False):
     a = L.ConvArgs()
@@ -110,7 +116,7 @@ def test_conv3x3_plain_and_ws(L, B, H, W, Cin, Cout):
         # GroupNorm partial sums of the stored values -> per (sample, 8-channel oct) totals
         o = from_nhwc(out)
         tiles = math.ceil(H / 8) * math.ceil(W / 32)
-        p = gn.cpu().reshape(B, tiles * 4, Cout // 8, 2).sum(1)     # [b][tile][wave][oct][2]
+        p = gn_octet_sums(gn, B, tiles, Cout)
         oc = o.reshape(B, Cout // 8, 8, H, W)
         assert torch.allclose(p[..., 0], oc.sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
         assert torch.allclose(p[..., 1], (oc * oc).sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
@@ -159,8 +165,8 @@ def test_conv3x3_producer_consumer_kernel_forms(L, B, H, W, cins, Cout, pro, up)
         check_close(from_nhwc(outs[pc][0]), ref, tol=tol, what=f"OFD_CONV_PC={pc}")
     assert rel_l2(from_nhwc(outs["1"][0]), from_nhwc(outs["0"][0])) < 2e-3
     tiles = math.ceil(H / 8) * math.ceil(W / 32)
-    p1 = outs["1"][1].cpu().reshape(B, tiles * 4, Cout // 8, 2).sum(1)
-    p0 = outs["0"][1].cpu().reshape(B, tiles * 4, Cout // 8, 2).sum(1)
+    p1 = gn_octet_sums(outs["1"][1], B, tiles, Cout)
+    p0 = gn_octet_sums(outs["0"][1], B, tiles, Cout)
     o = from_nhwc(outs["1"][0]).reshape(B, Cout // 8, 8, H, W)
     assert torch.allclose(p1[..., 0], o.sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
     assert torch.allclose(p1[..., 1], (o * o).sum(dim=(2, 3, 4)), rtol=1e-4, atol=1e-2)
