@@ -125,7 +125,9 @@ int ofd_ddim_update(const float* x_t, const float* model_out, const float* noise
                     const float* sqrt_alpha_next, const float* c, const float* sigma, int last,
                     float* out, float* x_start, int B, size_t n_per_sample, void* stream);
 /* sum and count over positions where neither pred nor target is NaN of (pred-target)^2.
- * result: 2 doubles {sum, count} (device), zeroed by the call. */
+ * result (device): ofd_nan_mse_result_doubles() doubles -- [0] sum, [1] count, the rest scratch (per-workgroup partial sums, added
+ * in a fixed order: the same inputs give the same sum bit for bit). */
+size_t ofd_nan_mse_result_doubles(void);
 int ofd_nan_mse_sum(const float* pred, const float* target, size_t n, double* result, void* stream);
 /* backward of result[0] / result[1] (the nanmean): dpred = 2 (pred - target) * gout[0] / result[1] on finite pairs, else 0;
  * result is what ofd_nan_mse_sum left, gout a device scalar */
@@ -137,8 +139,9 @@ int ofd_nan_mse_grad(const float* pred, const float* target, size_t n, const dou
  * clip_grad_norm_(max_norm) (exp_base.py:192,205), multi-tensor, no host synchronisation.
  * table: device array of {float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
  * uint64 numel}; tasks: device arrays (tensor index, chunk index) with ofd_adam_chunk() elements
- * per chunk.  sqnorm_acc (1 double), clip_coef (1 float) and optional total_norm are device
- * scratch/outputs.  step counts from 1.  max_norm <= 0 disables clipping. */
+ * per chunk.  sqnorm_acc (n_tasks + 1 doubles: [0] the squared norm, then one partial sum per task, added in a
+ * fixed order -- the same gradients give the same clip coefficient bit for bit), clip_coef (1 float) and optional
+ * total_norm are device scratch/outputs.  step counts from 1.  max_norm <= 0 disables clipping. */
 int ofd_adam_chunk(void);
 int ofd_adam_step(const void* table, const unsigned* task_tensor, const unsigned* task_chunk, int n_tasks,
                   double* sqnorm_acc, float* clip_coef, float* total_norm, float max_norm, float lr,
@@ -206,6 +209,15 @@ int ofd_unet_read_tap(ofd_unet* u, const char* name, float* dst, size_t numel, v
  * the final 1x1 conv (DD:361) then rides on the tile of its producer (out_dim 2, H*W a multiple of 128) and "final_res_block" is
  * not a tap.  The two forms sum the 64 products of a pixel in different orders (equal to fp32 rounding). */
 int ofd_unet_set_debug_taps(ofd_unet* u, int enabled);
+/* deterministic backward (default: the environment variable OFD_DETERMINISTIC, else off).  The backward accumulates parameter
+ * gradients from many workgroups with float atomics, whose order -- and so the last bits of the sums -- changes from run to run
+ * (torch's cuDNN weight gradients behave the same way in the reference).  Enabled, every such accumulation goes through a 64-bit
+ * fixed-point shadow (csrc/det.h: value * 2^38, integer atomics, order-independent) that is flushed into the fp32 gradient
+ * before anyone reads it: two backward passes over the same tape give bit-identical gradients.  Costs 8 bytes per parameter and
+ * accumulator of extra memory and a few small launches per layer.  ofd_unet_deterministic_misses: accumulations (since creation)
+ * that found no shadow and fell back to float atomics (0 for the UNet of this library; -1 on error). */
+int ofd_unet_set_deterministic(ofd_unet* u, int enabled);
+long ofd_unet_deterministic_misses(ofd_unet* u);
 /* per-kernel-class device time of forwards run with profiling enabled (HIP events on the
  * stream the kernels are launched on).  classes: see ofd_unet_prof_name(). */
 int ofd_unet_set_profiling(ofd_unet* u, int enabled);
@@ -361,7 +373,7 @@ int ofd_gn_finalize(const float* partial, int B, int H, int W, int C, const floa
 /* Batched training augmentation in one pass (replaces the per-sample torchvision pipeline of augmentation.py:6-76 behind
  * FlowDiffuser.preprocess(aug=True), flow_diffuser.py:137-138).  img / tgt (B,3,H,W), flow (B,2,H,W) fp32 NCHW; params (B,16) fp32:
  * 0 jitter on, 1 brightness, 2 contrast, 3 saturation, 4 grayscale on, 5 blur on, 6 sigma, 7 h-flip, 8 v-flip, 9 crop on,
- * 10 oy, 11 ox, 12 ch, 13 cw (crop window origin / size as fractions of the image; 1, 1 without a crop).  means_ws: B*2 doubles.
+ * 10 oy, 11 ox, 12 ch, 13 cw (crop window origin / size as fractions of the image; 1, 1 without a crop).  means_ws: B*2 x 8 bytes of device scratch.
  * reference_semantics == 0 (default of the plugin): geometrically consistent flow -- a flip negates the component along the flipped
  * axis, a crop divides each component by its axis' window fraction.  != 0: the reference's own arithmetic on the flow channels --
  * flips negate the other channel (augmentation.py:37-45), the crop multiplies channel 0 by ch and channel 1 by cw (augmentation.py:47-48). */

@@ -62,6 +62,7 @@ SIGNATURES = {
     "ofd_ddpm_update": (c_int, [c_void_p] * 8 + [c_int, c_size_t, c_void_p]),
     "ofd_ddim_update": (c_int, [c_void_p] * 8 + [c_int] + [c_void_p] * 2 + [c_int, c_size_t, c_void_p]),
     "ofd_nan_mse_sum": (c_int, [c_void_p] * 2 + [c_size_t, c_void_p, c_void_p]),
+    "ofd_nan_mse_result_doubles": (c_size_t, []),
     "ofd_adam_chunk": (c_int, []),
     "ofd_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_float] * 6 + [c_int, c_void_p]),
     "ofd_unet_create": (c_int, [ctypes.POINTER(UnetConfig), ctypes.POINTER(c_void_p)]),
@@ -81,6 +82,8 @@ SIGNATURES = {
     "ofd_unet_read_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_size_t, c_void_p]),
     "ofd_unet_set_debug_taps": (c_int, [c_void_p, c_int]),
     "ofd_unet_set_profiling": (c_int, [c_void_p, c_int]),
+    "ofd_unet_set_deterministic": (c_int, [c_void_p, c_int]),
+    "ofd_unet_deterministic_misses": (ctypes.c_long, [c_void_p]),
     "ofd_unet_prof_count": (c_int, [c_void_p]),
     "ofd_unet_prof_name": (c_char_p, [c_void_p, c_int]),
     "ofd_unet_prof_read": (c_int, [c_void_p, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),

@@ -13,8 +13,12 @@ constexpr int AUG_NP = 16;
 
 __device__ __forceinline__ float aug_gray(float r, float g, float b) { return 0.299f * r + 0.587f * g + 0.114f * b; }
 
-// mean gray level of every (sample, frame): what the contrast factor pivots on
-__global__ void __launch_bounds__(256) aug_gray_mean_kernel(const float* __restrict__ img, const float* __restrict__ tgt, double* __restrict__ means, int plane) {
+// mean gray level of every (sample, frame): what the contrast factor pivots on.  The workgroups of a (sample, frame) add their shares as
+// 64-bit fixed point (x 2^44, integer atomics): the sum does not depend on the order they retire in, the augmented batch is the same
+// bit for bit for the same inputs and table (a double atomic made the last bits of the mean, and through the contrast pivot every
+// jittered pixel, a matter of scheduling).  |mean| < 5e5, resolution 6e-14.
+constexpr double AUG_MEAN_SCALE = 17592186044416.0;      // 2^44
+__global__ void __launch_bounds__(256) aug_gray_mean_kernel(const float* __restrict__ img, const float* __restrict__ tgt, long long* __restrict__ means, int plane) {
     const int b = blockIdx.y >> 1, frame = blockIdx.y & 1;
     const float* p = (frame ? tgt : img) + (size_t)b * 3 * plane;
     double s = 0.0;
@@ -23,11 +27,12 @@ __global__ void __launch_bounds__(256) aug_gray_mean_kernel(const float* __restr
     __shared__ double ws[4];
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(means + blockIdx.y, (ws[0] + ws[1] + ws[2] + ws[3]) / (double)plane);
+    if (threadIdx.x == 0)
+        atomicAdd((unsigned long long*)(means + blockIdx.y), (unsigned long long)__double2ll_rn(((ws[0] + ws[1]) + (ws[2] + ws[3])) / (double)plane * AUG_MEAN_SCALE));
 }
 
 __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ img, const float* __restrict__ tgt, const float* __restrict__ flow,
-                                                      const float* __restrict__ params, const double* __restrict__ means,
+                                                      const float* __restrict__ params, const long long* __restrict__ means,
                                                       float* __restrict__ o_img, float* __restrict__ o_tgt, float* __restrict__ o_flow,
                                                       int H, int W, int ref_flip) {
     const int b = blockIdx.y, plane = H * W;
@@ -40,7 +45,7 @@ __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ 
         const float n = 1.0f / (1.0f + 2.0f * e);
         k1[0] = e * n; k1[1] = n; k1[2] = e * n;
     }
-    const float mean_g[2] = {(float)means[b * 2] * br, (float)means[b * 2 + 1] * br};    // mean gray after the brightness factor
+    const float mean_g[2] = {(float)((double)means[b * 2] / AUG_MEAN_SCALE) * br, (float)((double)means[b * 2 + 1] / AUG_MEAN_SCALE) * br};    // mean gray after the brightness factor
     const float* src[2] = {img + (size_t)b * 3 * plane, tgt + (size_t)b * 3 * plane};
     const float* fsrc = flow + (size_t)b * 2 * plane;
 
@@ -131,8 +136,8 @@ extern "C" int ofd_augment(const float* img, const float* tgt, const float* flow
     OFD_HIP(hipMemsetAsync(means_ws, 0, (size_t)B * 2 * sizeof(double), s));
     const int plane = H * W;
     int gx = (plane + 255) / 256;
-    aug_gray_mean_kernel<<<dim3(gx < 64 ? gx : 64, B * 2), 256, 0, s>>>(img, tgt, (double*)means_ws, plane);
-    augment_kernel<<<dim3(gx < 512 ? gx : 512, B), 256, 0, s>>>(img, tgt, flow, params, (const double*)means_ws, out_img, out_tgt, out_flow, H, W,
+    aug_gray_mean_kernel<<<dim3(gx < 64 ? gx : 64, B * 2), 256, 0, s>>>(img, tgt, (long long*)means_ws, plane);
+    augment_kernel<<<dim3(gx < 512 ? gx : 512, B), 256, 0, s>>>(img, tgt, flow, params, (const long long*)means_ws, out_img, out_tgt, out_flow, H, W,
                                                                   reference_semantics);
     OFD_LAUNCH_CHECK();
     return OFD_OK;

@@ -15,7 +15,10 @@
 //     waits are counted by hand: per tile and wave the VMEM issue order is [DMA(t+1)] ... [h2(t+1)] [stores(t)], the top-of-tile
 //     wait is vmcnt(#h2 + #stores), the wait before the epilogue vmcnt(#stores + #DMA).
 // Persistent: workgroup w walks tiles w, w + G, ... (P.interleave; all resident workgroups inside one moving window of memory).
-// Tiles are always full (the host checks H*W % TILE == 0), stores are never predicated: the hand-counted waits depend on it.
+// Tiles are always full and stores never predicated (the hand-counted waits depend on it): when TILE does not divide H*W the LAST tile of
+// a sample starts at H*W - TILE and recomputes the pixels it shares with the tile before it (same inputs, same arithmetic, the same
+// bytes written twice; the host admits this only for same-size sources, an output that is none of the inputs, and never for the
+// atomics of the FC form).
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -132,11 +135,12 @@ __global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel
             for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(fcw[k][i]));
         asm volatile("" : "+v"(fcb));
     }
-    const int plane = P.H * P.W, tps = plane / TILE;                   // tiles per sample
+    const int plane = P.H * P.W, tps = (plane + TILE - 1) / TILE;      // tiles per sample (the last one overlaps its predecessor when TILE does not divide the plane)
+    auto tile_p0 = [&](int t, int b) { return min((t - b * tps) * TILE, plane - TILE); };
     // DMA lane constants: piece = 8 pixel rows x 128 B of one unit; lane -> row lane >> 3, 16-byte chunk (lane & 7) ^ (lane >> 3)
     const int d_row = lane >> 3, d_chunk = ((lane & 7) ^ (lane >> 3)) * 8;          // (elements)
     auto issue_dma = [&](int t, int buf) {
-        const int b = t / tps, p0 = (t - b * tps) * TILE;              // first pixel of the tile inside its sample
+        const int b = t / tps, p0 = tile_p0(t, b);                     // first pixel of the tile inside its sample
         const int y = p0 / P.W, x0 = p0 - y * P.W;                     // (TILE divides W when an unshuffled source is present: host check)
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
@@ -153,7 +157,8 @@ __global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel
     u4 ra[RA ? NRA : 1];
     auto issue_ra = [&](int t) {
         if constexpr (RA) {
-            const size_t gp0 = (size_t)t * TILE;                       // global pixel index (tiles never straddle samples)
+            const int b = t / tps;
+            const size_t gp0 = (size_t)b * plane + tile_p0(t, b);     // global pixel index (tiles never straddle samples)
 #pragma unroll
             for (int f = 0; f < F; ++f)
 #pragma unroll
@@ -206,7 +211,7 @@ __global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel
 #pragma unroll
         for (int q = 0; q < 4; ++q) xa[q] = xaddr + cx[q];
         const int b = t / tps;
-        const size_t gp0 = (size_t)t * TILE;
+        const size_t gp0 = (size_t)b * plane + tile_p0(t, b);
         static_for<0, NCB>([&](auto cbc) {
         constexpr int cbk = decltype(cbc)::value;
         f32x16 acc[F];
@@ -347,13 +352,16 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
     const bool ra = C.res_act != nullptr;
     if (cin % 64 != 0 || (cin > 384 && !(cin == 512 && !ra) && !(cin == 768 && ra)) || cin == 320 || (cin < 128 && !(cin == 64 && C.Cout == 384 && !ra && !C.bias)) || (C.Cout != 64 && C.Cout % 128 != 0)) return 1;
     const int tile = (cin <= 128) ? 128 : (cin >= 384 ? 32 : 64);
-    if (plane % tile != 0 || (size_t)C.B * plane * (size_t)(C.Cout > cin ? C.Cout : cin) * 2 >= (1ull << 40)) return 1;
+    if (plane < tile || (size_t)C.B * plane * (size_t)(C.Cout > cin ? C.Cout : cin) * 2 >= (1ull << 40)) return 1;
+    const bool ragged = plane % tile != 0;                        // the last tile of a sample overlaps the one before it (see the header)
+    if (ragged && (C.fc_out || (const bf16_t*)C.out == C.res_act)) return 1;
     Params P{};
     int nu = 0;
     for (int i = 0; i < C.n_src; ++i) {
         const ConvSrcDev& S = C.src[i];
         if (S.mode == 1) return 1;
         if (S.mode == 2 && (C.W % tile != 0)) return 1;
+        if (ragged && (S.mode != 0 || S.ptr == (const bf16_t*)C.out)) return 1;
         for (int k = 0; k < S.chunks; ++k) {
             if (nu >= 12) return 1;
             Unit& U = P.unit[nu++];
@@ -367,7 +375,7 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
     P.weight = C.weight; P.bias = C.bias; P.res_act = C.res_act; P.res_scale = C.res_scale; P.res_shift = C.res_shift; P.out = C.out;
     P.fc_w = C.fc_w; P.fc_b = C.fc_b; P.fc_out = C.fc_out;
     if (C.fc_out && !(cin == 128 && C.Cout == 64 && ra)) return 1;
-    P.B = C.B; P.H = C.H; P.W = C.W; P.Cout = C.Cout; P.ntiles = C.B * (plane / tile);
+    P.B = C.B; P.H = C.H; P.W = C.W; P.Cout = C.Cout; P.ntiles = C.B * ((plane + tile - 1) / tile);
     static const int order = getenv("OFD_CONV1_ORDER") ? atoi(getenv("OFD_CONV1_ORDER")) : 1;
     P.interleave = order;
     const bool narrow = C.Cout == 64;

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "blocks.h"
+#include "det.h"
 #include "conv_params.h"
 #include "mfma_util.h"
 
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams P) {
                 }
             }
     }
-    if (do_bias) atomicAdd(P.dbias + cob * 64 + (tid & 63), bsum);
+    if (do_bias) gacc_add(P.dbias + cob * 64 + (tid & 63), bsum);
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) {
         const int tap = ky * KS + kx;
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradParams P) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
-            atomicAdd(d + (size_t)ci * P.Cout, acc[kx][r]);
+            gacc_add(d + (size_t)ci * P.Cout, acc[kx][r]);
         }
     }
 }
@@ -265,7 +266,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad1_qkv_kernel(const bf16_t* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
-                atomicAdd(d + (size_t)ci * WQ_CO, acc[a][j][r]);
+                gacc_add(d + (size_t)ci * WQ_CO, acc[a][j][r]);
             }
         }
 }
@@ -345,7 +346,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad1_wide_kernel(const WgradPar
                     acc[a][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a], yf[j], acc[a][j], 0, 0, 0);   // rows = ci, cols = co
         }
     }
-    if (do_bias && tid < CO) atomicAdd(P.dbias + tid, bsum);
+    if (do_bias && tid < CO) gacc_add(P.dbias + tid, bsum);
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -354,7 +355,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad1_wide_kernel(const WgradPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
-                atomicAdd(d + (size_t)ci * CO, acc[a][j][r]);
+                gacc_add(d + (size_t)ci * CO, acc[a][j][r]);
             }
         }
 }
@@ -528,7 +529,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
                 }
         }
     }
-    if (do_bias) atomicAdd(P.dbias + cob * 64 + (tid & 63), bsum);
+    if (do_bias) gacc_add(P.dbias + cob * 64 + (tid & 63), bsum);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -539,7 +540,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const WgradParams P
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
-                atomicAdd(d + (size_t)ci * P.Cout, acc[ay][ax][r]);
+                gacc_add(d + (size_t)ci * P.Cout, acc[ay][ax][r]);
             }
         }
 }
@@ -732,7 +733,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad3_db_kernel(const WgradParam
         });
         cur ^= 1;
     }
-    if (do_bias) atomicAdd(P.dbias + cob * 64 + (tid & 63), bsum);
+    if (do_bias) gacc_add(P.dbias + cob * 64 + (tid & 63), bsum);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -741,7 +742,7 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad3_db_kernel(const WgradParam
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
-                atomicAdd(d + (size_t)ci * P.Cout, acc[ky][kx][r]);
+                gacc_add(d + (size_t)ci * P.Cout, acc[ky][kx][r]);
             }
         }
 }
@@ -833,7 +834,7 @@ __global__ void __launch_bounds__(512) conv7_wgrad_kernel(const bf16_t* __restri
                 }
             }
     }
-    if (dbias) atomicAdd(dbias + (tid & 63), bsum);
+    if (dbias) gacc_add(dbias + (tid & 63), bsum);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int ky = kg + 4 * a;
@@ -843,7 +844,7 @@ __global__ void __launch_bounds__(512) conv7_wgrad_kernel(const bf16_t* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * half, kx = 2 * k + (m >> 4), ci = m & 15;
-                if (kx < 7) atomicAdd(dw + ((size_t)(ky * 7 + kx) * 16 + ci) * 64 + nt * 32 + l31, acc[a][k][r]);
+                if (kx < 7) gacc_add(dw + ((size_t)(ky * 7 + kx) * 16 + ci) * 64 + nt * 32 + l31, acc[a][k][r]);
             }
     }
 }
@@ -876,7 +877,7 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const bf16_t* __restri
             for (int j = 0; j < 8; ++j) {
                 float s = 0.0f;
                 for (int r = 0; r < rows; ++r) s += red[r * lanes_c + tid][j];
-                atomicAdd(out + (cu + tid) * 8 + j, s);
+                gacc_add(out + (cu + tid) * 8 + j, s);
             }
         }
         __syncthreads();
@@ -1198,6 +1199,8 @@ int k_grad_scatter(const bf16_t* D, int Ctot, int ch_off, bf16_t* dst, int C, in
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
+
+OFD_DET_DEFINE_SETTER(det_set_ctx_conv_bwd)
 
 }  // namespace ofd
 

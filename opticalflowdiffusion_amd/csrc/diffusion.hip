@@ -98,8 +98,11 @@ __global__ void __launch_bounds__(256) ddim_update_kernel(const float* __restric
     }
 }
 
+// per-workgroup (sum, count) -> part[2 * block]; nan_mse_total_kernel adds the workgroups up in a fixed order (no atomics: the loss is
+// the same number, bit for bit, for the same inputs)
+constexpr int NAN_MSE_BLOCKS = 2048;
 __global__ void __launch_bounds__(256) nan_mse_kernel(const float* __restrict__ pred, const float* __restrict__ target,
-                                                      size_t n, double* __restrict__ result) {
+                                                      size_t n, double* __restrict__ part) {
     double sum = 0.0, cnt = 0.0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float p = pred[i], t = target[i];
@@ -118,9 +121,21 @@ __global__ void __launch_bounds__(256) nan_mse_kernel(const float* __restrict__ 
     if (lane == 0) { ssum[wid] = sum; scnt[wid] = cnt; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&result[0], ssum[0] + ssum[1] + ssum[2] + ssum[3]);
-        atomicAdd(&result[1], scnt[0] + scnt[1] + scnt[2] + scnt[3]);
+        part[2 * blockIdx.x] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        part[2 * blockIdx.x + 1] = (scnt[0] + scnt[1]) + (scnt[2] + scnt[3]);
     }
+}
+__global__ void __launch_bounds__(256) nan_mse_total_kernel(double* __restrict__ result, int nblocks) {
+    __shared__ double s1[256], s2[256];
+    double a = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { a += result[2 + 2 * i]; c += result[3 + 2 * i]; }
+    s1[threadIdx.x] = a; s2[threadIdx.x] = c;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) { s1[threadIdx.x] += s1[threadIdx.x + k]; s2[threadIdx.x] += s2[threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { result[0] = s1[0]; result[1] = s2[0]; }
 }
 
 // backward of mean over the non-NaN entries: dpred = 2 (pred - target) * gout / count where both are finite
@@ -186,13 +201,14 @@ extern "C" int ofd_ddim_update(const float* x_t, const float* model_out, const f
 extern "C" int ofd_nan_mse_sum(const float* pred, const float* target, size_t n, double* result, void* stream) {
     OFD_CHECK_ARG(pred && target && result && n > 0, "nan_mse_sum: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    OFD_HIP(hipMemsetAsync(result, 0, 2 * sizeof(double), s));
     size_t b = (n + 255) / 256;
-    if (b > 2048) b = 2048;
-    nan_mse_kernel<<<(unsigned)b, 256, 0, s>>>(pred, target, n, result);
+    if (b > NAN_MSE_BLOCKS) b = NAN_MSE_BLOCKS;
+    nan_mse_kernel<<<(unsigned)b, 256, 0, s>>>(pred, target, n, result + 2);
+    nan_mse_total_kernel<<<1, 256, 0, s>>>(result, (int)b);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
+extern "C" size_t ofd_nan_mse_result_doubles(void) { return 2 + 2 * (size_t)NAN_MSE_BLOCKS; }
 
 extern "C" int ofd_nan_mse_grad(const float* pred, const float* target, size_t n, const double* result, const float* gout, float* dpred,
                                 void* stream) {

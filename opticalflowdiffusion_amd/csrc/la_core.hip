@@ -8,6 +8,7 @@
 // qkv / dqkv: [B][n][384] bf16 (q | k | v, 4 heads x 32); out / dout: [B][n][128].
 #include <cstdlib>
 #include "blocks.h"
+#include "det.h"
 #include "mfma_util.h"
 
 namespace ofd {
@@ -348,7 +349,7 @@ __global__ void __launch_bounds__(256) lc_dctx_partial_kernel(const bf16_t* __re
         }
     }
     if constexpr (FD) {
-        if (dbias) atomicAdd(dbias + (tid & 63), bsum);
+        if (dbias) gacc_add(dbias + (tid & 63), bsum);
         float* o = partial + ((size_t)(b * 4 + wave) * nparts + part) * 2048;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -431,7 +432,7 @@ __global__ void __launch_bounds__(256) lc_dctx_partial_rq_kernel(const bf16_t* _
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, tr_frag(gs + sl * 16 * 128 + 64, 128, lane), acc1, 0, 0, 0);   // cols = c 32..63
         }
     }
-    if (dbias) atomicAdd(dbias + (tid & 63), bsum);
+    if (dbias) gacc_add(dbias + (tid & 63), bsum);
     float* o = partial + ((size_t)(b * 4 + wave) * nparts + part) * 2048;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -678,7 +679,7 @@ __global__ void __launch_bounds__(256, 2) lc_bwd_apply_kernel(const bf16_t* __re
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    atomicAdd(d + (size_t)ci * 384, wacc[a][j][r]);
+                    gacc_add(d + (size_t)ci * 384, wacc[a][j][r]);
                 }
             }
     }
@@ -720,7 +721,7 @@ __global__ void __launch_bounds__(256) lc_bwd_combine_kernel(const float* __rest
                 const int c = i & 63, e = i >> 6;
                 float a = 0.0f;
                 for (int d = 0; d < 32; ++d) a += qd[d * 64 + c] * ctx[(size_t)bh * 1024 + d * 32 + e];
-                atomicAdd(dwo + (size_t)(h * 32 + e) * 64 + c, a);
+                gacc_add(dwo + (size_t)(h * 32 + e) * 64 + c, a);
             }
         }
         for (int i = tid; i < 1024; i += 256) {
@@ -812,5 +813,7 @@ int k_linear_attention_core_bwd(const bf16_t* qkv, const bf16_t* dout, const flo
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
+
+OFD_DET_DEFINE_SETTER(det_set_ctx_la_core)
 
 }  // namespace ofd

@@ -17,9 +17,11 @@ struct AdamTensor {
 
 constexpr int OPT_CHUNK = 65536;   // elements per workgroup task
 
-// sum of squares of all gradients -> acc[0] (double), zeroed by the launcher
+// sum of squares of a task's chunk -> part[task] (double): no atomics, clip_coef_kernel adds the tasks up in a fixed order (the same
+// gradients give the same norm, bit for bit -- a double atomic per workgroup made the clip coefficient, and with it every parameter,
+// depend on the order the workgroups retired in)
 __global__ void __launch_bounds__(256) grad_sqnorm_kernel(const AdamTensor* __restrict__ tab, const unsigned* __restrict__ task_tensor,
-                                                          const unsigned* __restrict__ task_chunk, double* __restrict__ acc) {
+                                                          const unsigned* __restrict__ task_chunk, double* __restrict__ part) {
     const AdamTensor t = tab[task_tensor[blockIdx.x]];
     const unsigned long long start = (unsigned long long)task_chunk[blockIdx.x] * OPT_CHUNK;
     const unsigned long long stop = min(t.n, start + OPT_CHUNK);
@@ -32,12 +34,24 @@ __global__ void __launch_bounds__(256) grad_sqnorm_kernel(const AdamTensor* __re
     __shared__ double sh[4];
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 // clip_grad_norm_: coef = min(1, max_norm / (sqrt(sum) + 1e-6)); max_norm <= 0 disables clipping
-__global__ void clip_coef_kernel(const double* __restrict__ acc, float max_norm, float* __restrict__ coef, float* __restrict__ total_norm) {
-    const float norm = (float)sqrt(acc[0]);
+// acc[0] <- sum of acc[1 .. n_tasks] (thread t adds tasks t, t + 256, ...; then a fixed tree)
+__global__ void __launch_bounds__(256) clip_coef_kernel(double* __restrict__ acc, int n_tasks, float max_norm, float* __restrict__ coef, float* __restrict__ total_norm) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_tasks; i += 256) s += acc[1 + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    acc[0] = sh[0];
+    const float norm = (float)sqrt(sh[0]);
     if (total_norm) *total_norm = norm;
     float c = 1.0f;
     if (max_norm > 0.0f) c = fminf(1.0f, max_norm / (norm + 1e-6f));
@@ -74,9 +88,8 @@ extern "C" int ofd_adam_step(const void* table, const unsigned* task_tensor, con
                              float weight_decay, int step, void* stream) {
     OFD_CHECK_ARG(table && task_tensor && task_chunk && n_tasks > 0 && sqnorm_acc && clip_coef && step >= 1, "adam_step: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    OFD_HIP(hipMemsetAsync(sqnorm_acc, 0, sizeof(double), s));
-    grad_sqnorm_kernel<<<n_tasks, 256, 0, s>>>((const AdamTensor*)table, task_tensor, task_chunk, sqnorm_acc);
-    clip_coef_kernel<<<1, 1, 0, s>>>(sqnorm_acc, max_norm, clip_coef, total_norm);
+    grad_sqnorm_kernel<<<n_tasks, 256, 0, s>>>((const AdamTensor*)table, task_tensor, task_chunk, sqnorm_acc + 1);
+    clip_coef_kernel<<<1, 256, 0, s>>>(sqnorm_acc, n_tasks, max_norm, clip_coef, total_norm);
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
     adam_step_kernel<<<n_tasks, 256, 0, s>>>((const AdamTensor*)table, task_tensor, task_chunk, clip_coef, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);

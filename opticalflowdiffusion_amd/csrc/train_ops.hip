@@ -4,6 +4,7 @@
 // activation gradients, fp32 statistics and parameter gradients.
 #include <cstdlib>
 #include "blocks.h"
+#include "det.h"
 
 namespace ofd {
 
@@ -137,8 +138,8 @@ __global__ void __launch_bounds__(256) gnbwd_finalize_kernel(const float* __rest
         }
         const float scp = ss ? ss[(size_t)b * ss_stride + ss_offset + c] + 1.0f : 1.0f;
         const double S = (double)r * (A2 - (double)mu * A1);
-        atomicAdd(dgamma + c, (float)(scp * S));
-        atomicAdd(dbeta + c, (float)(scp * A1));
+        gacc_add(dgamma + c, (float)(scp * S));
+        gacc_add(dbeta + c, (float)(scp * A1));
         if (dss) {
             dss[(size_t)b * ss_stride + ss_offset + c] = (float)(gamma[c] * S + beta[c] * A1);
             dss[(size_t)b * ss_stride + ss_offset + C + c] = (float)A1;
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(256) gnbwd_finalize_kernel(const float* __rest
         c2c3[((size_t)b * 8 + g) * 2] = (float)c2;
         c2c3[((size_t)b * 8 + g) * 2 + 1] = (float)c3;
     }
-    if (dconv_bias && tid < gs) atomicAdd(dconv_bias + c, (float)((double)a_aff[(size_t)b * C + c] * A1 + c2 * A3 + c3 * hw));
+    if (dconv_bias && tid < gs) gacc_add(dconv_bias + c, (float)((double)a_aff[(size_t)b * C + c] * A1 + c2 * A3 + c3 * hw));
 }
 
 // pass 3: dh = a * g * silu'(a h + s) + c2[b,grp] * h + c3[b,grp]
@@ -189,9 +190,7 @@ __global__ void __launch_bounds__(256) gnbwd_apply_kernel(const bf16_t* __restri
 __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gw, const bf16_t* __restrict__ dy,
                                                               bf16_t* __restrict__ dx, float* __restrict__ dg, int C, float eps, size_t npix, int accumulate,
                                                               const bf16_t* __restrict__ extra) {
-    extern __shared__ float dg_s[];       // [C]
-    for (int i = threadIdx.x; i < C; i += 256) dg_s[i] = 0.0f;
-    __syncthreads();
+    extern __shared__ float dg_s[];       // [4 waves][C]: one row per wave, added in wave order (no LDS float atomics: their order is the scheduler's)
     const int lpp = C / 8, lane = threadIdx.x & 63, sub = lane % lpp, slot = lane / lpp, ppw = 64 / lpp;
     const size_t wave_global = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
     float gv[8], dgl[8];
@@ -234,10 +233,16 @@ __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const bf16_t* __re
             *(uint4*)(dx + p * C + sub * 8) = t_pack8(d);
         }
     }
+    // lanes sub, sub + lpp, ... of a wave hold partial sums of the same 8 channels: butterfly over the pixel slots, then the wave's row
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(&dg_s[sub * 8 + j], dgl[j]);
+    for (int j = 0; j < 8; ++j)
+        for (int o = lpp; o < 64; o <<= 1) dgl[j] += __shfl_xor(dgl[j], o, 64);
+    if (slot == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dg_s[(threadIdx.x >> 6) * C + sub * 8 + j] = dgl[j];
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(dg + i, dg_s[i]);
+    for (int i = threadIdx.x; i < C; i += 256) gacc_add(dg + i, (dg_s[i] + dg_s[C + i]) + (dg_s[2 * C + i] + dg_s[3 * C + i]));
 }
 
 // ---- final 1x1 conv backward (DD:361,417): y[o] = sum_c w[o,c] x[c] + b[o], y NCHW fp32, x NHWC bf16 -----
@@ -245,11 +250,8 @@ __global__ void __launch_bounds__(256) layernorm_c_bwd_kernel(const bf16_t* __re
 __global__ void __launch_bounds__(256) final_conv_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
                                                              bf16_t* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int C, int out_dim,
                                                              size_t plane, size_t total) {
-    extern __shared__ float sm[];          // dw_s[out_dim*C] + db_s[4]
-    float* dw_s = sm;
-    float* db_s = sm + out_dim * C;
-    for (int i = threadIdx.x; i < out_dim * C + 4; i += 256) sm[i] = 0.0f;
-    __syncthreads();
+    extern __shared__ float sm[];          // [4 waves][out_dim*C + 4]: dw row and db of each wave, added in wave order (no LDS float atomics)
+    const int rowf = out_dim * C + 4;
     const int lpp = C / 8, lane = threadIdx.x & 63, sub = lane % lpp, slot = lane / lpp, ppw = 64 / lpp;
     float wv[4][8], dwl[4][8], dbl[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -274,16 +276,27 @@ __global__ void __launch_bounds__(256) final_conv_bwd_kernel(const bf16_t* __res
         }
         if (ok) *(uint4*)(dx + i * C + sub * 8) = t_pack8(dxv);
     }
+    float* const row = sm + (threadIdx.x >> 6) * rowf;
 #pragma unroll
     for (int o = 0; o < 4; ++o)
         if (o < out_dim) {
+            // lanes sub, sub + lpp, ... hold partial sums of the same 8 channels (db: the lanes with sub == 0): butterfly over the pixel slots
 #pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(&dw_s[o * C + sub * 8 + j], dwl[o][j]);
-            if (sub == 0) atomicAdd(&db_s[o], dbl[o]);
+            for (int j = 0; j < 8; ++j)
+                for (int k = lpp; k < 64; k <<= 1) dwl[o][j] += __shfl_xor(dwl[o][j], k, 64);
+            for (int k = lpp; k < 64; k <<= 1) dbl[o] += __shfl_xor(dbl[o], k, 64);
+            if (slot == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) row[o * C + sub * 8 + j] = dwl[o][j];
+                if (sub == 0) row[out_dim * C + o] = dbl[o];
+            }
         }
     __syncthreads();
-    for (int i = threadIdx.x; i < out_dim * C; i += 256) atomicAdd(dw + i, dw_s[i]);
-    if (threadIdx.x < out_dim) atomicAdd(db + threadIdx.x, db_s[threadIdx.x]);
+    for (int i = threadIdx.x; i < out_dim * C; i += 256) gacc_add(dw + i, (sm[i] + sm[rowf + i]) + (sm[2 * rowf + i] + sm[3 * rowf + i]));
+    if (threadIdx.x < out_dim) {
+        const int i = out_dim * C + threadIdx.x;
+        gacc_add(db + threadIdx.x, (sm[i] + sm[rowf + i]) + (sm[2 * rowf + i] + sm[3 * rowf + i]));
+    }
 }
 
 // dst (+)= src, bf16 (gradient fan-in of skip connections / residual paths)
@@ -330,7 +343,7 @@ __global__ void __launch_bounds__(256) block_mlp_bwd_kernel(const float* __restr
                 float a = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) { dw[j] += ds[b][j] * tsv[b]; a += wv[j] * ds[b][j]; }
-                if (b0 + b < B && kv) atomicAdd(dts + (size_t)(b0 + b) * tdim + k, a);
+                if (b0 + b < B && kv) gacc_add(dts + (size_t)(b0 + b) * tdim + k, a);
             }
         }
 #pragma unroll
@@ -459,7 +472,7 @@ int k_layernorm_c_bwd(const bf16_t* x, const float* gw, const bf16_t* dy, bf16_t
                       hipStream_t st, const bf16_t* extra) {
     OFD_CHECK_ARG(C == 64 || C == 128 || C == 256 || C == 512, "layernorm_c_bwd: C=%d", C);
     const size_t waves = (npix + (512 / C) - 1) / (512 / C);
-    layernorm_c_bwd_kernel<<<tgrid(waves * 64, 1024), 256, C * sizeof(float), st>>>(x, gw, dy, dx, dg, C, eps, npix, accumulate, extra);
+    layernorm_c_bwd_kernel<<<tgrid(waves * 64, 1024), 256, 4 * C * sizeof(float), st>>>(x, gw, dy, dx, dg, C, eps, npix, accumulate, extra);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -468,7 +481,7 @@ int k_final_conv_bwd(const bf16_t* x, const float* w, const float* dy, bf16_t* d
                      hipStream_t st) {
     OFD_CHECK_ARG(out_dim >= 1 && out_dim <= 4 && (C == 64 || C == 128), "final_conv_bwd: out_dim=%d C=%d", out_dim, C);
     const size_t total = (size_t)B * H * W;
-    final_conv_bwd_kernel<<<tgrid((total + (512 / C) - 1) / (512 / C) * 64, 1024), 256, (out_dim * C + 4) * sizeof(float), st>>>(
+    final_conv_bwd_kernel<<<tgrid((total + (512 / C) - 1) / (512 / C) * 64, 1024), 256, 4 * (out_dim * C + 4) * sizeof(float), st>>>(
         x, w, dy, dx, dw, db, C, out_dim, (size_t)H * W, total);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
@@ -496,6 +509,27 @@ int k_time_mlp_bwd(const int64_t* t, const float* temb, const float* dts, const 
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
+
+// deterministic mode (det.h): slot += shadow * 2^-38, shadow = 0
+__global__ void __launch_bounds__(256) det_flush_kernel(long long* __restrict__ fx, float* __restrict__ f, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const long long v = fx[i];
+        if (v != 0) {
+            f[i] += (float)((double)v * DET_INV_SCALE);
+            fx[i] = 0;
+        }
+    }
+}
+int k_det_flush(long long* fx, float* f, size_t n, hipStream_t s) {
+    if (n == 0) return OFD_OK;
+    size_t b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    det_flush_kernel<<<(unsigned)b, 256, 0, s>>>(fx, f, n);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+OFD_DET_DEFINE_SETTER(det_set_ctx_train_ops)
 
 }  // namespace ofd
 using namespace ofd;

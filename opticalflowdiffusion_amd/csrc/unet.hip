@@ -581,6 +581,7 @@ extern "C" int ofd_unet_create(const ofd_unet_config* cfg, ofd_unet** out) {
     OFD_CHECK_ARG(cfg->no_time == 0 || cfg->no_time == 1, "unet_create: no_time=%d", cfg->no_time);
     ofd_unet* u = new ofd_unet();
     u->cfg = *cfg;
+    { const char* e = getenv("OFD_DETERMINISTIC"); u->deterministic = e && atoi(e) != 0; }      // default of ofd_unet_set_deterministic
     build_registry(u);
     if (hipMalloc(&u->d_params, u->n_param_floats * sizeof(float)) != hipSuccess ||
         hipMalloc(&u->d_wbuf, u->n_wbuf * sizeof(bf16_t)) != hipSuccess ||
@@ -608,6 +609,8 @@ extern "C" void ofd_unet_destroy(ofd_unet* u) {
     if (u->d_labuf) (void)hipFree(u->d_labuf);
     if (u->d_wtbuf) (void)hipFree(u->d_wtbuf);
     if (u->d_wacc) (void)hipFree(u->d_wacc);
+    if (u->d_fx) (void)hipFree(u->d_fx);
+    if (u->d_det_miss) (void)hipFree(u->d_det_miss);
     if (u->d_prep) (void)hipFree(u->d_prep);
     if (u->d_tr) (void)hipFree(u->d_tr);
     drop_graphs(u);

@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include "blocks.h"
+#include "det.h"
 
 namespace ofd {
 
@@ -112,6 +113,12 @@ struct ofd_unet {
     ofd_weight_prep_desc* d_tr = nullptr;
     int n_prep = 0, prep_blocks = 0, n_tr = 0, tr_blocks = 0;
     float* d_wacc = nullptr;      // fp32 weight-gradient accumulators of every conv (same offsets as d_wbuf): ONE memset per backward
+    // deterministic backward (det.h): fixed-point shadows of d_grads | d_wacc | the time-embedding gradient rows, in this order
+    bool deterministic = false;
+    long long* d_fx = nullptr;
+    size_t fx_cap = 0;            // elements
+    unsigned* d_det_miss = nullptr;
+    DetCtx det_host{};            // the context of the backward in flight (kept alive for the asynchronous upload)
     bool wt_prepared = false;
     std::vector<TapeRec> tape;
     TrainState ts;

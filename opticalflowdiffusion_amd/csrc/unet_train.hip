@@ -27,6 +27,50 @@ struct Bwd {
     float* stmpf(size_t n) { return (float*)c.alloc(c.scratch, c.scratch_used, c.scratch_cap, n * 4); }
 };
 
+// ---- deterministic backward (det.h) ----------------------------------------------------------------
+// uploads `ctx` to the three translation units whose kernels accumulate gradients (stream-ordered)
+static int det_upload(const DetCtx* ctx, hipStream_t s) {
+    if (det_set_ctx_conv_bwd(ctx, s) != 0 || det_set_ctx_la_core(ctx, s) != 0 || det_set_ctx_train_ops(ctx, s) != 0) {
+        set_error("unet_backward: deterministic-mode context upload failed");
+        return OFD_ERR_HIP;
+    }
+    return OFD_OK;
+}
+// shadows allocated / zeroed, the context of this backward switched on: [d_grads | d_wacc | dts rows]
+static int det_begin(Ctx& c, float* dts, size_t n_dts) {
+    ofd_unet* u = c.u;
+    const size_t need = u->n_param_floats + u->n_wbuf + n_dts;
+    if (u->fx_cap < need) {
+        if (u->d_fx) (void)hipFree(u->d_fx);
+        u->d_fx = nullptr; u->fx_cap = 0;
+        if (hipMalloc(&u->d_fx, need * sizeof(long long)) != hipSuccess) { set_error("unet_backward: %zu bytes of fixed-point shadow", need * sizeof(long long)); return OFD_ERR_HIP; }
+        u->fx_cap = need;
+    }
+    if (!u->d_det_miss) {
+        if (hipMalloc(&u->d_det_miss, sizeof(unsigned)) != hipSuccess || hipMemset(u->d_det_miss, 0, sizeof(unsigned)) != hipSuccess) {
+            set_error("unet_backward: miss counter"); return OFD_ERR_HIP;
+        }
+    }
+    if (hipMemsetAsync(u->d_fx, 0, need * sizeof(long long), c.s) != hipSuccess) { set_error("unet_backward: memset failed"); return OFD_ERR_HIP; }
+    DetCtx& h = u->det_host;
+    h.on = 1; h.misses = u->d_det_miss;
+    h.r[0] = {u->d_grads, u->d_fx, u->n_param_floats};
+    h.r[1] = {u->d_wacc, u->d_fx + u->n_param_floats, u->n_wbuf};
+    h.r[2] = {dts, u->d_fx + u->n_param_floats + u->n_wbuf, n_dts};
+    return det_upload(&h, c.s);
+}
+// the context off again (the standalone operators of the C-ABI share it)
+static int det_end(Ctx& c) {
+    static const DetCtx off{};
+    return det_upload(&off, c.s);
+}
+// a conv's fixed-point weight-gradient accumulator -> its fp32 accumulator, before wgrad_finish reads it
+static int det_flush_wacc(Ctx& c, const ConvDesc& d) {
+    ofd_unet* u = c.u;
+    if (!u->deterministic || c.dry) return OFD_OK;
+    return k_det_flush(u->d_fx + u->n_param_floats + d.w_off, u->d_wacc + d.w_off, (size_t)d.ksize * d.ksize * d.Cin_pad * d.Cout, c.s);
+}
+
 static void fill_args(ofd_conv_args& a, int B, int H, int W, int ksize, int Cout, const std::vector<SrcSpec>& srcs) {
     a.B = B; a.H = H; a.W = W; a.ksize = ksize; a.n_src = (int)srcs.size(); a.Cout = Cout;
     for (size_t i = 0; i < srcs.size(); ++i) {
@@ -78,6 +122,7 @@ static Tensor conv_backward(Bwd& b, const std::string& prefix, const std::vector
         a.in_scale = in_scale; a.in_shift = in_shift;         // the weight gradient sees SiLU(affine(src)) (block2: act1 from h1)
         RUN(k_conv_wgrad(&a, dy, acc, c.s, gb));
     }
+    RUN(det_flush_wacc(c, d));
     RUN(k_wgrad_finish(acc, u->P(d.wname), u->G(d.wname), d.Cout, d.Cin, d.Cin_pad, d.ksize, d.ws_eps, d.unshuffle, 0, c.s));
     c.end();
     if (!need_dx) return D;
@@ -290,9 +335,11 @@ static void linattn_backward(Bwd& b, const TapeRec& r) {
             RUN(k_linear_attention_core_bwd(r.qkv.p, r.o2.g, r.ctx, r.ml, nullptr, ws, B, n, c.s, r.xn.p, u->d_wtbuf + d.w_off, acc, Dx.p,
                                             u->d_wbuf + dto.w_off, u->d_wtbuf + dto.w_off, u->d_wacc + dto.w_off, u->G(name + ".fn.fn.to_out.0.bias"),
                                             (la_train_no_ao(C) && la_recompute_q()) ? u->d_wbuf + d.w_off : nullptr));
+            RUN(det_flush_wacc(c, dto));
             RUN(k_wgrad_finish(u->d_wacc + dto.w_off, u->P(dto.wname), u->G(dto.wname), dto.Cout, dto.Cin, dto.Cin_pad, dto.ksize, dto.ws_eps, dto.unshuffle, 0, c.s));
         }
         else RUN(k_linear_attention_core_bwd(r.qkv.p, Dao.p, r.ctx, r.ml, nullptr, ws, B, n, c.s, r.xn.p, u->d_wtbuf + d.w_off, acc, Dx.p));
+        RUN(det_flush_wacc(c, d));
         RUN(k_wgrad_finish(acc, u->P(d.wname), u->G(d.wname), d.Cout, d.Cin, d.Cin_pad, d.ksize, d.ws_eps, d.unshuffle, 0, c.s));
         c.end();
         attn_tail_backward(b, r, name + ".fn.fn.to_qkv", name + ".fn.norm.g", dy, &Dx);
@@ -343,10 +390,14 @@ static int run_backward(Ctx& c, const float* dout, const TrainLayout& L, float* 
     float* dss = fsmall + L.off_dss;
     float* dts = fsmall + L.off_dts;
     float* tm = fsmall + L.off_tm;
+    const bool det = u->deterministic && !c.dry;
     auto notify = [&](const std::string& prefix) {
-        if (!cb || c.dry || c.rc != OFD_OK) return;
+        if (c.dry || c.rc != OFD_OK || (!cb && !det)) return;
         auto it = u->prange.find(prefix);
-        if (it != u->prange.end()) cb(it->second.first, it->second.second, user);
+        if (it == u->prange.end()) return;
+        // deterministic mode: the range's fixed-point shadow lands in the fp32 gradients before anyone is told they are ready
+        if (det) RUN(k_det_flush(u->d_fx + it->second.first, u->d_grads + it->second.first, it->second.second - it->second.first, c.s));
+        if (cb && c.rc == OFD_OK) cb(it->second.first, it->second.second, user);
     };
     if (!c.dry) {
         if (hipMemsetAsync(u->d_wacc, 0, u->n_wbuf * sizeof(float), c.s) != hipSuccess ||
@@ -355,6 +406,8 @@ static int run_backward(Ctx& c, const float* dout, const TrainLayout& L, float* 
             set_error("unet_backward: memset failed");
             return OFD_ERR_HIP;
         }
+        if (det) RUN(det_begin(c, dts, (size_t)B * dim * 4));
+        if (c.rc != OFD_OK) return c.rc;
     }
     c.begin(PC_MISC, 0, 0, "final_conv bwd");
     RUN(k_final_conv_bwd(u->ts.xf.p, u->P("final_conv.weight"), dout, u->ts.xf.g, u->G("final_conv.weight"), u->G("final_conv.bias"), B, H, W, dim,
@@ -365,7 +418,11 @@ static int run_backward(Ctx& c, const float* dout, const TrainLayout& L, float* 
     for (auto it = u->tape.rbegin(); it != u->tape.rend() && c.rc == OFD_OK; ++it) {
         const TapeRec& r = *it;
         c.reset_scratch();
-        if (!b.has(r.out)) { set_error("unet_backward: no gradient reached %s", r.name.c_str()); return OFD_ERR_STATE; }
+        if (!b.has(r.out)) {
+            set_error("unet_backward: no gradient reached %s", r.name.c_str());
+            if (det) (void)det_end(c);
+            return OFD_ERR_STATE;
+        }
         switch (r.kind) {
             case TK_RES: resblock_backward(b, r, dss, dts); break;
             case TK_LINATTN: linattn_backward(b, r); break;
@@ -381,12 +438,21 @@ static int run_backward(Ctx& c, const float* dout, const TrainLayout& L, float* 
         }
         notify(r.name);
     }
-    if (u->cfg.no_time) return c.rc;
+    if (u->cfg.no_time) {
+        if (det) { RUN(k_det_flush(u->d_fx, u->d_grads, u->n_param_floats, c.s)); const int e = det_end(c); if (c.rc == OFD_OK) c.rc = e; }
+        return c.rc;
+    }
+    if (det) RUN(k_det_flush(u->d_fx + u->n_param_floats + u->n_wbuf, dts, (size_t)B * dim * 4, c.s));      // every block's Linear has added its share
     c.begin(PC_MISC, 0, 0, "time_mlp bwd");
     RUN(k_time_mlp_bwd(u->ts.t, u->ts.temb, dts, u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"), u->P("time_mlp.3.weight"),
                        u->G("time_mlp.1.weight"), u->G("time_mlp.1.bias"), u->G("time_mlp.3.weight"), u->G("time_mlp.3.bias"), tm, B, dim, c.s));
     c.end();
     notify("time_mlp");
+    if (det) {          // whatever no notified range covers, then the context off (also after a failed launch: it is shared)
+        RUN(k_det_flush(u->d_fx, u->d_grads, u->n_param_floats, c.s));
+        const int e = det_end(c);
+        if (c.rc == OFD_OK) c.rc = e;
+    }
     return c.rc;
 }
 
@@ -428,6 +494,19 @@ extern "C" size_t ofd_unet_train_workspace_bytes(ofd_unet* u, int B, int H, int 
     TrainLayout L;
     if (plan(u, B, H, W, L) != OFD_OK) return 0;
     return L.small_b + 2 * L.persist_b + L.scratch_b + 4096;
+}
+
+extern "C" int ofd_unet_set_deterministic(ofd_unet* u, int enabled) {
+    OFD_CHECK_ARG(u, "unet_set_deterministic: null handle");
+    u->deterministic = enabled != 0;
+    return OFD_OK;
+}
+extern "C" long ofd_unet_deterministic_misses(ofd_unet* u) {
+    if (!u) return -1;
+    if (!u->d_det_miss) return 0;
+    unsigned v = 0;
+    if (hipMemcpy(&v, u->d_det_miss, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long)v;
 }
 
 extern "C" size_t ofd_unet_param_floats(const ofd_unet* u) { return u ? u->n_param_floats : 0; }

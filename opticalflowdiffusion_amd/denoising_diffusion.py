@@ -295,6 +295,15 @@ class Unet(nn.Module):
         L.check(L.lib().ofd_unet_set_split_streams(self._handle, -1 if enabled is None else int(bool(enabled)), int(offset_blocks)))
 
     # -- per-kernel-class device timing (HIP events on the launch stream) ----------------------
+    def set_deterministic(self, enabled=True):
+        """order-independent gradient accumulation in the backward (csrc/det.h: 64-bit fixed-point shadows instead of float atomics): two
+        backward passes over the same inputs give bit-identical parameter gradients.  Default: the environment variable OFD_DETERMINISTIC."""
+        L.check(L.lib().ofd_unet_set_deterministic(self._handle, int(enabled)))
+
+    def deterministic_misses(self):
+        """accumulations that found no fixed-point shadow and fell back to float atomics since the handle was created (0 expected)"""
+        return int(L.lib().ofd_unet_deterministic_misses(self._handle))
+
     def set_profiling(self, enabled, dump_path=None):
         L.check(L.lib().ofd_unet_set_profiling(self._handle, int(enabled)))
         L.check(L.lib().ofd_unet_prof_dump_path(self._handle, dump_path.encode() if dump_path else None))

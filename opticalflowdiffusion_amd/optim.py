@@ -34,7 +34,7 @@ class FusedAdam(torch.optim.Optimizer):
         tab = dict(key=key,
                    table=torch.frombuffer(bytearray(b"".join(rows)), dtype=torch.uint8).to(dev),
                    tt=torch.tensor(tt, dtype=torch.int32, device=dev), tc=torch.tensor(tc, dtype=torch.int32, device=dev),
-                   acc=torch.zeros(1, dtype=torch.float64, device=dev), coef=torch.ones(1, dtype=torch.float32, device=dev),
+                   acc=torch.zeros(len(tt) + 1, dtype=torch.float64, device=dev), coef=torch.ones(1, dtype=torch.float32, device=dev),
                    norm=torch.zeros(1, dtype=torch.float32, device=dev), n=len(tt))
         self._tables[gi] = tab
         return tab

@@ -148,7 +148,7 @@ class _NanMseMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target):
         p, t = L.f32c(pred).reshape(-1), L.f32c(target).reshape(-1)
-        res = torch.empty(2, dtype=torch.float64, device=p.device)
+        res = torch.empty(L.lib().ofd_nan_mse_result_doubles(), dtype=torch.float64, device=p.device)     # [0] sum, [1] count, scratch
         L.check(L.lib().ofd_nan_mse_sum(L.ptr(p), L.ptr(t), p.numel(), L.ptr(res), L.stream()))
         ctx.save_for_backward(p, t, res)
         ctx.shape = pred.shape
@@ -171,7 +171,7 @@ class _NanSqSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target):
         p, t = L.f32c(pred).reshape(-1), L.f32c(target).reshape(-1)
-        res = torch.empty(2, dtype=torch.float64, device=p.device)
+        res = torch.empty(L.lib().ofd_nan_mse_result_doubles(), dtype=torch.float64, device=p.device)     # [0] sum, [1] count, scratch
         L.check(L.lib().ofd_nan_mse_sum(L.ptr(p), L.ptr(t), p.numel(), L.ptr(res), L.stream()))
         ctx.save_for_backward(p, t)
         ctx.shape = pred.shape

@@ -387,6 +387,44 @@ def test_unet_training_step_gradients(L, B, H, W):
     assert cos > 0.999, cos
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 32, 48), (3, 24, 104)])
+def test_unet_backward_deterministic_mode_is_bit_reproducible(L, B, H, W):
+    """ofd_unet_set_deterministic (csrc/det.h): every cross-workgroup gradient accumulation of the backward goes through a fixed-point shadow
+    (integer atomics: order-independent).  Three forward + backward passes over the same inputs give BIT-identical parameter gradients (all
+    276 tensors), no accumulation missed its shadow, and the gradients agree with the default (float-atomic) mode to fp32 rounding of the
+    sums -- the two modes add the same partials."""
+    from opticalflowdiffusion_amd import Unet
+    from opticalflowdiffusion_amd.warp import nan_mse
+    torch.manual_seed(11)
+    net = Unet(64, channels=5, out_dim=2).cuda()
+    x = torch.randn(B, 2, H, W).cuda()
+    cond = (torch.rand(B, 3, H, W) * 2 - 1).cuda()
+    t = torch.tensor([17, 803, 400][:B]).cuda()
+    target = torch.randn(B, 2, H, W).cuda()
+
+    def grads():
+        for p in net.parameters():
+            p.grad = None
+        loss = nan_mse(net(x, external_cond=cond, time=t), target)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+
+    _, g_default = grads()
+    net.set_deterministic(True)
+    runs = [grads() for _ in range(3)]
+    assert net.deterministic_misses() == 0
+    for l, g in runs[1:]:
+        assert l == runs[0][0]
+        assert torch.equal(g, runs[0][1]), f"{int((g != runs[0][1]).sum())} of {g.numel()} gradient elements differ between two deterministic runs"
+    assert torch.isfinite(runs[0][1]).all()
+    err = (runs[0][1] - g_default).norm() / g_default.norm()
+    assert err < 1e-5, err
+    net.set_deterministic(False)
+    _, g_again = grads()
+    assert (g_again - g_default).norm() / g_default.norm() < 1e-5
+
+
 def test_regression_unet_time_in_false_forward_and_gradients(L):
     """Unet(64, channels=6, out_dim=3, time_in=False): no time MLP, ResnetBlocks without scale/shift (DD:192-208).  Forward on the
     oracle in the engine's bf16c contract and every parameter gradient against oracle autograd (the oracle itself is pinned to the

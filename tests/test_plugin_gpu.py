@@ -171,6 +171,42 @@ def test_flow_diffuser_training_steps_reduce_the_loss():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in fd.unet.parameters())
 
 
+def test_flow_diffuser_training_is_bit_reproducible_in_deterministic_mode():
+    """two training runs from the same seed -- GPU augmentation (fixed-point gray means), q_sample, UNet training forward, nan_mse (ordered
+    partial sums), backward in deterministic mode (csrc/det.h: fixed-point gradient accumulation), gradient-norm clip (ordered partial sums)
+    and Adam -- give the same losses and the same parameters after six steps, BIT for bit; no accumulation missed its shadow."""
+    from opticalflowdiffusion_amd import FlowDiffuser
+    H, W, B = 40, 72, 3
+
+    def run():
+        torch.manual_seed(0)
+        fd = FlowDiffuser(dict(target="flow", image_size=[H, W], timesteps=50, flow_max=20, zero_init=False, lr=2e-4, weight_decay=1e-4,
+                               gradient_clip_val=0.5)).cuda()
+        fd.log_dict = lambda *a, **k: None
+        fd.unet.set_deterministic(True)
+        opt = fd.configure_optimizers()
+        g = torch.Generator(device="cuda").manual_seed(5)
+        img = torch.rand(B, 3, H, W, device="cuda", generator=g)
+        tgt = torch.rand(B, 3, H, W, device="cuda", generator=g)
+        flow = torch.clamp(torch.randn(B, 2, H, W, device="cuda", generator=g) * 8, -20, 20)
+        losses = []
+        for it in range(6):
+            loss = fd.training_step((img, tgt, flow), it)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        assert fd.unet.deterministic_misses() == 0
+        return torch.stack(losses), torch.cat([p.detach().flatten() for p in fd.unet.parameters()]).clone()
+
+    l1, p1 = run()
+    l2, p2 = run()
+    assert torch.isfinite(l1).all() and torch.isfinite(p1).all()
+    assert torch.equal(l1, l2), (l1, l2)
+    assert torch.equal(p1, p2), f"{int((p1 != p2).sum())} of {p1.numel()} parameters differ after six steps"
+
+
 def test_trajectory_stride_keeps_strided_frames_only():
     """optional `trajectory_stride`: x_T, every k-th step and the final sample; the kept frames equal those of the full trajectory"""
     from opticalflowdiffusion_amd import FlowDiffuser

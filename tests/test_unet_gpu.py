@@ -204,10 +204,12 @@ def test_conv3x3_concat_prologue_upsample_epilogues(L):
     check_close(from_nhwc(out), ref2, what="residual")
 
 
-@pytest.mark.parametrize("B,H,W,grid", [(2, 10, 48, 0), (2, 12, 64, 0), (3, 6, 128, 5), (2, 16, 192, 3)])
+@pytest.mark.parametrize("B,H,W,grid", [(2, 10, 48, 0), (3, 9, 37, 4), (1, 135, 240, 0), (2, 12, 64, 0), (3, 6, 128, 5), (2, 16, 192, 3)])
 def test_conv1x1_variants(L, B, H, W, grid, monkeypatch):
-    """(10, 48): the shared-slab kernel; the others have H*W % 128 == 0 and W % 64 == 0 and take the streaming kernel of
-    conv1_wp.hip where it serves the shape -- with `grid` workgroups, so that each walks several tiles and crosses samples."""
+    """the streaming kernel of conv1_wp.hip where it serves the shape -- with `grid` workgroups, so that each walks several tiles and
+    crosses samples.  (10, 48), (9, 37) and (135, 240: the coarsest level of 1080p) have H*W % tile != 0 for some or all of the tile sizes
+    (128 / 64 / 32 pixels by input width): the last tile of a sample overlaps the one before it; their Downsample (W % tile != 0) and
+    planes smaller than a tile take the shared-slab kernel.  The others have H*W % 128 == 0 and W % 64 == 0."""
     if grid:
         monkeypatch.setenv("OFD_CONV1_GRID", str(grid))
     torch.manual_seed(2)
