@@ -77,6 +77,11 @@ struct Params {
     const float* fc_b;
     float* fc_out;
     int interleave;            // 1: workgroup w walks tiles w, w + G, ... (the resident workgroups sweep ONE moving window of memory); 0: a contiguous range each
+    // 1-D grid of gx * nb workgroups (gx tile walkers x nb output-channel blocks), channel block fastest and the nb blocks of a walker on ONE
+    // XCD (workgroup i runs on XCD i % 8): the walker's input tile comes from HBM once and from that XCD's L2 for the other blocks, and every
+    // workgroup is resident from the start.  (The 2-D grid ran the channel blocks one after the other: 768 -> 512 at 55 x 128 read its
+    // input four times, in four rounds of workgroups.)  gx is a multiple of 8 or nb == 1.
+    int gx, nb;
 };
 
 // NSG: 32-channel slices per workgroup (output block = 32 NSG channels), CIN, TILE pixels per step, RA: fused SiLU(affine(h2)) input,
@@ -98,7 +103,13 @@ __global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int ns = wave % NSG, pg = wave / NSG;
-    const int n0 = P.cout0 + blockIdx.y * 32 * NSG * NCB, cb = n0 + 32 * ns;    // (block k of this workgroup: cb + 32 NSG k)
+    int wx = (int)blockIdx.x, wy = 0;                                 // tile walker, output-channel block
+    if (P.nb > 1) {
+        const int xcd = wx & 7, j = wx >> 3;
+        wy = j % P.nb;
+        wx = (j / P.nb) * 8 + xcd;
+    }
+    const int n0 = P.cout0 + wy * 32 * NSG * NCB, cb = n0 + 32 * ns;    // (block k of this workgroup: cb + 32 NSG k)
 
     // ---- weights: this wave's A fragments, for good
     bf16x8 wf[NCB][KS];
@@ -172,9 +183,9 @@ __global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel
     // tile walk: interleaved (t = w, w + G, ...) keeps the ~500 resident workgroups inside one moving window of a few MB -- DRAM pages
     // are streamed through once; contiguous per-workgroup ranges spread them over the whole tensor (measured 20 % slower on the
     // same pattern in resblock_out).  The price: the sample index changes every plane / TILE / G tiles instead of once or twice.
-    const int t_step = P.interleave ? (int)gridDim.x : 1;
-    int t = P.interleave ? (int)blockIdx.x : (int)(((long)blockIdx.x * P.ntiles) / gridDim.x);
-    const int t_end = P.interleave ? P.ntiles : (int)(((long)(blockIdx.x + 1) * P.ntiles) / gridDim.x);
+    const int t_step = P.interleave ? P.gx : 1;
+    int t = P.interleave ? wx : (int)(((long)wx * P.ntiles) / P.gx);
+    const int t_end = P.interleave ? P.ntiles : (int)(((long)(wx + 1) * P.ntiles) / P.gx);
     if (t >= t_end) return;
     int b_cur = -1;
     float4 sc4[RA ? 4 : 1], sh4[RA ? 4 : 1];
@@ -333,10 +344,28 @@ static int launch(const Params& P, hipStream_t s) {
         attr = true;
     }
     const int per_cu = (LDS * 2 <= 160 * 1024) ? 2 : 1;
+    const int nb = (P.Cout - P.cout0) / (32 * NSG * NCB);
     int gx = 256 * per_cu;
+    // several channel blocks: all of them resident at once, walkers in whole groups of 8 (one per XCD); OFD_CONV1_NB_ROUNDS=1: a full set of
+    // walkers per channel block as before (nb rounds of workgroups)
+    static const int nb_rounds = getenv("OFD_CONV1_NB_ROUNDS") ? atoi(getenv("OFD_CONV1_NB_ROUNDS")) : 0;
+    if (nb > 1 && !nb_rounds) gx = (gx / nb) / 8 * 8;
     if (const char* e = getenv("OFD_CONV1_GRID")) gx = atoi(e) > 0 ? atoi(e) : gx;       // diagnostics / tests: long tile ranges on small inputs
     if (gx > P.ntiles) gx = P.ntiles;
-    conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB, FC><<<dim3(gx, (P.Cout - P.cout0) / (32 * NSG * NCB)), NTHREADS, LDS, s>>>(P);
+    if (nb > 1 && gx > 8) gx = gx / 8 * 8;
+    Params Q = P;
+    Q.gx = gx;
+    Q.nb = (nb > 1 && gx % 8 == 0) ? nb : 1;
+    if (nb > 1 && Q.nb == 1) {              // fewer than 8 walkers (tiny inputs, OFD_CONV1_GRID): the 2-D form, one channel block per launch row
+        for (int k = 0; k < nb; ++k) {
+            Params R = Q;
+            R.cout0 = P.cout0 + k * 32 * NSG * NCB;
+            conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB, FC><<<gx, NTHREADS, LDS, s>>>(R);
+        }
+        OFD_LAUNCH_CHECK();
+        return OFD_OK;
+    }
+    conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB, FC><<<gx * Q.nb, NTHREADS, LDS, s>>>(Q);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
