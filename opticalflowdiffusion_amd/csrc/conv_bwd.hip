@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad1_wide_kernel(const WgradPar
     __shared__ __attribute__((aligned(16))) unsigned char xs[WQ_PX * 128];
     __shared__ __attribute__((aligned(16))) unsigned char ys[WQ_PX * YP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
-    const int kc = blockIdx.y;
+    const int kc = blockIdx.y, zc = blockIdx.z * CO;             // this workgroup's ci block; first of its CO output channels (Cout = 512: two column blocks of 256)
     const int cw = WCO == 4 ? wave : wave >> 1, a0 = WCO == 4 ? 0 : wave & 1;
     int si = 0, first = 0;
     while (si + 1 < P.n_src && kc >= first + P.src[si].chunks) { first += P.src[si].chunks; ++si; }
@@ -299,35 +299,45 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad1_wide_kernel(const WgradPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.0f;
     const size_t ntiles = (npix + WQ_PX - 1) / WQ_PX;
-    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // the tiles are pure traffic (24 KB staged for 8 MFMAs per wave at Cout = 128): the loads of tile t + G are issued before the MFMAs of tile t
+    // and land while they and the next barrier pair run (r04: without the prefetch the loads were in flight only part of the time -- 192 -> 128 at
+    // half resolution ran at 1.8 TB/s)
+    u32x4 xr[2], yr[YPT];
+    unsigned okm = 0;                   // bit i: xr[i] is a pixel of the tensor, bit 2 + i: yr[i] -- applied when the registers are written to LDS (a select
+                                        // right behind each load made the compiler wait for it: ten serial round trips per tile)
+    auto load_tile = [&](size_t t) {
         const size_t p0 = t * WQ_PX;
-        u32x4 xr[2], yr[YPT];
+        okm = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {                     // X tile: 64 pixels x 8 units
             const int u = tid + i * 256, p = u >> 3, c8 = u & 7;
             const size_t gp = min(p0 + p, npix - 1);
             xr[i] = *(const u32x4*)(x + gp * x_stride + c8 * 8);
-            if (p0 + p >= npix) xr[i] = u32x4{0u, 0u, 0u, 0u};
+            okm |= (p0 + p < npix ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < YPT; ++i) {                   // dY tile: 64 pixels x CO / 8 units
             const int u = tid + i * 256, p = u / YU, c8 = u - p * YU;
             const size_t gp = min(p0 + p, npix - 1);
-            yr[i] = *(const u32x4*)(P.dy + gp * CO + c8 * 8);
-            if (p0 + p >= npix) yr[i] = u32x4{0u, 0u, 0u, 0u};
+            yr[i] = *(const u32x4*)(P.dy + gp * P.Cout + zc + c8 * 8);
+            okm |= (p0 + p < npix ? 1u : 0u) << (2 + i);
         }
+    };
+    if (blockIdx.x < ntiles) load_tile(blockIdx.x);
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         __syncthreads();                                  // previous tile's fragment reads are complete
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int u = tid + i * 256;
-            *(u32x4*)(xs + (u >> 3) * 128 + (u & 7) * 16) = xr[i];
+            *(u32x4*)(xs + (u >> 3) * 128 + (u & 7) * 16) = ((okm >> i) & 1u) ? xr[i] : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int i = 0; i < YPT; ++i) {
             const int u = tid + i * 256, p = u / YU, c8 = u - p * YU;
-            *(u32x4*)(ys + p * YP + c8 * 16) = yr[i];
+            *(u32x4*)(ys + p * YP + c8 * 16) = ((okm >> (2 + i)) & 1u) ? yr[i] : u32x4{0u, 0u, 0u, 0u};
         }
         __syncthreads();
+        if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);
         if (do_bias && tid < CO) {
 #pragma unroll 8
             for (int p = 0; p < WQ_PX; ++p) bsum += bf2f(*(const bf16_t*)(ys + p * YP + tid * 2));
@@ -346,16 +356,16 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad1_wide_kernel(const WgradPar
                     acc[a][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[a], yf[j], acc[a][j], 0, 0, 0);   // rows = ci, cols = co
         }
     }
-    if (do_bias && tid < CO) gacc_add(P.dbias + tid, bsum);
+    if (do_bias && tid < CO) gacc_add(P.dbias + zc + tid, bsum);
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            float* d = P.dw + ((size_t)kc * 64 + (a0 + a) * 32) * CO + cw * SPAN + j * 32 + l31;
+            float* d = P.dw + ((size_t)kc * 64 + (a0 + a) * 32) * P.Cout + zc + cw * SPAN + j * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = (r & 3) + 8 * (r >> 2) + 4 * half;
-                gacc_add(d + (size_t)ci * CO, acc[a][j][r]);
+                gacc_add(d + (size_t)ci * P.Cout, acc[a][j][r]);
             }
         }
 }
@@ -366,10 +376,10 @@ static void launch_wgrad1_wide(const WgradParams& P, size_t npix, int ncib, hipS
     // (full-resolution res_conv 128 -> 64: 0.76 / 0.61 / 0.66 ms at 512 / 1024 / 2048; 256 -> 128 at half resolution: 0.355 / 0.378 / 0.343)
     static const int total_env = getenv("OFD_WGRAD1_WIDE_WGS") ? atoi(getenv("OFD_WGRAD1_WIDE_WGS")) : 0;
     const int total = total_env > 0 ? total_env : (CO == 64 ? 1024 : 512);
-    int g = cdiv(total, ncib);
+    int g = cdiv(total, ncib * (P.Cout / CO));
     const size_t nt = (npix + WQ_PX - 1) / WQ_PX;
     if ((size_t)g > nt) g = (int)nt;
-    conv_wgrad1_wide_kernel<CO, WCO><<<dim3(g, ncib), 256, 0, s>>>(P, npix);
+    conv_wgrad1_wide_kernel<CO, WCO><<<dim3(g, ncib, P.Cout / CO), 256, 0, s>>>(P, npix);
 }
 
 // 3x3: all nine taps in one workgroup.  grid (pixel-tile groups, (Cin/64)*(Cout/64)); 4 waves, wave -> 32 ci x 32 co x 9 taps
@@ -1058,7 +1068,7 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
         return OFD_OK;
     }
     static const bool no_wide = getenv("OFD_NO_WGRAD1_WIDE") && atoi(getenv("OFD_NO_WGRAD1_WIDE"));
-    if (a->ksize == 1 && !no_wide && !P.in_scale && (a->Cout == 64 || a->Cout == 128 || a->Cout == 192 || a->Cout == 256)) {
+    if (a->ksize == 1 && !no_wide && !P.in_scale && (a->Cout == 64 || a->Cout == 128 || a->Cout == 192 || a->Cout == 256 || a->Cout == 512)) {
         bool plain = true;
         for (int i = 0; i < a->n_src; ++i) plain = plain && P.src[i].mode == 0;
         if (plain) {
@@ -1067,7 +1077,7 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
             if (a->Cout == 64) launch_wgrad1_wide<64, 2>(P, npix, ncib, s);
             else if (a->Cout == 128) launch_wgrad1_wide<128, 4>(P, npix, ncib, s);
             else if (a->Cout == 192) launch_wgrad1_wide<192, 2>(P, npix, ncib, s);
-            else launch_wgrad1_wide<256, 4>(P, npix, ncib, s);
+            else launch_wgrad1_wide<256, 4>(P, npix, ncib, s);          // (Cout = 512: two column blocks of 256 per ci block)
             OFD_LAUNCH_CHECK();
             return OFD_OK;
         }

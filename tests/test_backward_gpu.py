@@ -78,12 +78,15 @@ def test_conv3x3_backward(L, B, H, W, Cin, Cout):
     assert rel_l2(out.cpu(), dy.sum(dim=(0, 2, 3))) < 1e-3
 
 
-@pytest.mark.parametrize("Cout,cins", [(64, (64, 64)), (128, (128, 128)), (192, (192, 192)), (256, (256, 256)), (64, (128,)), (256, (64,))])
-def test_conv1x1_weight_gradient_wide_kernel(L, Cout, cins, monkeypatch):
+@pytest.mark.parametrize("Cout,cins,B,H,W", [(64, (64, 64), 2, 13, 21), (128, (128, 128), 2, 13, 21), (192, (192, 192), 2, 13, 21), (256, (256, 256), 2, 13, 21),
+                                             (64, (128,), 2, 13, 21), (256, (64,), 2, 13, 21), (512, (512, 256), 2, 13, 21), (512, (128,), 1, 9, 7),
+                                             (128, (128, 64), 3, 40, 56)])
+def test_conv1x1_weight_gradient_wide_kernel(L, Cout, cins, B, H, W, monkeypatch):
     """res_conv / to_out.0 shapes (DD:212, DD:226): the kernel that owns a ci block and ALL output channels (conv_wgrad1_wide_kernel), over
-    one or two concatenated sources and a pixel count that is not a multiple of its 64-pixel tile; against autograd."""
+    one or two concatenated sources and a pixel count that is not a multiple of its 64-pixel tile; Cout = 512 (ups.0's res_conv, the mid
+    attention's to_out) as two 256-channel column blocks; (3, 40, 56): several tiles per workgroup, so the register prefetch of the next
+    tile runs; against autograd."""
     torch.manual_seed(7)
-    B, H, W = 2, 13, 21
     xs = [q(torch.randn(B, c, H, W)).requires_grad_(True) for c in cins]
     cin = sum(cins)
     w = (torch.randn(Cout, cin, 1, 1) / math.sqrt(cin)).requires_grad_(True)
