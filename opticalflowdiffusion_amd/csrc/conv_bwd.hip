@@ -215,6 +215,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad1_qkv_kernel(const bf16_t* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][j][r] = 0.0f;
     const size_t ntiles = (npix + WQ_PX - 1) / WQ_PX;
+    // (r04: the cross-tile register prefetch that helped conv_wgrad1_wide_kernel measured SLOWER here -- 128 -> 384 at half resolution 0.376 -> 0.514 ms,
+    // and 0.459 with the loads in the loop but the out-of-range selects moved to the LDS write: the kernel is left as it was)
     for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const size_t p0 = t * WQ_PX;
         u32x4 xr[2], yr[12];
