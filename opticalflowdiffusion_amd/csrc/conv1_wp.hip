@@ -82,6 +82,15 @@ struct Params {
     // workgroup is resident from the start.  (The 2-D grid ran the channel blocks one after the other: 768 -> 512 at 55 x 128 read its
     // input four times, in four rounds of workgroups.)  gx is a multiple of 8 or nb == 1.
     int gx, nb;
+    // PL instantiations (data gradients, the mid attention's to_out): the epilogue input is a PLAIN residual (out = W x + b + r) and the output /
+    // residual may be split between two tensors -- channels [0, split) in out / res_act with pixel stride `split`, [split, Cout) in out2 / res2
+    // with stride Cout - split (split = 0: one tensor of stride Cout).  A side without a residual reads `zero64` (64 bytes of zeros, stride 0):
+    // every wave issues the same number of loads per tile, which the hand-counted waits depend on.  out may BE the residual (in-place
+    // accumulation): a pixel's residual is read one tile before that pixel is written, by the same wave.
+    const bf16_t* res2;
+    bf16_t* out2;
+    int split;
+    const bf16_t* zero64;
 };
 
 // NSG: 32-channel slices per workgroup (output block = 32 NSG channels), CIN, TILE pixels per step, RA: fused SiLU(affine(h2)) input,
@@ -90,7 +99,7 @@ struct Params {
 // with the two weight rows, one v_permlane32_swap + add joins the lane halves (lanes 0-31 end with channel 0's partial, 32-63 with
 // channel 1's), and ONE float atomic per fragment adds it to the zeroed fp32 output (the other 32-channel wave adds the second addend:
 // two addends onto zero, any order, same sum).  The 922 MB bf16 tensor between the two convs is neither written nor read.
-template <int NSG, int CIN, int TILE, bool RA, int NCB = 1, bool FC = false>
+template <int NSG, int CIN, int TILE, bool RA, int NCB = 1, bool FC = false, bool PL = false>
 __global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel(const Params P) {      // (768 input channels: 192 weight registers per wave, one wave per SIMD)
     constexpr int KS = CIN / 16, UNITS = CIN / 64, UNITB = TILE * 128, BUFB = UNITS * UNITB;
     constexpr int PG = 4 / NSG, F = (TILE / 32) / PG;                 // pixel groups of waves, 32-pixel fragments per wave
@@ -99,6 +108,7 @@ __global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel
     static_assert(!FC || (NCB == 1 && NSG == 2), "FC: two 32-channel waves per pixel");
     static_assert(TILE % 32 == 0 && (TILE / 32) % PG == 0 && BUFB % 4096 == 0, "tile shape");
     static_assert(!(RA && NCB > 1) && NRA + NST <= 63, "the fused epilogue input is for single-block launches; vmcnt is 6 bits");
+    static_assert(!PL || (RA && !FC), "PL: the plain-residual form of the fused epilogue input");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
@@ -164,7 +174,21 @@ __global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel
             __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(smem + buf * BUFB + u * UNITB + rb * 1024), 16, 0, 0);
         }
     };
-    // h2 of the wave's pixels, one tile ahead, through loads the compiler does not count
+    // this wave's 32-channel slice of the output and of the epilogue input: tensor, pixel stride, first channel inside it (PL: either side of a
+    // split; a side without a residual reads the zero block at stride 0)
+    bf16_t* o_base = P.out;
+    const bf16_t* r_base = P.res_act;
+    int o_stride = P.Cout, o_c0 = cb, r_stride = P.Cout, r_c0 = cb;
+    if constexpr (PL) {
+        const bool second = P.split > 0 && cb >= P.split;
+        o_base = second ? P.out2 : P.out;
+        o_stride = P.split > 0 ? (second ? P.Cout - P.split : P.split) : P.Cout;
+        o_c0 = cb - (second ? P.split : 0);
+        r_base = second ? P.res2 : P.res_act;
+        r_stride = o_stride; r_c0 = o_c0;
+        if (!r_base) { r_base = P.zero64; r_stride = 0; r_c0 = 0; }
+    }
+    // h2 (PL: the residual) of the wave's pixels, one tile ahead, through loads the compiler does not count
     u4 ra[RA ? NRA : 1];
     auto issue_ra = [&](int t) {
         if constexpr (RA) {
@@ -174,7 +198,7 @@ __global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel
             for (int f = 0; f < F; ++f)
 #pragma unroll
                 for (int gi = 0; gi < 2; ++gi) {
-                    const bf16_t* p = P.res_act + (gp0 + (pg * F + f) * 32 + l31) * P.Cout + cb + 16 * gi + 8 * half;
+                    const bf16_t* p = r_base + (gp0 + (pg * F + f) * 32 + l31) * (size_t)r_stride + r_c0 + 16 * gi + 8 * half;
                     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[f * 2 + gi]) : "v"(p) : "memory");
                 }
         }
@@ -253,7 +277,7 @@ __global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel
         });
 
         // ---- epilogue: bias, + SiLU(affine(h2)), bf16, 16-byte stores (one v_permlane32_swap per dword pairs two register quads)
-        if constexpr (RA) {
+        if constexpr (RA && !PL) {
             if (b != b_cur) {                                // (ordinary loads: the compiler's wait drains the queue -- once per sample)
                 b_cur = b;
 #pragma unroll
@@ -286,7 +310,12 @@ __global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float v[4] = {acc[f][4 * g] + bias4[g].x, acc[f][4 * g + 1] + bias4[g].y, acc[f][4 * g + 2] + bias4[g].z, acc[f][4 * g + 3] + bias4[g].w};
-                if constexpr (RA) {
+                if constexpr (PL) {
+                    v[0] += bf2f((bf16_t)(rq[g].x & 0xffffu));
+                    v[1] += bf2f((bf16_t)(rq[g].x >> 16));
+                    v[2] += bf2f((bf16_t)(rq[g].y & 0xffffu));
+                    v[3] += bf2f((bf16_t)(rq[g].y >> 16));
+                } else if constexpr (RA) {
                     const float4 sc = sc4[g], sh = sh4[g];
                     v[0] += silu_f(bf2f((bf16_t)(rq[g].x & 0xffffu)) * sc.x + sh.x);
                     v[1] += silu_f(bf2f((bf16_t)(rq[g].x >> 16)) * sc.y + sh.y);
@@ -322,7 +351,7 @@ __global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel
             for (int g = 0; g < 4; g += 2) {
                 const auto rx = __builtin_amdgcn_permlane32_swap(qout[f][g].x, qout[f][g + 1].x, false, false);
                 const auto ry = __builtin_amdgcn_permlane32_swap(qout[f][g].y, qout[f][g + 1].y, false, false);
-                *(uint4*)(P.out + pix * P.Cout + cb + 32 * NSG * cbk + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                *(uint4*)(o_base + pix * (size_t)o_stride + o_c0 + 32 * NSG * cbk + 8 * g + 8 * half) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
             }
         }
         }
@@ -335,12 +364,12 @@ __global__ void __launch_bounds__(NTHREADS, CIN > 512 ? 1 : 2) conv1x1_wp_kernel
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NSG, int CIN, int TILE, bool RA, int NCB = 1, bool FC = false>
+template <int NSG, int CIN, int TILE, bool RA, int NCB = 1, bool FC = false, bool PL = false>
 static int launch(const Params& P, hipStream_t s) {
     constexpr int LDS = 2 * (CIN / 64) * TILE * 128;
     static bool attr = false;
     if (!attr) {
-        OFD_HIP(hipFuncSetAttribute((const void*)conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB, FC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        OFD_HIP(hipFuncSetAttribute((const void*)conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB, FC, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
     const int per_cu = (LDS * 2 <= 160 * 1024) ? 2 : 1;
@@ -360,12 +389,12 @@ static int launch(const Params& P, hipStream_t s) {
         for (int k = 0; k < nb; ++k) {
             Params R = Q;
             R.cout0 = P.cout0 + k * 32 * NSG * NCB;
-            conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB, FC><<<gx, NTHREADS, LDS, s>>>(R);
+            conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB, FC, PL><<<gx, NTHREADS, LDS, s>>>(R);
         }
         OFD_LAUNCH_CHECK();
         return OFD_OK;
     }
-    conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB, FC><<<gx * Q.nb, NTHREADS, LDS, s>>>(Q);
+    conv1x1_wp_kernel<NSG, CIN, TILE, RA, NCB, FC, PL><<<gx * Q.nb, NTHREADS, LDS, s>>>(Q);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -375,22 +404,31 @@ static int launch(const Params& P, hipStream_t s) {
 // returns 1 when the shape is not one this kernel serves (the caller falls back to conv_igemm.hip), else the launch status
 int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
     using namespace c1;
-    if (C.in_scale || C.residual || C.gn_partial || C.split || C.out2) return 1;
+    if (C.in_scale || C.gn_partial) return 1;
+    // plain residual(s) and / or a split output (the 1x1 data gradients of the training backward, the mid attention's to_out): the PL instantiations
+    const char* e_pl = getenv("OFD_CONV1_NO_PL");          // read per call (A/B switch): 1 = these go to the shared-slab kernel as before
+    const bool no_pl = e_pl && atoi(e_pl);
+    const bool pl = (C.residual || C.residual2 || C.split > 0) && !C.res_act;
+    if (!pl && (C.residual || C.residual2 || C.split || C.out2)) return 1;
+    if (pl && (no_pl || C.fc_out || C.residual_b || C.pool2 || C.cout0 || (C.split > 0 && (!C.out2 || C.split % 32 != 0 || C.split >= C.Cout)))) return 1;
     if (C.res_act && !(C.res_scale && C.res_shift)) return 1;
     const int cin = C.Cin_total, plane = C.H * C.W;
     const bool ra = C.res_act != nullptr;
-    if (cin % 64 != 0 || (cin > 384 && !(cin == 512 && !ra) && !(cin == 768 && ra)) || cin == 320 || (cin < 128 && !(cin == 64 && C.Cout == 384 && !ra && !C.bias)) || (C.Cout != 64 && C.Cout % 128 != 0)) return 1;
+    if (pl) {
+        const bool wide_ok = C.Cout % 128 == 0;
+        if (!((cin == 64 && wide_ok) || (cin == 128 && C.Cout % 64 == 0) || (cin == 256 && wide_ok) || (cin == 512 && wide_ok))) return 1;
+    } else if (cin % 64 != 0 || (cin > 384 && !(cin == 512 && !ra) && !(cin == 768 && ra)) || cin == 320 || (cin < 128 && !(cin == 64 && C.Cout == 384 && !ra && !C.bias)) || (C.Cout != 64 && C.Cout % 128 != 0)) return 1;
     const int tile = (cin <= 128) ? 128 : (cin >= 384 ? 32 : 64);
     if (plane < tile || (size_t)C.B * plane * (size_t)(C.Cout > cin ? C.Cout : cin) * 2 >= (1ull << 40)) return 1;
     const bool ragged = plane % tile != 0;                        // the last tile of a sample overlaps the one before it (see the header)
-    if (ragged && (C.fc_out || (const bf16_t*)C.out == C.res_act)) return 1;
+    if (ragged && (C.fc_out || (const bf16_t*)C.out == C.res_act || (pl && (C.out == C.residual || (C.out2 && C.out2 == C.residual2))))) return 1;
     Params P{};
     int nu = 0;
     for (int i = 0; i < C.n_src; ++i) {
         const ConvSrcDev& S = C.src[i];
         if (S.mode == 1) return 1;
         if (S.mode == 2 && (C.W % tile != 0)) return 1;
-        if (ragged && (S.mode != 0 || S.ptr == (const bf16_t*)C.out)) return 1;
+        if (ragged && (S.mode != 0 || S.ptr == (const bf16_t*)C.out || (C.out2 && S.ptr == (const bf16_t*)C.out2))) return 1;
         for (int k = 0; k < S.chunks; ++k) {
             if (nu >= 12) return 1;
             Unit& U = P.unit[nu++];
@@ -409,6 +447,21 @@ int launch_conv1x1_wp(const ConvParams& C, hipStream_t s) {
     P.interleave = order;
     const bool narrow = C.Cout == 64;
     P.cout0 = 0;
+    if (pl) {
+        static const bf16_t* zero64 = nullptr;             // 64 bytes of zeros: what a side without a residual reads (stride 0)
+        if (!zero64) {
+            void* z = nullptr;
+            OFD_HIP(hipMalloc(&z, 64));
+            OFD_HIP(hipMemset(z, 0, 64));
+            zero64 = (const bf16_t*)z;
+        }
+        P.res_act = C.residual; P.res2 = C.residual2; P.out2 = C.out2; P.split = C.split; P.zero64 = zero64;
+        P.res_scale = nullptr; P.res_shift = nullptr;
+        if (cin == 64) return launch<4, 64, 128, true, 1, false, true>(P, s);
+        if (cin == 128) return C.Cout % 128 == 0 ? launch<4, 128, 128, true, 1, false, true>(P, s) : launch<2, 128, 128, true, 1, false, true>(P, s);
+        if (cin == 256) return launch<4, 256, 64, true, 1, false, true>(P, s);
+        return launch<4, 512, 32, true, 1, false, true>(P, s);
+    }
     if (cin == 64 && C.cout0 == 128) { P.cout0 = 128; return launch<4, 64, 128, false, 2>(P, s); }      // ... its k and v blocks only (q recomputed downstream)
     if (cin == 64) return launch<4, 64, 128, false, 3>(P, s);                 // to_qkv of the 64-channel LinearAttention (training)
     if (cin == 128 && C.Cout == 384 && !ra && !C.bias) return launch<4, 128, 128, false, 3>(P, s);

@@ -280,6 +280,64 @@ def test_conv1x1_variants(L, B, H, W, grid, monkeypatch):
         check_close(from_nhwc(out), ref, what=f"downsample -> {co}")
 
 
+@pytest.mark.parametrize("B,H,W,cin,Cout,split,res,grid", [(2, 16, 64, 64, 128, 64, (True, False), 0), (3, 12, 64, 128, 192, 128, (True, True), 5),
+                                                         (2, 10, 48, 256, 384, 256, (False, True), 0), (1, 9, 37, 512, 768, 512, (True, False), 0),
+                                                         (2, 8, 32, 128, 512, 0, (True,), 0), (2, 16, 64, 64, 128, 64, (False, False), 16)])
+def test_conv1x1_plain_residual_and_split_outputs(L, B, H, W, cin, Cout, split, res, grid, monkeypatch):
+    """the PL instantiations of conv1x1_wp_kernel (r04: the 1x1 data gradients of the backward and the mid attention's to_out on the streaming
+    kernel): out = W x + residual with the output -- and the residual -- split between two tensors at channel `split`, either side with or
+    without a residual (a side without one reads the zero block), IN PLACE (the residual is the output tensor, as the backward accumulates),
+    pixel counts that are not a multiple of the tile ((10, 48), (9, 37): no in-place there, the host refuses the overlap), `grid` workgroups
+    so that a walker crosses samples.  Against F.conv2d and against the shared-slab kernel (OFD_CONV1_NO_PL=1) on the same inputs."""
+    import os
+    if grid:
+        monkeypatch.setenv("OFD_CONV1_GRID", str(grid))
+    torch.manual_seed(3 + cin)
+    x = q(torch.randn(B, cin, H, W))
+    w = torch.randn(Cout, cin, 1, 1) / math.sqrt(cin)
+    wprep = prep_weight(L, w, 1)
+    widths = [split, Cout - split] if split else [Cout]
+    rs = [q(torch.randn(B, c, H, W)) if r else None for c, r in zip(widths, res)]
+    ref_full = F.conv2d(x, q(w))
+    refs, c0 = [], 0
+    for c, r in zip(widths, rs):
+        refs.append(ref_full[:, c0:c0 + c] + (r if r is not None else 0))
+        c0 += c
+    in_place = (H * W) % 128 == 0
+    xin = to_nhwc(x)
+
+    def run(no_pl):
+        os.environ["OFD_CONV1_NO_PL"] = no_pl
+        outs = [to_nhwc(r).clone() if (r is not None and in_place) else torch.empty(B, H, W, c, dtype=torch.bfloat16, device="cuda") for c, r in zip(widths, rs)]
+        rin = [o if (r is not None and in_place) else (to_nhwc(r) if r is not None else None) for o, r in zip(outs, rs)]
+        a = L.ConvArgs()
+        a.B, a.H, a.W, a.ksize, a.n_src, a.Cout = B, H, W, 1, 1, Cout
+        a.src[0].src = xin.data_ptr(); a.src[0].channels = cin; a.src[0].src_channels = cin
+        a.weight = wprep.data_ptr()
+        a.out = outs[0].data_ptr()
+        a.residual = rin[0].data_ptr() if rin[0] is not None else None
+        if split:
+            a.split = split
+            a.out2 = outs[1].data_ptr()
+            a.residual2 = rin[1].data_ptr() if rin[1] is not None else None
+        L.check(L.lib().ofd_conv_forward(ctypes.byref(a), L.stream()))
+        torch.cuda.synchronize()
+        return [from_nhwc(o) for o in outs]
+
+    old = os.environ.get("OFD_CONV1_NO_PL")
+    try:
+        got, slab = run("0"), run("1")
+    finally:
+        if old is None:
+            os.environ.pop("OFD_CONV1_NO_PL", None)
+        else:
+            os.environ["OFD_CONV1_NO_PL"] = old
+    for g_, s_, r_ in zip(got, slab, refs):
+        check_close(g_, r_, what="streaming 1x1, plain residual / split")
+        check_close(s_, r_, what="shared-slab 1x1, plain residual / split")
+        assert float((g_ - s_).abs().max()) <= 2.0 ** -7 * float(s_.abs().max())      # same products, another fp32 summation order
+
+
 @pytest.mark.parametrize("Cin", [5, 9])
 def test_conv7x7_init(L, Cin):
     torch.manual_seed(3)
