@@ -86,7 +86,18 @@ __global__ void __launch_bounds__(256) block_mlp_kernel(const float* __restrict_
     for (int j = tid; j < d.n_out; j += 256) {
         float a = d.bias[j];
         const float* wr = d.weight + (size_t)j * tdim;
-        for (int k = 0; k < tdim; ++k) a += wr[k] * e[k];
+        if ((tdim & 3) == 0) {               // (a row is 16-byte aligned: 4 weights per load, 8 loads in flight; same summation order)
+#pragma unroll 8
+            for (int k = 0; k < tdim; k += 4) {
+                const float4 w4 = *(const float4*)(wr + k);
+                a += w4.x * e[k];
+                a += w4.y * e[k + 1];
+                a += w4.z * e[k + 2];
+                a += w4.w * e[k + 3];
+            }
+        } else {
+            for (int k = 0; k < tdim; ++k) a += wr[k] * e[k];
+        }
         ss[(size_t)b * ss_stride + d.offset + j] = a;
     }
 }

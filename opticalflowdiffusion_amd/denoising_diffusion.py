@@ -465,16 +465,15 @@ class ConditionalDiffusion(nn.Module):
     def p_sample(self, x, t: int, x_self_cond=None, external_cond=None, additional_tgt=None, noise=None):
         """DD:676-698: network call + one fused kernel for clamp / posterior mean / noise add."""
         b = x.shape[0]
-        bt = torch.full((b,), t, device=x.device, dtype=torch.long)
+        tab = self._sampling_tables(b, x.device)           # rows of per-(T, batch) tables: no fill / gather / exp launches per step
+        bt = tab["t"][t]
         out = self.model_with_condition(x, bt, x_self_cond, external_cond=external_cond, additional_tgt=additional_tgt)
         additional_out = None
         if additional_tgt is not None:
             additional_out = out[:, -1 * additional_tgt.shape[1]:]
             out = L.f32c(out[:, :-1 * additional_tgt.shape[1]])
         x = L.f32c(x)
-        c1 = self.posterior_mean_coef1[bt].contiguous()
-        c2 = self.posterior_mean_coef2[bt].contiguous()
-        sigma = (0.5 * self.posterior_log_variance_clipped[bt]).exp().contiguous()
+        c1, c2, sigma = tab["c1"][t], tab["c2"][t], tab["sigma"][t]
         if t > 0:
             noise = default(noise, lambda: torch.randn_like(x))
         else:
