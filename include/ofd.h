@@ -379,6 +379,16 @@ int ofd_gn_finalize(const float* partial, int B, int H, int W, int C, const floa
  * flips negate the other channel (augmentation.py:37-45), the crop multiplies channel 0 by ch and channel 1 by cw (augmentation.py:47-48). */
 int ofd_augment(const float* img, const float* tgt, const float* flow, const float* params, void* means_ws, float* out_img,
                 float* out_tgt, float* out_flow, int B, int H, int W, int reference_semantics, void* stream);
+/* the (B, 16) table above from (B, 14) uniform draws in [0, 1) (the caller's RNG: torch's device generator in the plugin), one launch:
+ * columns 0, 4, 5, 7, 8, 9 are the decisions u < p (p = 0.4, 0.1, 0.2, 0.3, 0.3, 0.15: augmentation.py:8-35 of the reference), 1-3 = 1 +- 0.1,
+ * 6 = max(u / 2, 0.05), the crop window from RandomResizedCrop's scale (0.8, 1.0) and log-uniform ratio (0.9, 1.1). */
+int ofd_augment_table(const float* uniforms, float* params, int B, void* stream);
+
+/* the four statistics FlowDiffuser.training_step logs for cond and for flow (flow_diffuser.py:218-235: torch.min, torch.max, torch.mean,
+ * torch.mean(torch.std(x, dim=0))) of x (B, n_per_sample) fp32 in one pass: out4 = {min, max, mean, mean over elements of the unbiased standard
+ * deviation across the batch} (device); ws: ofd_batch_stats_ws_doubles() doubles of device scratch (partial sums, added in a fixed order). */
+size_t ofd_batch_stats_ws_doubles(void);
+int ofd_batch_stats(const float* x, int B, size_t n_per_sample, double* ws, float* out4, void* stream);
 
 #ifdef __cplusplus
 }

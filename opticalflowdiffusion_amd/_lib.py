@@ -49,6 +49,9 @@ SIGNATURES = {
     "ofd_splat_bwd_flow": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "ofd_warp_prep": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p]),
     "ofd_augment": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p]),
+    "ofd_augment_table": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "ofd_batch_stats_ws_doubles": (c_size_t, []),
+    "ofd_batch_stats": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p]),
     "ofd_warp_holes": (c_int, [c_void_p] * 2 + [c_int] * 6 + [c_void_p]),
     "ofd_grid_warp_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "ofd_splat_pyramid_workspace_bytes": (c_size_t, [c_int] * 4),

@@ -51,6 +51,11 @@ class Augmentor:
         """(B, 16) table: 0 jitter on, 1 brightness, 2 contrast, 3 saturation, 4 grayscale on, 5 blur on, 6 sigma, 7 h-flip, 8 v-flip,
         9 crop on, 10 oy, 11 ox, 12 ch, 13 cw -- ONE random draw per call, no host synchronisation"""
         u = self._rand((B, 14), device)
+        if u.is_cuda:                                       # the same table in one launch (ofd_augment_table) instead of ~50 tensor ops
+            from . import _lib as L
+            P = torch.empty(B, self.NP, device=device)
+            L.check(L.lib().ofd_augment_table(L.ptr(u), L.ptr(P), B, L.stream()))
+            return P
         P = torch.zeros(B, self.NP, device=device)
         P[:, 0] = (u[:, 0] < 0.4).float()
         P[:, 1:4] = 1.0 + (u[:, 1:4] - 0.5) * 0.2                              # brightness, contrast, saturation in 1 +- 0.1

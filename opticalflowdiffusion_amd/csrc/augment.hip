@@ -125,8 +125,115 @@ __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ 
     }
 }
 
+// The (B, 16) decision table from (B, 14) uniform draws, one thread per sample: what Augmentor.draw (augmentation.py of this package) spells
+// as ~50 tensor operations -- 50 launches of a few microseconds in front of every training step.
+__global__ void __launch_bounds__(64) augment_table_kernel(const float* __restrict__ u, float* __restrict__ P, int B) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float* v = u + (size_t)b * 14;
+    float* o = P + (size_t)b * AUG_NP;
+    o[0] = v[0] < 0.4f ? 1.0f : 0.0f;
+    o[1] = 1.0f + (v[1] - 0.5f) * 0.2f;                      // brightness, contrast, saturation in 1 +- 0.1
+    o[2] = 1.0f + (v[2] - 0.5f) * 0.2f;
+    o[3] = 1.0f + (v[3] - 0.5f) * 0.2f;
+    o[4] = v[4] < 0.1f ? 1.0f : 0.0f;
+    o[5] = v[5] < 0.2f ? 1.0f : 0.0f;
+    o[6] = fmaxf(v[6] * 0.5f, 0.05f);                        // Gaussian sigma
+    o[7] = v[7] < 0.3f ? 1.0f : 0.0f;
+    o[8] = v[8] < 0.3f ? 1.0f : 0.0f;
+    const bool crop = v[9] < 0.15f;
+    const float area = 0.8f + 0.2f * v[10];                  // RandomResizedCrop scale (0.8, 1.0), ratio (0.9, 1.1) log-uniform
+    const float ratio = expf((v[11] * 2.0f - 1.0f) * 0.09531018f);
+    const float ch = fminf(sqrtf(area / ratio), 1.0f), cw = fminf(sqrtf(area * ratio), 1.0f);
+    o[9] = crop ? 1.0f : 0.0f;
+    o[10] = crop ? v[12] * (1.0f - ch) : 0.0f;
+    o[11] = crop ? v[13] * (1.0f - cw) : 0.0f;
+    o[12] = crop ? ch : 1.0f;
+    o[13] = crop ? cw : 1.0f;
+    o[14] = 0.0f;
+    o[15] = 0.0f;
+}
+
+// min, max, mean and mean over the elements of the (unbiased) standard deviation ACROSS the batch of x (B, n): the statistics training_step logs
+// for cond and flow (flow_diffuser.py:218-235 of the reference: torch.min / max / mean / mean(std(x, dim = 0))) in one pass over x.
+// Per-workgroup partials (ws: 4 doubles per workgroup), added in a fixed order by the second kernel.
+constexpr int BS_BLOCKS = 1024;
+__global__ void __launch_bounds__(256) batch_stats_kernel(const float* __restrict__ x, int B, size_t n, double* __restrict__ ws) {
+    float mn = 3.0e38f, mx = -3.0e38f;
+    double sum = 0.0, sd = 0.0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        float s1 = 0.0f;
+        for (int b = 0; b < B; ++b) {
+            const float v = x[(size_t)b * n + e];
+            mn = fminf(mn, v); mx = fmaxf(mx, v);
+            s1 += v;
+        }
+        const float m = s1 / (float)B;
+        float q = 0.0f;
+        for (int b = 0; b < B; ++b) { const float d = x[(size_t)b * n + e] - m; q += d * d; }      // (second read: L2)
+        sum += (double)s1;
+        sd += (double)sqrtf(B > 1 ? q / (float)(B - 1) : __builtin_nanf(""));
+    }
+    __shared__ double r0[256], r1[256];
+    __shared__ float r2[256], r3[256];
+    r0[threadIdx.x] = sum; r1[threadIdx.x] = sd; r2[threadIdx.x] = mn; r3[threadIdx.x] = mx;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            r0[threadIdx.x] += r0[threadIdx.x + k]; r1[threadIdx.x] += r1[threadIdx.x + k];
+            r2[threadIdx.x] = fminf(r2[threadIdx.x], r2[threadIdx.x + k]); r3[threadIdx.x] = fmaxf(r3[threadIdx.x], r3[threadIdx.x + k]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double* o = ws + 4 * (size_t)blockIdx.x;
+        o[0] = r0[0]; o[1] = r1[0]; o[2] = (double)r2[0]; o[3] = (double)r3[0];
+    }
+}
+__global__ void __launch_bounds__(256) batch_stats_total_kernel(const double* __restrict__ ws, int nblocks, int B, size_t n, float* __restrict__ out) {
+    __shared__ double r0[256], r1[256], r2[256], r3[256];
+    double sum = 0.0, sd = 0.0, mn = 3.0e38, mx = -3.0e38;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        sum += ws[4 * i]; sd += ws[4 * i + 1];
+        mn = fmin(mn, ws[4 * i + 2]); mx = fmax(mx, ws[4 * i + 3]);
+    }
+    r0[threadIdx.x] = sum; r1[threadIdx.x] = sd; r2[threadIdx.x] = mn; r3[threadIdx.x] = mx;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            r0[threadIdx.x] += r0[threadIdx.x + k]; r1[threadIdx.x] += r1[threadIdx.x + k];
+            r2[threadIdx.x] = fmin(r2[threadIdx.x], r2[threadIdx.x + k]); r3[threadIdx.x] = fmax(r3[threadIdx.x], r3[threadIdx.x + k]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (float)r2[0];                                // min
+        out[1] = (float)r3[0];                                // max
+        out[2] = (float)(r0[0] / ((double)B * (double)n));    // mean
+        out[3] = (float)(r1[0] / (double)n);                  // mean over elements of the std across the batch
+    }
+}
+
 }  // namespace ofd
 using namespace ofd;
+
+extern "C" int ofd_augment_table(const float* uniforms, float* params, int B, void* stream) {
+    OFD_CHECK_ARG(uniforms && params && B > 0, "augment_table: bad argument");
+    augment_table_kernel<<<(B + 63) / 64, 64, 0, (hipStream_t)stream>>>(uniforms, params, B);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
+
+extern "C" size_t ofd_batch_stats_ws_doubles(void) { return 4 * (size_t)BS_BLOCKS; }
+extern "C" int ofd_batch_stats(const float* x, int B, size_t n_per_sample, double* ws, float* out4, void* stream) {
+    OFD_CHECK_ARG(x && ws && out4 && B > 0 && n_per_sample > 0, "batch_stats: bad argument");
+    size_t g = (n_per_sample + 255) / 256;
+    if (g > BS_BLOCKS) g = BS_BLOCKS;
+    batch_stats_kernel<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(x, B, n_per_sample, ws);
+    batch_stats_total_kernel<<<1, 256, 0, (hipStream_t)stream>>>(ws, (int)g, B, n_per_sample, out4);
+    OFD_LAUNCH_CHECK();
+    return OFD_OK;
+}
 
 extern "C" int ofd_augment(const float* img, const float* tgt, const float* flow, const float* params, void* means_ws, float* out_img,
                            float* out_tgt, float* out_flow, int B, int H, int W, int reference_semantics, void* stream) {

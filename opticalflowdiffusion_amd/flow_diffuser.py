@@ -12,6 +12,7 @@ import torch
 
 from .denoising_diffusion import Unet, ConditionalDiffusion
 from .warp import warp
+from . import _lib as L
 
 try:                                                   # pragma: no cover - not installed in this image
     import pytorch_lightning as pl
@@ -212,16 +213,28 @@ class FlowDiffuser(_Base):
             samples = warp(img, None, flow[:, -1], mode="forward")
         return samples, flow
 
+    @staticmethod
+    def _batch_stats(x):
+        """(min, max, mean, mean(std(x, dim=0))) of a (B, ...) tensor as 0-dim views of one 4-float result: what FD:218-235 logs, in one pass
+        over x (`ofd_batch_stats`) instead of five reductions"""
+        L.require_gpu(x)
+        x = L.f32c(x)
+        ws = torch.empty(L.lib().ofd_batch_stats_ws_doubles(), dtype=torch.float64, device=x.device)
+        out = torch.empty(4, dtype=torch.float32, device=x.device)
+        L.check(L.lib().ofd_batch_stats(L.ptr(x), x.shape[0], x[0].numel(), L.ptr(ws), L.ptr(out), L.stream()))
+        return out[0], out[1], out[2], out[3]
+
     def training_step(self, batch, batch_idx):                              # FD:218-235
         batch = self.preprocess(batch)
         loss = self.loss(*batch)
         tgt, cond, flow = batch
+        with torch.no_grad():
+            c_min, c_max, c_mean, c_std = self._batch_stats(cond)
+            f_min, f_max, f_mean, f_std = self._batch_stats(flow)
         self.log_dict({
             "train/loss": loss,
-            "train/cond_min": torch.min(cond), "train/cond_max": torch.max(cond), "train/cond_mean": torch.mean(cond),
-            "train/cond_std": torch.mean(torch.std(cond, dim=0)),
-            "train/flow_min": torch.min(flow), "train/flow_max": torch.max(flow), "train/flow_mean": torch.mean(flow),
-            "train/flow_std": torch.mean(torch.std(flow, dim=0)),
+            "train/cond_min": c_min, "train/cond_max": c_max, "train/cond_mean": c_mean, "train/cond_std": c_std,
+            "train/flow_min": f_min, "train/flow_max": f_max, "train/flow_mean": f_mean, "train/flow_std": f_std,
         })
         return loss
 

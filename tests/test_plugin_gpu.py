@@ -207,6 +207,29 @@ def test_flow_diffuser_training_is_bit_reproducible_in_deterministic_mode():
     assert torch.equal(p1, p2), f"{int((p1 != p2).sum())} of {p1.numel()} parameters differ after six steps"
 
 
+def test_training_step_logged_statistics_and_the_augmentation_table():
+    """`ofd_batch_stats` (the eight scalars FD:218-235 logs, one pass per tensor) against torch.min / max / mean / mean(std(x, dim=0)), and
+    `ofd_augment_table` (Augmentor.draw on the device: one launch) against the tensor-op form of the same table from the same uniforms."""
+    from opticalflowdiffusion_amd import FlowDiffuser
+    from opticalflowdiffusion_amd.augmentation import Augmentor
+    torch.manual_seed(3)
+    for shape in [(4, 3, 40, 72), (3, 2, 17, 33), (2, 1, 300, 500)]:
+        x = torch.randn(*shape, device="cuda") * 3 + 0.5
+        mn, mx, mean, sd = FlowDiffuser._batch_stats(x)
+        assert float(mn) == float(torch.min(x)) and float(mx) == float(torch.max(x))
+        assert float(mean) == pytest.approx(float(torch.mean(x)), rel=1e-5, abs=1e-6)
+        assert float(sd) == pytest.approx(float(torch.mean(torch.std(x, dim=0))), rel=1e-5)
+    aug = Augmentor(seed=11)
+    B = 257
+    P = aug.draw(B, torch.device("cuda"))                   # the kernel
+    aug2 = Augmentor(seed=11)
+    u = aug2._rand((B, 14), torch.device("cuda"))           # the same uniforms (same seed, same first draw)
+    aug2._rand = lambda shape, device: u.cpu()              # ... through the tensor-op form on the CPU
+    P_ref = aug2.draw(B, torch.device("cpu"))
+    assert P.shape == (B, 16) and torch.equal(P[:, [0, 4, 5, 7, 8, 9, 14, 15]].cpu(), P_ref[:, [0, 4, 5, 7, 8, 9, 14, 15]])
+    assert torch.allclose(P.cpu(), P_ref, rtol=1e-6, atol=1e-7)
+
+
 def test_trajectory_stride_keeps_strided_frames_only():
     """optional `trajectory_stride`: x_T, every k-th step and the final sample; the kept frames equal those of the full trajectory"""
     from opticalflowdiffusion_amd import FlowDiffuser
