@@ -20,7 +20,7 @@ bool conv_residual_b_supported(const ofd_conv_args* a);                         
 // conv backward (conv_bwd.hip)
 int k_wt_transpose(const bf16_t* w, bf16_t* wt, int taps, int Cin, int Cout, hipStream_t s);
 int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_t s, float* dbias = nullptr);
-int k_conv7_wgrad(const bf16_t* x16, const bf16_t* dy, float* dw, int B, int H, int W, hipStream_t s, float* dbias = nullptr);
+int k_conv7_wgrad(const bf16_t* x16, const bf16_t* dy, float* dw, int B, int H, int W, hipStream_t s, float* dbias = nullptr, int channels = 16);
 int k_channel_sum(const bf16_t* dy, float* out, size_t npix, int C, hipStream_t s);
 int k_wgrad_finish(const float* acc, const float* w_raw, float* dst, int Cout, int Cin, int Cin_pad, int ksize, float ws_eps, int unshuffle,
                    int accumulate, hipStream_t s);

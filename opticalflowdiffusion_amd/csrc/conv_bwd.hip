@@ -764,49 +764,54 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad3_db_kernel(const WgradParam
 // "second 16-channel block" of a transposing fragment read is simply the NEXT PIXEL: one 32-row A
 // operand carries the taps (ky, kx) and (ky, kx+1).  8 waves: wave -> (n-tile of 32 co, two ky rows),
 // 8 accumulator tiles each; workgroups walk many 8x32 pixel tiles and add their sums once.
+// CH = 8 (r04: the input packed to 8 channels, what the forward conv reads): 16 B per pixel, a 32-row A operand carries FOUR taps (kx .. kx + 3) x 8
+// channels -- 2 MFMAs per kernel row and pixel block instead of 4, 4 accumulator tiles per wave; the accumulator keeps its [tap][16][64] layout
+// (channels 8 .. 15 stay zero).
+template <int CH>
 __global__ void __launch_bounds__(512) conv7_wgrad_kernel(const bf16_t* __restrict__ x16, const bf16_t* __restrict__ dy, float* __restrict__ dw,
                                                           int B, int H, int W, int tiles_x, int tiles_y, float* __restrict__ dbias) {
     constexpr int XW = 40, XPIX = 14 * XW;                // 38 columns needed (+1 for the phantom tap kx = 7)
-    __shared__ __attribute__((aligned(16))) unsigned char xs[XPIX * 32];
+    constexpr int PB = CH * 2, UPP = PB / 16, TPF = 64 / PB, NK = 8 / TPF;      // bytes and 16-byte units per pixel; taps per A fragment; fragments per kernel row
+    __shared__ __attribute__((aligned(16))) unsigned char xs[XPIX * PB];
     __shared__ __attribute__((aligned(16))) unsigned char ys[256 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int nt = wave & 1, kg = wave >> 1;               // ky rows of this wave: kg and kg + 4 (kg + 4 < 7)
     const int tpi = tiles_x * tiles_y, ntiles = tpi * B;
     float bsum = 0.0f;
-    f32x16 acc[2][4];
+    f32x16 acc[2][NK];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < NK; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][k][r] = 0.0f;
     // One 8-wave workgroup per CU (170 registers): nothing else hides a tile's loads, so the tile of step t + 1 is fetched into registers
     // before the MFMAs of step t and written to LDS after them.
-    constexpr int XU = (XPIX * 2 + 511) / 512;             // 16-byte units of the halo tile per thread (3)
+    constexpr int XU = (XPIX * UPP + 511) / 512;           // 16-byte units of the halo tile per thread (3; CH = 8: 2)
+    // (Out-of-range rows are zeroed when the registers are written to LDS, from the bits of `okm`: a select right behind each load made the compiler
+    // wait for all seven before the MFMAs -- the prefetch hid nothing.)
     u32x4 xr[XU], yr[4];
+    unsigned okm = 0;
     auto fetch = [&](int t) {
+        okm = 0;
         const int b = t / tpi, t_in = t - b * tpi;
         const int oy0 = (t_in / tiles_x) * 8, ox0 = (t_in % tiles_x) * 32;
 #pragma unroll
         for (int k = 0; k < XU; ++k) {
-            const int i = min(tid + k * 512, XPIX * 2 - 1);
-            const int p = i >> 1, u = i & 1, ty = p / XW, tx = p - ty * XW;
+            const int i = min(tid + k * 512, XPIX * UPP - 1);
+            const int p = i / UPP, u = i % UPP, ty = p / XW, tx = p - ty * XW;
             const int iy = oy0 + ty - 3, ix = ox0 + tx - 3;
             const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-            u32x4 v = *(const u32x4*)(x16 + (((size_t)b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * 16 + u * 8);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
-            xr[k] = v;
+            xr[k] = *(const u32x4*)(x16 + (((size_t)b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * CH + u * 8);
+            okm |= (ok ? 1u : 0u) << k;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = tid + i * 512, p = id >> 3, c8 = id & 7;
             const int oy = oy0 + (p >> 5), ox = ox0 + (p & 31);
             const bool ok = oy < H && ox < W;
-            u32x4 v = *(const u32x4*)(dy + (((size_t)b * H + min(oy, H - 1)) * W + min(ox, W - 1)) * 64 + c8 * 8);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
-            yr[i] = v;
+            yr[i] = *(const u32x4*)(dy + (((size_t)b * H + min(oy, H - 1)) * W + min(ox, W - 1)) * 64 + c8 * 8);
+            okm |= (ok ? 1u : 0u) << (XU + i);
         }
     };
     if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
@@ -815,12 +820,12 @@ __global__ void __launch_bounds__(512) conv7_wgrad_kernel(const bf16_t* __restri
 #pragma unroll
         for (int k = 0; k < XU; ++k) {
             const int i = tid + k * 512;
-            if (i < XPIX * 2) *(u32x4*)(xs + (i >> 1) * 32 + (i & 1) * 16) = xr[k];
+            if (i < XPIX * UPP) *(u32x4*)(xs + (i / UPP) * PB + (i % UPP) * 16) = ((okm >> k) & 1u) ? xr[k] : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = tid + i * 512;
-            *(u32x4*)(ys + (id >> 3) * 128 + (id & 7) * 16) = yr[i];
+            *(u32x4*)(ys + (id >> 3) * 128 + (id & 7) * 16) = ((okm >> (XU + i)) & 1u) ? yr[i] : u32x4{0u, 0u, 0u, 0u};
         }
         __syncthreads();
         if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);      // (after the barrier: its fence would wait for the loads)
@@ -838,9 +843,9 @@ __global__ void __launch_bounds__(512) conv7_wgrad_kernel(const bf16_t* __restri
                     const int ky = kg + 4 * a;
                     if (ky < 7) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const bf16x8 xf = tr_frag(xs + ((r + ky) * XW + xb * 16 + 2 * k) * 32, 32, lane);
-                            acc[a][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yf, acc[a][k], 0, 0, 0);   // rows = (tap kx|kx+1, ci), cols = co
+                        for (int k = 0; k < NK; ++k) {
+                            const bf16x8 xf = tr_frag(xs + ((r + ky) * XW + xb * 16 + TPF * k) * PB, PB, lane);
+                            acc[a][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yf, acc[a][k], 0, 0, 0);   // rows = (tap kx .. kx + TPF - 1, ci), cols = co
                         }
                     }
                 }
@@ -852,10 +857,10 @@ __global__ void __launch_bounds__(512) conv7_wgrad_kernel(const bf16_t* __restri
         const int ky = kg + 4 * a;
         if (ky >= 7) continue;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < NK; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * half, kx = 2 * k + (m >> 4), ci = m & 15;
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * half, kx = TPF * k + m / CH, ci = m % CH;
                 if (kx < 7) gacc_add(dw + ((size_t)(ky * 7 + kx) * 16 + ci) * 64 + nt * 32 + l31, acc[a][k][r]);
             }
     }
@@ -1166,11 +1171,15 @@ int k_conv_wgrad(const ofd_conv_args* a, const bf16_t* dy, float* dw, hipStream_
     return OFD_OK;
 }
 
-int k_conv7_wgrad(const bf16_t* x16, const bf16_t* dy, float* dw, int B, int H, int W, hipStream_t s, float* dbias) {
+int k_conv7_wgrad(const bf16_t* x16, const bf16_t* dy, float* dw, int B, int H, int W, hipStream_t s, float* dbias, int channels) {
     const int tx = cdiv(W, 32), ty = cdiv(H, 8);
+    OFD_CHECK_ARG(channels == 16 || channels == 8, "conv7_wgrad: input packed to %d channels", channels);
+    static const int grid_env = getenv("OFD_CONV7_WGRAD_GRID") ? atoi(getenv("OFD_CONV7_WGRAD_GRID")) : 0;
     int grid = tx * ty * B;
-    if (grid > 768) grid = 768;
-    conv7_wgrad_kernel<<<grid, 512, 0, s>>>(x16, dy, dw, B, H, W, tx, ty, dbias);
+    const int cap = grid_env > 0 ? grid_env : (channels == 8 ? 512 : 768);       // (the 8-channel form: two workgroups per CU at 128 registers, all resident: 0.45 ms at 512, 0.47 at 768, 0.58 at 1024)
+    if (grid > cap) grid = cap;
+    if (channels == 8) conv7_wgrad_kernel<8><<<grid, 512, 0, s>>>(x16, dy, dw, B, H, W, tx, ty, dbias);
+    else conv7_wgrad_kernel<16><<<grid, 512, 0, s>>>(x16, dy, dw, B, H, W, tx, ty, dbias);
     OFD_LAUNCH_CHECK();
     return OFD_OK;
 }
@@ -1227,7 +1236,7 @@ extern "C" int ofd_conv_wgrad(const ofd_conv_args* fwd, const void* dy, float* d
 }
 extern "C" int ofd_conv7_wgrad(const void* x16, const void* dy, float* dw_acc, int B, int H, int W, void* stream) {
     OFD_CHECK_ARG(x16 && dy && dw_acc, "conv7_wgrad: null argument");
-    return k_conv7_wgrad((const bf16_t*)x16, (const bf16_t*)dy, dw_acc, B, H, W, (hipStream_t)stream, nullptr);
+    return k_conv7_wgrad((const bf16_t*)x16, (const bf16_t*)dy, dw_acc, B, H, W, (hipStream_t)stream, nullptr, 16);
 }
 extern "C" int ofd_conv_wgrad_finish(const float* dw_acc, const float* w_oihw, float* dst_oihw, int Cout, int Cin, int Cin_pad, int ksize,
                                      float ws_eps, int unshuffle, int accumulate, void* stream) {

@@ -376,16 +376,14 @@ int run_forward(Ctx& c, const float* x, int Cx, const float* cond, int Cc, const
     u->last_B = B;
     if (c.train) u->tape.clear();
     // <= 8 input channels: 8-channel packing, the 7x7 pairs horizontally adjacent taps into one k-step (conv_igemm.hip Cfg::K7P).
-    // Training packs the input twice: the forward conv reads the 8-channel tensor, the tape keeps the 16-channel one its weight-gradient
-    // kernel reads (conv_bwd.hip conv7_wgrad_kernel).
+    // Training keeps the same 8-channel tensor on the tape: its weight-gradient kernel reads either packing (conv_bwd.hip conv7_wgrad_kernel<8>;
+    // r04: the 16-channel copy and its pack pass are gone).
     static const bool no_pack8 = getenv("OFD_NO_CONV7_PACK8") && atoi(getenv("OFD_NO_CONV7_PACK8"));
     const bool pack8 = !no_pack8 && u->convs[u->cindex.at("init_conv")].pack8_off >= 0;
-    const int cpad = (!c.train && pack8) ? 8 : 16;
+    const int cpad = pack8 ? 8 : 16;
     Tensor xin = c.keep(cpad, H, W);
-    Tensor xin8 = (c.train && pack8) ? c.tmp(8, H, W) : xin;
     c.begin(PC_MISC, 0, 0);
     RUN(k_pack_input(x, Cx, cond, cond ? Cc : 0, xin.p, B, H, W, c.s, cpad));
-    if (c.train && pack8) RUN(k_pack_input(x, Cx, cond, cond ? Cc : 0, xin8.p, B, H, W, c.s, 8));
     if (!u->cfg.no_time) {
         RUN(k_time_mlp(t, u->P("time_mlp.1.weight"), u->P("time_mlp.1.bias"), u->P("time_mlp.3.weight"), u->P("time_mlp.3.bias"), temb, temb_silu, B, dim, c.s));
         RUN(k_block_mlp(temb_silu, u->d_mlp, (int)u->resblocks.size(), c.ss, B, dim * 4, u->ss_stride, c.s));
@@ -394,16 +392,7 @@ int run_forward(Ctx& c, const float* x, int Cx, const float* cond, int Cc, const
     }
     c.end();
     Tensor r = c.keep(dim, H, W);
-    if (c.train && pack8) {
-        SrcSpec s8; s8.t = xin8;
-        conv(c, "init_conv", {s8}, r, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-        SrcSpec s16; s16.t = xin;
-        TapeRec rec;
-        rec.kind = TK_CONV; rec.name = "init_conv"; rec.srcs = {s16}; rec.out = r;
-        u->tape.push_back(rec);
-    } else {
-        SrcSpec s; s.t = xin; plain_conv(c, "init_conv", {s}, r);
-    }
+    { SrcSpec s; s.t = xin; plain_conv(c, "init_conv", {s}, r); }
     u->taps["init_conv"] = r;
 
     Tensor xcur = r;

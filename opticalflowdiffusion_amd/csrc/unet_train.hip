@@ -115,7 +115,7 @@ static Tensor conv_backward(Bwd& b, const std::string& prefix, const std::vector
     (void)nacc;
     c.begin(d.ksize == 3 ? PC_WGRAD3 : PC_WGRAD1, 2.0 * px * d.Cout * (double)d.Cin * taps, px * 2.0 * (d.Cout + cin), prefix + " wgrad");
     if (d.ksize == 7) {
-        RUN(k_conv7_wgrad(srcs[0].t.p, dy, acc, B, H, W, c.s, gb));
+        RUN(k_conv7_wgrad(srcs[0].t.p, dy, acc, B, H, W, c.s, gb, srcs[0].t.C));
     } else {
         ofd_conv_args a{};
         fill_args(a, B, H, W, d.ksize, d.Cout, srcs);
